@@ -1,0 +1,157 @@
+/* ssn.h - C ABI of libssn_hip.so: the MI355X (gfx950) step-loop backend for SSP-SLAM spiking networks.
+ *
+ * Drop-in boundary.  The reference has no FFI of its own: its hot path is the
+ * Python call  `sim = nengo.Simulator(model); with sim: sim.run(T); sim.data[probe]`
+ * (reference experiments/run_pathint.py:147-165,171-181; experiments/run_slam.py:198-235,250-268),
+ * whose per-timestep arithmetic is executed by the third-party `nengo` / `nengo_ocl` simulators.
+ * This library replaces that simulator core.  A thin ctypes wrapper (sspslam_amd/simulator.py)
+ * exposes the same Simulator API on top of the entry points below; each entry point names the
+ * Simulator member it serves.
+ *
+ * Model = one flat signal vector + parameter/state buffers + an ordered operator list (the frozen
+ * "BuiltModel", produced on the host by sspslam_amd/builder.py).  All host arrays are float64 (or
+ * int32 for index buffers), borrowed for the duration of the call only and converted to the
+ * simulator's arithmetic type on upload.  The library owns all device memory.
+ *
+ * Every call returns SSN_OK (0) or a negative error code; ssn_last_error() gives the message
+ * (thread-local).  One host thread drives a simulator; nothing calls back into the host during
+ * ssn_run_steps.
+ */
+#ifndef SSN_H
+#define SSN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSN_ABI_VERSION 1
+
+enum ssn_status {
+  SSN_OK = 0,
+  SSN_EINVAL = -1,        /* bad argument / inconsistent model description        */
+  SSN_EHIP = -2,          /* a HIP runtime call failed (message has the HIP error) */
+  SSN_ERCCL = -3,         /* reserved                                             */
+  SSN_ENOMEM = -4,        /* host or device allocation failed                     */
+  SSN_EUNSUPPORTED = -5   /* operator shape outside what the kernels implement    */
+};
+
+enum ssn_dtype { SSN_F32 = 0, SSN_F64 = 1 };           /* arithmetic + state type of a simulator   */
+enum ssn_buffer_kind { SSN_BUF_REAL = 0, SSN_BUF_I32 = 1 };
+enum ssn_neuron { SSN_LIF = 0, SSN_LIFRATE = 1, SSN_RELU = 2 };
+
+/* Operator kinds; field use per kind is listed next to ssn_op_desc. */
+enum ssn_op_kind {
+  SSN_OP_FILL = 1, SSN_OP_TABLE = 2, SSN_OP_AXPY = 3, SSN_OP_MATVEC = 4, SSN_OP_LOWPASS = 5,
+  SSN_OP_ENSARRAY = 6, SSN_OP_NEURONS = 7, SSN_OP_PES = 8, SSN_OP_VOJA = 9, SSN_OP_CLEANUP = 10,
+  SSN_OP_GATE = 11
+};
+
+typedef struct ssn_buffer_desc {
+  const void* data;     /* float64 (SSN_BUF_REAL) or int32 (SSN_BUF_I32) host array, C order */
+  int64_t count;        /* number of elements                                               */
+  int32_t kind;         /* ssn_buffer_kind                                                  */
+  int32_t reserved;
+} ssn_buffer_desc;
+
+/* One operator.  Offsets are element offsets into the signal vector; "buf" = index into buffers[].
+ *  FILL     i0 dst  i1 len                                  f0 value
+ *  TABLE    i0 dst  i1 width i2 table_id                                      (ssn_set_table)
+ *  AXPY     i0 dst  i1 src   i2 len  i3 mode(0 inc,1 set)   f0 alpha
+ *  MATVEC   i0 dst  i1 src   i2 rows i3 cols i4 W buf i5 mode                 W is rows x cols
+ *  LOWPASS  i0 dst  i1 src   i2 len                         f0 a  f1 gain     dst=a*dst+(1-a)*gain*src
+ *  ENSARRAY i0 x    i1 K i2 n i3 din i4 dout i5 enc buf [K][din][n] i6 bias buf [K][n]
+ *           i7 dec buf [K][dout][n] i8 dst_idx buf (int32 [K][dout]) i9 V buf i10 R buf
+ *           i11 neuron                                      f0 tau_rc f1 tau_ref f2 min_voltage
+ *  NEURONS  i0 J    i1 out   i2 n i3 V buf i4 R buf i5 neuron  f0 tau_rc f1 tau_ref f2 min_voltage f3 amp
+ *  PES      i0 W buf i1 rows i2 cols i3 err i4 act          f0 kappa          W += kappa*outer(err,act)
+ *  VOJA     i0 E buf i1 rows i2 cols i3 spk i4 key i5 learn i6 scale buf  f0 lr*dt
+ *  CLEANUP  i0 dst  i1 src   i2 rows i3 cols i4 table buf                     dst = T[argmax(T@src)]
+ *  GATE     i0 dst  i1 src   i2 d                           f0 thres f1 rate  (reference slam.py:233-237)
+ * level: scheduling round from the host builder; vector ops of equal level touch disjoint data. */
+typedef struct ssn_op_desc {
+  int32_t kind;
+  int32_t level;
+  int64_t i[12];
+  double f[4];
+} ssn_op_desc;
+
+typedef struct ssn_probe_desc {
+  int64_t src;          /* signal offset  */
+  int64_t width;
+  int64_t every;        /* sample when (step % every) == 0, steps counted from 1 */
+} ssn_probe_desc;
+
+typedef struct ssn_model_desc {
+  int32_t abi_version;  /* SSN_ABI_VERSION */
+  int32_t dtype;        /* ssn_dtype       */
+  int32_t device;       /* HIP device index */
+  int32_t n_tables;
+  double dt;
+  int64_t n_signals;
+  const double* signal_init;          /* n_signals values */
+  int32_t n_buffers;
+  int32_t n_ops;
+  int32_t n_probes;
+  int32_t steps_per_graph;            /* timesteps captured per hipGraph; 0 = library default */
+  const ssn_buffer_desc* buffers;
+  const ssn_op_desc* ops;
+  const ssn_probe_desc* probes;
+} ssn_model_desc;
+
+typedef struct ssn_counters {
+  int64_t n_steps;                  /* steps executed since create/reset                          */
+  int64_t launches_per_step;        /* kernel launches in one timestep                            */
+  int64_t dominant_launches;        /* timed launches of the dominant (ensemble-array) kernel      */
+  double dominant_ms_total;         /* sum of their durations, HIP events on the launching stream */
+  double dominant_bytes_per_launch; /* algorithmic bytes of one such launch           */
+  int64_t dominant_units_per_launch;/* neuron-steps per launch                                    */
+  double last_run_ms;               /* device time of the last ssn_run_steps (events)             */
+  int64_t device_bytes;             /* device memory held by this simulator                       */
+} ssn_counters;
+
+typedef struct ssn_sim ssn_sim;
+
+/* Simulator(network): upload the built model, plan kernels, capture the step graph. */
+int ssn_create(const ssn_model_desc* desc, ssn_sim** out);
+/* Simulator.close() / __exit__ */
+void ssn_destroy(ssn_sim* sim);
+/* Simulator.reset(): restore initial signals, neuron state and learned buffers; step = 0. */
+int ssn_reset(ssn_sim* sim);
+
+/* Pre-tabulated output of a t-only Node (the host evaluates the user's closure once per step of
+ * the coming run): rows[n_rows][width] unique rows, idx[n_idx] row per step (-1 = zeros) for steps
+ * first_step .. first_step+n_idx-1 (0-based).  Serves Node(lambda t: ...) at run_pathint.py:134-136. */
+int ssn_set_table(ssn_sim* sim, int32_t table_id, const double* rows, int64_t n_rows, int64_t width,
+                  const int32_t* idx, int64_t n_idx, int64_t first_step);
+/* Same, rows already on the device in the simulator's dtype (multi-GPU exchange path). */
+int ssn_set_table_device(ssn_sim* sim, int32_t table_id, const void* rows_dev, int64_t n_rows,
+                         int64_t width, const int32_t* idx, int64_t n_idx, int64_t first_step);
+
+/* Make room for the probe samples of the next n_steps (drops samples already read). */
+int ssn_reserve_probes(ssn_sim* sim, int64_t n_steps);
+/* Simulator.run_steps(n): blocking. profile != 0 times every dominant-kernel launch with events. */
+int ssn_run_steps(ssn_sim* sim, int64_t n, int32_t profile);
+/* Simulator.data[probe]: samples [first, first+count) of the current reservation -> dst[count][width]. */
+int ssn_read_probe(ssn_sim* sim, int32_t probe_id, double* dst, int64_t first, int64_t count);
+/* Same into device memory (simulator dtype), no host round trip. */
+int ssn_read_probe_device(ssn_sim* sim, int32_t probe_id, void* dst_dev, int64_t first, int64_t count);
+int64_t ssn_probe_count(ssn_sim* sim, int32_t probe_id);
+
+/* Signals and buffers (learned weights, encoders, neuron state): checkpointing, tests, weight probes. */
+int ssn_read_signal(ssn_sim* sim, int64_t off, int64_t count, double* dst);
+int ssn_write_signal(ssn_sim* sim, int64_t off, int64_t count, const double* src);
+int ssn_read_buffer(ssn_sim* sim, int32_t buffer_id, double* dst, int64_t count);
+int ssn_write_buffer(ssn_sim* sim, int32_t buffer_id, const double* src, int64_t count);
+
+int ssn_get_counters(ssn_sim* sim, ssn_counters* out);
+int64_t ssn_n_steps(ssn_sim* sim);
+int ssn_device_count(void);
+const char* ssn_last_error(void);
+const char* ssn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSN_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of ``libssn_hip.so`` (C ABI in ``include/ssn.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C csrc``.  There is no CPU
+fallback: if the shared object is missing or cannot be loaded, ``load()`` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssn_hip.so")
+
+SSN_ABI_VERSION = 1
+SSN_F32, SSN_F64 = 0, 1
+SSN_BUF_REAL, SSN_BUF_I32 = 0, 1
+NEURON_CODE = {"lif": 0, "lifrate": 1, "relu": 2}
+OP_CODE = {"fill": 1, "table": 2, "axpy": 3, "matvec": 4, "lowpass": 5, "ensarray": 6, "neurons": 7,
+           "pes": 8, "voja": 9, "cleanup": 10, "gate": 11}
+STATUS = {0: "SSN_OK", -1: "SSN_EINVAL", -2: "SSN_EHIP", -3: "SSN_ERCCL", -4: "SSN_ENOMEM", -5: "SSN_EUNSUPPORTED"}
+
+
+class BufferDesc(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("count", C.c_int64), ("kind", C.c_int32), ("reserved", C.c_int32)]
+
+
+class OpDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("level", C.c_int32), ("i", C.c_int64 * 12), ("f", C.c_double * 4)]
+
+
+class ProbeDesc(C.Structure):
+    _fields_ = [("src", C.c_int64), ("width", C.c_int64), ("every", C.c_int64)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("dtype", C.c_int32), ("device", C.c_int32), ("n_tables", C.c_int32),
+                ("dt", C.c_double), ("n_signals", C.c_int64), ("signal_init", C.POINTER(C.c_double)),
+                ("n_buffers", C.c_int32), ("n_ops", C.c_int32), ("n_probes", C.c_int32),
+                ("steps_per_graph", C.c_int32), ("buffers", C.POINTER(BufferDesc)), ("ops", C.POINTER(OpDesc)),
+                ("probes", C.POINTER(ProbeDesc))]
+
+
+class Counters(C.Structure):
+    _fields_ = [("n_steps", C.c_int64), ("launches_per_step", C.c_int64), ("dominant_launches", C.c_int64),
+                ("dominant_ms_total", C.c_double), ("dominant_bytes_per_launch", C.c_double),
+                ("dominant_units_per_launch", C.c_int64), ("last_run_ms", C.c_double), ("device_bytes", C.c_int64)]
+
+
+EXPORTS = {
+    "ssn_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
+    "ssn_destroy": (None, [C.c_void_p]),
+    "ssn_reset": (C.c_int, [C.c_void_p]),
+    "ssn_set_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64]),
+    "ssn_set_table_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64]),
+    "ssn_reserve_probes": (C.c_int, [C.c_void_p, C.c_int64]),
+    "ssn_run_steps": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32]),
+    "ssn_read_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64]),
+    "ssn_read_probe_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64]),
+    "ssn_probe_count": (C.c_int64, [C.c_void_p, C.c_int32]),
+    "ssn_read_signal": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "ssn_write_signal": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "ssn_read_buffer": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
+    "ssn_write_buffer": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
+    "ssn_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
+    "ssn_n_steps": (C.c_int64, [C.c_void_p]),
+    "ssn_device_count": (C.c_int, []),
+    "ssn_last_error": (C.c_char_p, []),
+    "ssn_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libssn_hip.so and declare every entry point of include/ssn.h.  Raises if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C semantic-spiking-neural-slam-2023_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().ssn_last_error().decode("utf-8", "replace")

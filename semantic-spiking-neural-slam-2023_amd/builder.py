@@ -1,0 +1,884 @@
+"""Network -> BuiltModel: the frozen, flat operator list both the HIP backend and the oracle run.
+
+nengo separates *build* (sampling + least squares -> arrays) from *step* (arithmetic on those
+arrays).  This module is the build half for the object kinds the SLAM networks use:
+it samples ensemble parameters (Appendix A.3), solves decoders (A.5), lowers every Connection to
+operators on one flat signal vector, merges the thousands of per-ensemble operators of an
+``EnsembleArray`` into a handful of wide ones (nengo's operator-merge pass, A.12) and orders them
+by nengo's per-signal rule *sets -> incs -> reads -> updates* (A.1).
+
+Signals live in one flat vector, laid out in arenas so that a single fill resets every
+accumulator:  R (reset to 0 each step: node / ensemble inputs, neuron currents) | W (written each
+step: decoded "weighted" outputs, function-node outputs, spikes) | S (persistent synapse states) |
+C (constants) | T (tabulated t-only node outputs).
+
+Operator kinds (dict ``kind``):
+  fill      sig[dst:dst+len] = value
+  table     sig[dst:dst+width] = rows[idx[step]]           (t-only Node, pre-tabulated per run)
+  axpy      dst (+)= alpha * src                           (mode "inc" | "set")
+  matvec    dst (+)= W[rows x cols] @ src                  (W is a buffer; mode "inc" | "set")
+  lowpass   dst = a*dst + (1-a)*gain*src                   (Appendix A.6, an *update*)
+  ensarray  K equal ensembles: J = bias + enc.x ; neuron step ; decoded rows -> sig[dst_idx]
+  neurons   neuron step on a current vector J -> spike vector
+  pes / voja / cleanup / gate                              (SLAM; Appendix A.7, A.8, slam.py:212-237)
+"""
+import math
+import time
+
+import numpy as np
+
+from . import frontend as fe
+from .solvers import solve_decoders
+
+MICRO_KINDS = ("fill", "table", "axpy", "lowpass", "matvec_small", "gate")
+
+
+# --------------------------------------------------------------------------------------------
+class Ref:
+    """A contiguous range inside one arena (resolved to an absolute offset at finalisation)."""
+    __slots__ = ("arena", "off", "len")
+
+    def __init__(self, arena, off, length):
+        self.arena, self.off, self.len = arena, int(off), int(length)
+
+    def slice(self, start, length):
+        if start < 0 or start + length > self.len:
+            raise fe.BuildError(f"slice [{start}:{start + length}] outside signal of size {self.len}")
+        return Ref(self.arena, self.off + start, length)
+
+    def __repr__(self):
+        return f"{self.arena}[{self.off}:{self.off + self.len}]"
+
+
+class BuiltEnsemble:
+    """``sim.data[ens]`` (run_slam.py:266): the sampled / derived parameters of one ensemble."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class BuiltConnection:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class BuiltModel:
+    def __init__(self, dt):
+        self.dt = float(dt)
+        self.sig_size = 0
+        self.sig_init = None
+        self.arena_base = {}
+        self.buffers = []        # np.ndarray (float64 or int32)
+        self.buffer_meta = []    # {"name", "role": param|state|learned|table|index}
+        self.ops = []
+        self.probes = []         # {"probe", "src", "width", "every"} | {"probe","buf",...}
+        self.tables = []         # {"node","fn","width","rows_buf","idx_buf"}
+        self.params = {}         # frontend object -> Built*
+        self.sig = {}            # (obj, "in"|"out"|...) -> (abs_off, len)
+        self.stats = {}
+        self.label = None
+
+    def add_buffer(self, arr, name, role="param"):
+        self.buffers.append(arr)
+        self.buffer_meta.append({"name": name, "role": role})
+        return len(self.buffers) - 1
+
+    @property
+    def n_neurons(self):
+        return self.stats.get("n_neurons", 0)
+
+
+# --------------------------------------------------------------------------------------------
+def _contig(view_or_obj):
+    """(object, start, length) for an object or a contiguous ObjView."""
+    if hasattr(view_or_obj, "obj") and hasattr(view_or_obj, "slice"):
+        if hasattr(view_or_obj, "indices"):
+            idx = np.asarray(view_or_obj.indices)
+        else:  # foreign ObjView
+            size = max(view_or_obj.obj.size_in, view_or_obj.obj.size_out)
+            idx = np.atleast_1d(np.arange(size)[view_or_obj.slice])
+        if idx.size == 0 or np.any(np.diff(idx) != 1):
+            raise fe.BuildError(f"only contiguous ascending slices are supported, got {view_or_obj!r}")
+        return view_or_obj.obj, int(idx[0]), int(idx.size)
+    return view_or_obj, 0, None
+
+
+def _kind(obj):
+    n = type(obj).__name__
+    if isinstance(obj, fe.Node) or n == "Node":
+        return "node"
+    if isinstance(obj, fe.Ensemble) or n == "Ensemble":
+        return "ensemble"
+    if isinstance(obj, fe.Neurons) or n == "Neurons":
+        return "neurons"
+    if isinstance(obj, fe.LearningRule) or n == "LearningRule":
+        return "rule"
+    if isinstance(obj, fe.Connection) or n == "Connection":
+        return "connection"
+    raise fe.BuildError(f"unsupported object {obj!r}")
+
+
+def _neuron_desc(nt):
+    n = type(nt).__name__
+    if n == "LIF":
+        return dict(type="lif", tau_rc=float(nt.tau_rc), tau_ref=float(nt.tau_ref),
+                    min_voltage=float(getattr(nt, "min_voltage", 0.0)), amplitude=float(getattr(nt, "amplitude", 1.0)))
+    if n == "LIFRate":
+        return dict(type="lifrate", tau_rc=float(nt.tau_rc), tau_ref=float(nt.tau_ref), min_voltage=0.0,
+                    amplitude=float(getattr(nt, "amplitude", 1.0)))
+    if n == "RectifiedLinear":
+        return dict(type="relu", tau_rc=0.0, tau_ref=0.0, min_voltage=0.0, amplitude=float(getattr(nt, "amplitude", 1.0)))
+    raise fe.BuildError(f"unsupported neuron type {nt!r} (lif, lifrate, relu are available)")
+
+
+def _sample(dist_or_vals, n, d, rng, default):
+    v = default if (dist_or_vals is fe.Default or type(dist_or_vals).__name__ == "DefaultType") else dist_or_vals
+    if hasattr(v, "sample"):
+        return np.asarray(v.sample(n, d, rng=rng) if d is not None else v.sample(n, rng=rng), dtype=float)
+    return np.array(v, dtype=float)
+
+
+def _lowpass_coeff(tau, dt):
+    return math.exp(-dt / tau) if tau > 0 else 0.0
+
+
+# --------------------------------------------------------------------------------------------
+class Builder:
+    def __init__(self, network, dt=0.001, seed=None, n_eval_points=None, solver_backend="auto",
+                 vco_shard=None, progress=None):
+        self.net, self.dt = network, float(dt)
+        self.n_eval_points = n_eval_points
+        self.solver_backend = solver_backend
+        self.vco_shard = vco_shard           # (rank, world): build only this rank's slice of every EnsembleArray
+        self.progress = progress
+        self.model = BuiltModel(dt)
+        self.arena_size = {a: 0 for a in "RWSCT"}
+        self.inits = []                      # (Ref, values)
+        self.raw_ops = []
+        self.seed_of = {}
+        root = getattr(network, "seed", None)
+        if root is None:
+            root = seed if seed is not None else np.random.randint(2 ** 31 - 1)
+        self.root_seed = int(root)
+
+    # -- allocation ------------------------------------------------------------------------
+    def alloc(self, arena, size, init=None):
+        r = Ref(arena, self.arena_size[arena], size)
+        self.arena_size[arena] += int(size)
+        if init is not None:
+            self.inits.append((r, np.asarray(init, dtype=float).reshape(-1)))
+        return r
+
+    def op(self, kind, **kw):
+        kw["kind"] = kind
+        kw["seq"] = len(self.raw_ops)
+        self.raw_ops.append(kw)
+        return kw
+
+    # -- build -----------------------------------------------------------------------------
+    def build(self):
+        t0 = time.time()
+        net = self.net
+        ensembles = list(net.all_ensembles)
+        nodes = list(net.all_nodes)
+        conns = list(net.all_connections)
+        probes = list(net.all_probes)
+        rng = np.random.RandomState(self.root_seed)
+        for obj in ensembles + nodes + conns + probes:
+            s = getattr(obj, "seed", None)
+            self.seed_of[id(obj)] = int(s) if s is not None else int(rng.randint(2 ** 31 - 1))
+
+        # ensemble-array blocks (equal ensembles stepped by one kernel)
+        self.block_of = {}
+        self.blocks = []
+        for sub in ([net] + list(net.all_networks)):
+            eas = getattr(sub, "ea_ensembles", None)
+            if not eas:
+                continue
+            e0 = eas[0]
+            same = all(e.n_neurons == e0.n_neurons and e.dimensions == e0.dimensions
+                       and _neuron_desc(e.neuron_type) == _neuron_desc(e0.neuron_type) for e in eas)
+            if not same:
+                continue
+            lo, hi = 0, len(eas)
+            if self.vco_shard is not None:
+                rank, world = self.vco_shard
+                per = -(-len(eas) // world)
+                lo, hi = min(len(eas), rank * per), min(len(eas), (rank + 1) * per)
+            blk = {"net": sub, "ens": list(eas), "rows": [[] for _ in eas], "range": (lo, hi)}
+            self.blocks.append(blk)
+            for i, e in enumerate(eas):
+                self.block_of[id(e)] = (blk, i)
+
+        # signals for ensembles and nodes
+        self.ens_in, self.ens_J, self.ens_spk, self.node_in, self.node_out = {}, {}, {}, {}, {}
+        self.dense_rows = {}
+        for blk in self.blocks:
+            e0 = blk["ens"][0]
+            blk["x"] = self.alloc("R", len(blk["ens"]) * e0.dimensions)
+            for i, e in enumerate(blk["ens"]):
+                self.ens_in[id(e)] = blk["x"].slice(i * e0.dimensions, e0.dimensions)
+        for e in ensembles:
+            if id(e) in self.block_of:
+                continue
+            self.ens_in[id(e)] = self.alloc("R", e.dimensions)
+            self.ens_J[id(e)] = self.alloc("R", e.n_neurons)
+            self.ens_spk[id(e)] = self.alloc("W", e.n_neurons)
+            self.dense_rows[id(e)] = []
+        for n in nodes:
+            self._alloc_node(n)
+
+        self.built_ens = {}
+        self.rule_in = {}
+        self.learned = {}
+        self.pending = {}        # id(ensemble) -> [(conn-like, pre_start, pre_len, transform, callback)]
+        # parameters of every ensemble (cheap, vectorised); decoders are solved on demand
+        for e in ensembles:
+            self._build_ensemble_params(e)
+        for c in conns:
+            self._lower_connection(c)
+        for p in probes:
+            self._lower_probe(p)
+        for e in ensembles:
+            self._solve_pending(e)
+        for e in ensembles:
+            if id(e) not in self.block_of:
+                self._emit_dense_ensemble(e)
+        for blk in self.blocks:
+            self._emit_block(blk)
+        self._finalise()
+        self.model.stats["build_seconds"] = time.time() - t0
+        self.model.stats["n_neurons"] = int(sum(e.n_neurons for e in ensembles))
+        return self.model
+
+    # -- nodes -----------------------------------------------------------------------------
+    def _alloc_node(self, n):
+        out = getattr(n, "output", None)
+        if out is None:
+            r = self.alloc("R", n.size_in)
+            self.node_in[id(n)] = r
+            self.node_out[id(n)] = r
+        elif callable(out) and n.size_in == 0:
+            r = self.alloc("T", n.size_out)
+            self.node_out[id(n)] = r
+            self.model.tables.append({"node": n, "fn": out, "width": n.size_out, "ref": r})
+            self.op("table", dst=r, width=n.size_out, table=len(self.model.tables) - 1)
+        elif callable(out):
+            rin = self.alloc("R", n.size_in)
+            rout = self.alloc("W", n.size_out)
+            self.node_in[id(n)], self.node_out[id(n)] = rin, rout
+            native = getattr(n, "native", None)
+            if native is None:
+                native = self._probe_function_node(n)
+            if native[0] == "identity":
+                self.op("axpy", dst=rout, src=rin, len=n.size_in, alpha=1.0, mode="set")
+            elif native[0] == "cleanup":
+                table = np.ascontiguousarray(native[1], dtype=float)
+                b = self.model.add_buffer(table, f"cleanup_table_{len(self.model.buffers)}")
+                self.op("cleanup", dst=rout, src=rin, rows=table.shape[0], cols=table.shape[1], w=b)
+            elif native[0] == "gate":
+                _, d, thres, rate = native
+                self.op("gate", dst=rout, src=rin, d=int(d), thres=float(thres), rate=float(rate))
+            else:
+                raise fe.BuildError(f"unknown native node op {native[0]!r}")
+        else:
+            vals = np.asarray(out, dtype=float).reshape(-1)
+            self.node_out[id(n)] = self.alloc("C", vals.size, init=vals)
+
+    def _probe_function_node(self, n):
+        """A Python function node with inputs must map to a kernel; recognise the identity."""
+        rs = np.random.RandomState(0)
+        try:
+            ok = all(np.array_equal(np.asarray(n.output(0.01 * (i + 1), x)), x)
+                     for i, x in enumerate(rs.randn(3, n.size_in)))
+        except Exception:
+            ok = False
+        if ok and n.size_in == n.size_out:
+            return ("identity",)
+        raise fe.BuildError(
+            f"{n!r}: Python function nodes with inputs cannot run inside the device step loop; "
+            "tag the node with node.native = ('identity',) | ('cleanup', table) | ('gate', d, thres, rate)")
+
+    # -- ensembles -------------------------------------------------------------------------
+    def _build_ensemble_params(self, e):
+        rng = np.random.RandomState(self.seed_of[id(e)])
+        n, d = e.n_neurons, e.dimensions
+        nd = _neuron_desc(e.neuron_type)
+        enc = _sample(e.encoders, n, d, rng, fe.ScatteredHypersphere(surface=True))
+        if enc.shape != (n, d):
+            raise fe.BuildError(f"{e!r}: encoders must be ({n}, {d}), got {enc.shape}")
+        if getattr(e, "normalize_encoders", True):
+            enc = enc / np.linalg.norm(enc, axis=1, keepdims=True)
+        max_rates = _sample(e.max_rates, n, None, rng, fe.Uniform(200, 400)).reshape(-1)
+        intercepts = _sample(e.intercepts, n, None, rng, fe.Uniform(-1.0, 0.9)).reshape(-1)
+        if max_rates.size != n or intercepts.size != n:
+            raise fe.BuildError(f"{e!r}: max_rates / intercepts must have {n} entries")
+        gain_given = getattr(e, "gain", fe.Default)
+        if gain_given is not fe.Default and gain_given is not None and type(gain_given).__name__ != "DefaultType":
+            gain = np.asarray(gain_given, dtype=float)
+            bias = np.asarray(e.bias, dtype=float)
+        else:
+            gain, bias = e.neuron_type.gain_bias(max_rates, intercepts)
+        scaled = enc * (gain / e.radius)[:, None]
+        self.built_ens[id(e)] = be = BuiltEnsemble(
+            encoders=enc, scaled_encoders=scaled, gain=gain, bias=bias, max_rates=max_rates,
+            intercepts=intercepts, eval_points=None, neuron=nd, radius=float(e.radius),
+            seed=self.seed_of[id(e)], decoder_cache={})
+        self.model.params[e] = be
+
+    def _eval_points(self, e, conn_eval_points=None):
+        be = self.built_ens[id(e)]
+        if conn_eval_points is not None:
+            return np.asarray(conn_eval_points, dtype=float)
+        if be.eval_points is None:
+            rng = np.random.RandomState(be.seed ^ 0x5EED)
+            given = getattr(e, "eval_points", fe.Default)
+            if given is not fe.Default and type(given).__name__ != "DefaultType" and not hasattr(given, "sample"):
+                be.eval_points = np.asarray(given, dtype=float)
+            else:
+                m = getattr(e, "n_eval_points", fe.Default)
+                if m is fe.Default or m is None or type(m).__name__ == "DefaultType":
+                    m = self.n_eval_points
+                if m is None:
+                    m = max(int(np.clip(500 * e.dimensions, 750, 2500)), 2 * e.n_neurons)
+                dist = given if hasattr(given, "sample") else fe.ScatteredHypersphere(surface=False)
+                be.eval_points = np.asarray(dist.sample(int(m), e.dimensions, rng=rng)) * e.radius
+        return be.eval_points
+
+    def _request_decoders(self, conn, e, pre_start, pre_len, T, callback):
+        """Queue ``callback(W)`` with ``W = T @ decoders(conn.function)`` (size_out, n): all decoded
+        connections of one ensemble are solved together from a single factorisation."""
+        self.pending.setdefault(id(e), []).append((conn, pre_start, pre_len, T, callback))
+
+    def _targets(self, conn, X, pre_start, pre_len):
+        fn = conn.function
+        Xs = X[:, pre_start:pre_start + pre_len]
+        if fn is None:
+            return Xs
+        if hasattr(fn, "batch"):
+            Y = np.asarray(fn.batch(Xs), dtype=float)
+        else:
+            Y = np.stack([np.asarray(fn(x), dtype=float).reshape(-1) for x in Xs])
+        return Y.reshape(X.shape[0], -1)
+
+    def _solve_pending(self, e):
+        items = self.pending.pop(id(e), [])
+        if not items:
+            return
+        be = self.built_ens[id(e)]
+        groups = {}
+        for it in items:
+            conn = it[0]
+            solver = conn.solver
+            sname = type(solver).__name__
+            if getattr(solver, "weights", False):
+                raise fe.BuildError("weight solvers are not supported")
+            if sname == "NoSolver":
+                vals = getattr(solver, "values", None)
+                D = np.zeros((conn.size_mid, e.n_neurons)) if vals is None else np.asarray(vals, dtype=float).T
+                self._finish_decode(it, D)
+                continue
+            if sname != "LstsqL2":
+                raise fe.BuildError(f"unsupported solver {sname} (LstsqL2, NoSolver are available)")
+            key = (float(solver.reg), id(conn.eval_points) if conn.eval_points is not None else None)
+            groups.setdefault(key, []).append(it)
+        for (reg, _), lst in groups.items():
+            X = self._eval_points(e, lst[0][0].eval_points)
+            Ys = [self._targets(it[0], X, it[1], it[2]) for it in lst]
+            widths = [y.shape[1] for y in Ys]
+            Y = np.concatenate(Ys, axis=1)
+            nz = np.any(Y != 0, axis=0)
+            D = np.zeros((Y.shape[1], e.n_neurons))
+            if nz.any():
+                D[nz] = solve_decoders(X, be.scaled_encoders, be.bias, be.neuron, Y[:, nz], reg=reg,
+                                       backend=self.solver_backend).T
+            off = 0
+            for it, w in zip(lst, widths):
+                self._finish_decode(it, D[off:off + w])
+                off += w
+
+    @staticmethod
+    def _finish_decode(item, D):
+        _, _, _, T, callback = item
+        T = np.asarray(T, dtype=float)
+        callback(D * float(T) if T.ndim == 0 else T @ D)
+
+    def _is_local(self, e):
+        """False for EnsembleArray members owned by another rank of a VCO-sharded build."""
+        if id(e) not in self.block_of:
+            return True
+        blk, i = self.block_of[id(e)]
+        return blk["range"][0] <= i < blk["range"][1]
+
+    # -- connections -----------------------------------------------------------------------
+    def _target_ref(self, post):
+        obj, start, length = _contig(post)
+        k = _kind(obj)
+        if k == "node":
+            if id(obj) not in self.node_in:
+                raise fe.BuildError(f"{obj!r} has no input")
+            full = self.node_in[id(obj)]
+        elif k == "ensemble":
+            full = self.ens_in[id(obj)]
+        elif k == "neurons":
+            ens = obj.ensemble
+            if id(ens) in self.block_of:
+                raise fe.BuildError("direct neuron input into an EnsembleArray member is not supported")
+            full = self.ens_J[id(ens)]
+        elif k == "rule":
+            full = self._rule_input(obj)
+        else:
+            raise fe.BuildError(f"cannot connect into {obj!r}")
+        return full if length is None else full.slice(start, length)
+
+    def _rule_input(self, rule):
+        if id(rule) not in self.rule_in:
+            is_voja = type(rule.learning_rule_type).__name__ == "Voja"
+            # Voja's learning signal is Reset to 1 each step, PES's error to 0 (Appendix A.7/A.8):
+            # kept in the R arena; Voja's "+1" is applied where the rule reads it.
+            self.rule_in[id(rule)] = self.alloc("R", 1 if is_voja else rule.size_in)
+        return self.rule_in[id(rule)]
+
+    def _apply_synapse(self, conn, src, dst, size, gain=1.0):
+        """src (already transformed, ``size`` wide) -> [Lowpass] -> dst accumulation."""
+        syn = conn.synapse
+        if syn is None:
+            self.op("axpy", dst=dst, src=src, len=size, alpha=gain, mode="inc")
+            return
+        tau = float(syn.tau)
+        state = self.alloc("S", size)
+        self.op("lowpass", dst=state, src=src, len=size, a=_lowpass_coeff(tau, self.dt), gain=gain)
+        self.op("axpy", dst=dst, src=state, len=size, alpha=1.0, mode="inc")
+
+    def _lower_connection(self, c):
+        pre_obj, pre_start, pre_len = _contig(c.pre)
+        pk = _kind(pre_obj)
+        dst = self._target_ref(c.post)
+        size_out = dst.len
+        T = np.asarray(c.transform, dtype=float)
+        rule = getattr(c, "learning_rule_type", None)
+        bc = BuiltConnection(weights=None, learned_buffer=None)
+        self.model.params[c] = bc
+
+        if pk == "node":
+            full = self.node_out[id(pre_obj)]
+            src = full if pre_len is None else full.slice(pre_start, pre_len)
+            if c.function is not None:
+                raise fe.BuildError("functions on connections from Nodes are not supported")
+            post_obj = _contig(c.post)[0]
+            if rule is not None:
+                if type(rule).__name__ != "Voja" or _kind(post_obj) != "ensemble" or T.ndim != 0:
+                    raise fe.BuildError("only Voja on a plain Node -> Ensemble connection is supported")
+                self._lower_voja(c, src, post_obj, float(T), rule)
+                return
+            if T.ndim == 0:
+                self._apply_synapse(c, src, dst, size_out, gain=float(T))
+            elif T.ndim == 1:
+                raise fe.BuildError("diagonal transforms are not supported; pass a full matrix")
+            else:
+                self._lower_matrix(c, T, src, dst)
+            bc.weights = T
+            return
+
+        if pk == "neurons":
+            ens = pre_obj.ensemble
+            if id(ens) in self.block_of:
+                raise fe.BuildError("connections from the neurons of an EnsembleArray member are not supported")
+            full = self.ens_spk[id(ens)]
+            src = full if pre_len is None else full.slice(pre_start, pre_len)
+            if T.ndim == 0:
+                self._apply_synapse(c, src, dst, size_out, gain=float(T))
+            else:
+                self._lower_matrix(c, T, src, dst)
+            return
+
+        if pk != "ensemble":
+            raise fe.BuildError(f"cannot connect from {pre_obj!r}")
+        e = pre_obj
+        if pre_len is None:
+            pre_start, pre_len = 0, e.dimensions
+        if rule is not None and type(rule).__name__ == "PES":
+            self._lower_pes(c, e, pre_start, pre_len, T, dst, rule)
+            return
+        if rule is not None:
+            raise fe.BuildError(f"unsupported learning rule {rule!r} on a decoded connection")
+        w = self.alloc("W", size_out)
+        if self._is_local(e):               # other ranks' VCOs: same signal layout, no decoders
+            def done(W, e=e, w=w, bc=bc):
+                bc.weights = W
+                self._register_rows(e, W, w)
+            self._request_decoders(c, e, pre_start, pre_len, T, done)
+        self._apply_synapse(c, w, dst, size_out)
+
+    def _lower_matrix(self, c, T, src, dst):
+        rows, cols = T.shape
+        if cols != src.len or rows != dst.len:
+            raise fe.BuildError(f"transform {T.shape} does not map {src.len} -> {dst.len}")
+        b = self.model.add_buffer(np.ascontiguousarray(T), f"transform_{len(self.model.buffers)}")
+        if c.synapse is None:
+            self.op("matvec", dst=dst, src=src, rows=rows, cols=cols, w=b, mode="inc")
+        else:
+            w = self.alloc("W", rows)
+            self.op("matvec", dst=w, src=src, rows=rows, cols=cols, w=b, mode="set")
+            self._apply_synapse(c, w, dst, rows)
+
+    def _register_rows(self, e, W, w_ref):
+        """Decoded rows of ensemble ``e``: row r of W (n,) lands in sig[w_ref + r]."""
+        if id(e) in self.block_of:
+            blk, i = self.block_of[id(e)]
+            for r in range(W.shape[0]):
+                if np.any(W[r]):
+                    blk["rows"][i].append((W[r], w_ref.slice(r, 1)))
+        else:
+            self.dense_rows[id(e)].append((W, w_ref))
+
+    def _lower_pes(self, c, e, pre_start, pre_len, T, dst, rule):
+        if id(e) in self.block_of:
+            raise fe.BuildError("PES on an EnsembleArray member is not supported")
+        size_out, n = dst.len, e.n_neurons
+        b = self.model.add_buffer(np.zeros((size_out, n)), f"pes_decoders_{len(self.model.buffers)}", role="learned")
+        self.model.params[c].learned_buffer = b
+
+        def done(W, b=b, c=c):
+            self.model.buffers[b][...] = W
+            self.model.params[c].weights = self.model.buffers[b]
+        self._request_decoders(c, e, pre_start, pre_len, T, done)
+        w = self.alloc("W", size_out)
+        spk = self.ens_spk[id(e)]
+        self.op("matvec", dst=w, src=spk, rows=size_out, cols=n, w=b, mode="set")
+        self._apply_synapse(c, w, dst, size_out)
+        # filtered pre activities (pre_synapse) and the fused delta + increment (Appendix A.7)
+        act = self.alloc("S", n)
+        tau = float(rule.pre_synapse.tau) if rule.pre_synapse is not None else 0.0
+        err = self._rule_input(c.learning_rule)
+        self.op("pes", w=b, rows=size_out, cols=n, err=err, act=act,
+                kappa=-float(rule.learning_rate) * self.dt / n)
+        self.op("lowpass", dst=act, src=spk, len=n, a=_lowpass_coeff(tau, self.dt) if tau > 0 else 0.0, gain=1.0)
+        self.learned[id(c)] = b
+
+    def _lower_voja(self, c, src, post_ens, alpha, rule):
+        """Node -> Ensemble with Voja: the key reaches the ensemble through its encoders as usual;
+        the rule then moves the (scaled) encoders of spiking neurons towards the key (A.8)."""
+        if id(post_ens) in self.block_of:
+            raise fe.BuildError("Voja on an EnsembleArray member is not supported")
+        d = post_ens.dimensions
+        dst = self.ens_in[id(post_ens)]
+        if c.synapse is not None:
+            raise fe.BuildError("Voja connections with a synapse are not supported (reference uses synapse=None)")
+        key = self.alloc("W", d)   # the connection's weighted output = pre_decoded of the rule
+        self.op("axpy", dst=key, src=src, len=d, alpha=alpha, mode="set")
+        self.op("axpy", dst=dst, src=key, len=d, alpha=1.0, mode="inc")
+        if rule.post_synapse is not None:
+            raise fe.BuildError("Voja with a post_synapse is not supported (reference uses post_synapse=None)")
+        be = self.built_ens[id(post_ens)]
+        be.voja = dict(key=key, learn=self._rule_input(c.learning_rule), lr=float(rule.learning_rate))
+        self.model.params[c].weights = alpha
+
+    # -- emit ensembles --------------------------------------------------------------------
+    def _emit_dense_ensemble(self, e):
+        be = self.built_ens[id(e)]
+        n, d = e.n_neurons, e.dimensions
+        J, spk, x = self.ens_J[id(e)], self.ens_spk[id(e)], self.ens_in[id(e)]
+        bias = self.alloc("C", n, init=be.bias)
+        role = "learned" if hasattr(be, "voja") else "param"
+        eb = self.model.add_buffer(np.ascontiguousarray(be.scaled_encoders), f"encoders_{e.label}", role=role)
+        be.encoder_buffer = eb
+        self.op("axpy", dst=J, src=bias, len=n, alpha=1.0, mode="inc")
+        self.op("matvec", dst=J, src=x, rows=n, cols=d, w=eb, mode="inc")
+        vb = self.model.add_buffer(np.zeros(n), f"voltage_{e.label}", role="state")
+        rb = self.model.add_buffer(np.zeros(n), f"refractory_{e.label}", role="state")
+        be.state_buffers = (vb, rb)
+        self.op("neurons", j=J, out=spk, n=n, v=vb, r=rb, neuron=be.neuron,
+                amp=be.neuron["amplitude"] / self.dt if be.neuron["type"] == "lif" else be.neuron["amplitude"])
+        for W, w_ref in self.dense_rows[id(e)]:
+            b = self.model.add_buffer(np.ascontiguousarray(W), f"decoders_{e.label}_{len(self.model.buffers)}")
+            self.op("matvec", dst=w_ref, src=spk, rows=W.shape[0], cols=n, w=b, mode="set")
+        if hasattr(be, "voja"):
+            v = be.voja
+            self.op("voja", w=eb, rows=n, cols=d, spk=spk, key=v["key"], learn=v["learn"],
+                    lr_dt=v["lr"] * self.dt, scale_buf=self.model.add_buffer(be.gain / be.radius, f"voja_scale_{e.label}"))
+
+    def _emit_block(self, blk):
+        ens = blk["ens"]
+        K_all = len(ens)
+        lo, hi = blk["range"]
+        e0 = ens[0]
+        n, din = e0.n_neurons, e0.dimensions
+        K = hi - lo
+        if K == 0:
+            return
+        dout = max(1, max(len(blk["rows"][i]) for i in range(lo, hi)))
+        enc = np.zeros((K, din, n))
+        bias = np.zeros((K, n))
+        dec = np.zeros((K, dout, n))
+        trash = self.alloc("W", 1)
+        dst_idx = np.empty((K, dout), dtype=object)
+        nd = self.built_ens[id(e0)].neuron
+        amp = nd["amplitude"] / self.dt if nd["type"] == "lif" else nd["amplitude"]
+        for i in range(lo, hi):
+            be = self.built_ens[id(ens[i])]
+            enc[i - lo] = be.scaled_encoders.T
+            bias[i - lo] = be.bias
+            rows = blk["rows"][i]
+            for r in range(dout):
+                if r < len(rows):
+                    dec[i - lo, r] = rows[r][0] * amp
+                    dst_idx[i - lo, r] = rows[r][1]
+                else:
+                    dst_idx[i - lo, r] = trash
+        m = self.model
+        label = getattr(blk["net"], "label", None) or "ensarray"
+        x = blk["x"].slice(lo * din, K * din)
+        self.op("ensarray", x=x, K=K, n=n, din=din, dout=dout,
+                enc=m.add_buffer(enc, f"{label}_enc"), bias=m.add_buffer(bias, f"{label}_bias"),
+                dec=m.add_buffer(dec, f"{label}_dec"), dst_refs=dst_idx,
+                v=m.add_buffer(np.zeros((K, n)), f"{label}_voltage", role="state"),
+                r=m.add_buffer(np.zeros((K, n)), f"{label}_refractory", role="state"),
+                neuron=nd, label=label, k_lo=lo, k_total=K_all)
+
+    # -- probes ----------------------------------------------------------------------------
+    def _lower_probe(self, p):
+        obj, start, length = _contig(p.target)
+        k = _kind(obj)
+        every = 1 if p.sample_every is None else max(1, int(round(p.sample_every / self.dt)))
+        attr = p.attr
+        if k == "connection" and attr == "weights":
+            bc = self.model.params.get(obj)
+            if bc is None or bc.learned_buffer is None:
+                raise fe.BuildError("Probe(conn, 'weights') needs a connection with a learning rule")
+            buf = self.model.buffers[bc.learned_buffer]
+            self.model.probes.append({"probe": p, "buf": bc.learned_buffer, "shape": buf.shape, "every": every})
+            return
+        if k == "rule" and attr == "scaled_encoders":
+            post = _contig(obj.connection.post)[0]
+            be = self.built_ens[id(post)]
+            self.model.probes.append({"probe": p, "buf": ("encoders_of", id(post)),
+                                      "shape": be.scaled_encoders.shape, "every": every, "ens": post})
+            return
+        if k == "node":
+            full = self.node_out[id(obj)]
+        elif k == "ensemble":
+            if attr not in ("decoded_output", "output"):
+                raise fe.BuildError(f"unsupported ensemble probe attr {attr!r}")
+            e = obj
+            fake = type("C", (), dict(function=None, solver=fe.LstsqL2(), eval_points=None, size_mid=e.dimensions))()
+            full = self.alloc("W", e.dimensions)
+            if self._is_local(e):
+                self._request_decoders(fake, e, 0, e.dimensions, 1.0,
+                                       lambda W, e=e, full=full: self._register_rows(e, W, full))
+        elif k == "neurons":
+            e = obj.ensemble
+            if id(e) in self.block_of:
+                raise fe.BuildError("probing neurons of an EnsembleArray member is not supported yet")
+            full = self.ens_spk[id(e)]
+        else:
+            raise fe.BuildError(f"unsupported probe target {obj!r}")
+        src = full if length is None else full.slice(start, length)
+        if p.synapse is not None:
+            state = self.alloc("S", src.len)
+            self.op("lowpass", dst=state, src=src, len=src.len, a=_lowpass_coeff(float(p.synapse.tau), self.dt), gain=1.0)
+            src = state
+        self.model.probes.append({"probe": p, "src": src, "width": src.len, "every": every})
+
+    # -- finalise: resolve offsets, merge, schedule ------------------------------------------
+    def _finalise(self):
+        m = self.model
+        base, off = {}, 0
+        for a in "RWSCT":
+            base[a] = off
+            off += self.arena_size[a]
+        m.sig_size, m.arena_base, m.arena_size = off, base, dict(self.arena_size)
+        m.sig_init = np.zeros(off)
+        for r, vals in self.inits:
+            m.sig_init[base[r.arena] + r.off: base[r.arena] + r.off + r.len] = vals
+
+        def A(r):
+            return base[r.arena] + r.off
+
+        for table in m.tables:
+            table["dst"] = A(table.pop("ref"))
+        ops = []
+        if self.arena_size["R"]:
+            ops.append({"kind": "fill", "dst": base["R"], "len": self.arena_size["R"], "value": 0.0, "seq": -1})
+        for o in self.raw_ops:
+            o = dict(o)
+            for key in ("dst", "src", "x", "j", "out", "err", "act", "spk", "key", "learn"):
+                if isinstance(o.get(key), Ref):
+                    o[key] = A(o[key])
+            if o["kind"] == "ensarray":
+                refs = o.pop("dst_refs")
+                idx = np.array([[A(r) for r in row] for row in refs], dtype=np.int32)
+                o["dst_idx"] = m.add_buffer(idx, f"{o['label']}_dst_idx", role="index")
+            ops.append(o)
+        for p in m.probes:
+            if "src" in p:
+                p["src"] = A(p["src"])
+        for name, table in (("ens_in", self.ens_in), ("node_in", self.node_in), ("node_out", self.node_out),
+                            ("ens_spk", self.ens_spk)):
+            for key, r in table.items():
+                m.sig[(name, key)] = (A(r), r.len)
+        ops = merge_ops(ops, m)
+        m.ops = schedule_ops(ops, m)
+        m.stats.update(n_raw_ops=len(self.raw_ops), n_ops=len(m.ops), sig_size=m.sig_size,
+                       n_buffers=len(m.buffers))
+
+
+# --------------------------------------------------------------------------------------------
+# operator merging (nengo's optimizer pass, Appendix A.12)
+# --------------------------------------------------------------------------------------------
+def merge_ops(ops, model):
+    out = []
+    groups = {}
+    for o in ops:
+        k = o["kind"]
+        if k == "fill":
+            key = ("fill", o["value"])
+        elif k == "axpy":
+            key = ("axpy", o["alpha"], o["mode"], o["dst"] - o["src"])
+        elif k == "lowpass":
+            key = ("lowpass", o["a"], o["gain"], o["dst"] - o["src"])
+        elif k == "matvec" and o["rows"] * o["cols"] <= 64 and model.buffer_meta[o["w"]]["role"] == "param":
+            key = ("matvec", o["src"], o["cols"], o["mode"])
+        else:
+            out.append(o)
+            continue
+        groups.setdefault(key, []).append(o)
+    for key, lst in groups.items():
+        lst.sort(key=lambda o: o["dst"])
+        cur = None
+        for o in lst:
+            n = o["rows"] if key[0] == "matvec" else o["len"]
+            if cur is not None and o["dst"] == cur["dst"] + (cur["rows"] if key[0] == "matvec" else cur["len"]):
+                if key[0] == "matvec":
+                    cur["_stack"].append(model.buffers[o["w"]])
+                    cur["rows"] += n
+                else:
+                    cur["len"] += n
+                cur["seq"] = min(cur["seq"], o["seq"])
+                continue
+            if cur is not None:
+                out.append(cur)
+            cur = dict(o)
+            if key[0] == "matvec":
+                cur["_stack"] = [model.buffers[o["w"]]]
+        if cur is not None:
+            out.append(cur)
+    for o in out:
+        if "_stack" in o:
+            st = o.pop("_stack")
+            if len(st) > 1:
+                o["w"] = model.add_buffer(np.ascontiguousarray(np.vstack(st)), f"stacked_transform_{len(model.buffers)}")
+    out.sort(key=lambda o: o["seq"])
+    return out
+
+
+def op_access(o, model):
+    """(sets, incs, reads, updates): lists of resources ('s', lo, hi) signal ranges / ('b', id) buffers."""
+    k = o["kind"]
+    S = lambda off, n: ("s", off, off + n)  # noqa: E731
+    B = lambda b: ("b", b)                  # noqa: E731
+    if k == "fill":
+        return [S(o["dst"], o["len"])], [], [], []
+    if k == "table":
+        return [S(o["dst"], o["width"])], [], [], []
+    if k == "axpy":
+        w = [S(o["dst"], o["len"])]
+        return (w, [], [S(o["src"], o["len"])], []) if o["mode"] == "set" else ([], w, [S(o["src"], o["len"])], [])
+    if k == "matvec":
+        w = [S(o["dst"], o["rows"])]
+        r = [S(o["src"], o["cols"]), B(o["w"])]
+        return (w, [], r, []) if o["mode"] == "set" else ([], w, r, [])
+    if k == "lowpass":
+        return [], [], [S(o["src"], o["len"])], [S(o["dst"], o["len"])]
+    if k == "ensarray":
+        idx = np.unique(model.buffers[o["dst_idx"]].reshape(-1))
+        runs, start, prev = [], int(idx[0]), int(idx[0])
+        for v in idx[1:]:
+            v = int(v)
+            if v != prev + 1:
+                runs.append(S(start, prev - start + 1))
+                start = v
+            prev = v
+        runs.append(S(start, prev - start + 1))
+        return runs, [], [S(o["x"], o["K"] * o["din"])], [B(o["v"]), B(o["r"])]
+    if k == "neurons":
+        return [S(o["out"], o["n"])], [], [S(o["j"], o["n"])], [B(o["v"]), B(o["r"])]
+    if k == "pes":
+        return [], [], [S(o["err"], o["rows"]), S(o["act"], o["cols"])], [B(o["w"])]
+    if k == "voja":
+        return [], [], [S(o["spk"], o["rows"]), S(o["key"], o["cols"]), S(o["learn"], 1), B(o["scale_buf"])], [B(o["w"])]
+    if k == "cleanup":
+        return [S(o["dst"], o["cols"])], [], [S(o["src"], o["cols"]), B(o["w"])], []
+    if k == "gate":
+        return [S(o["dst"], o["d"])], [], [S(o["src"], 2 * o["d"] + 1)], []
+    raise fe.BuildError(f"unknown op kind {k}")
+
+
+def _overlap(a, b):
+    if a[0] != b[0]:
+        return False
+    if a[0] == "b":
+        return a[1] == b[1]
+    return a[1] < b[2] and b[1] < a[2]
+
+
+def is_micro(o):
+    k = o["kind"]
+    if k in ("fill", "table", "axpy", "lowpass", "gate"):
+        return True
+    return k == "matvec" and o["cols"] <= 16 and o["rows"] <= 8192
+
+
+def schedule_ops(ops, model):
+    """Order by *sets -> incs -> reads -> updates* per resource; returns ops annotated with ``level``.
+
+    Kahn's algorithm in rounds.  A round takes every ready cheap vector op ("micro") at once - they
+    were all ready together, so they touch disjoint data and need no barrier between them - or,
+    when none is ready, the single oldest big op.  ``level`` is the round number: the device-side
+    program executor puts a workgroup barrier between micro ops of different level, and runs of
+    consecutive micro ops become one launch.
+    """
+    n = len(ops)
+    acc = [op_access(o, model) for o in ops]
+    entries = [(res, cls, i) for i, a in enumerate(acc) for cls in range(4) for res in a[cls]]
+    succ = [set() for _ in range(n)]
+    for x in range(len(entries)):
+        rx, cx, ix = entries[x]
+        for y in range(x + 1, len(entries)):
+            ry, cy, iy = entries[y]
+            if ix == iy or (cx == 2 and cy == 2) or not _overlap(rx, ry):
+                continue
+            if cx == cy:      # same class on overlapping data: keep creation order (deterministic sums)
+                a, b = (ix, iy) if ops[ix]["seq"] <= ops[iy]["seq"] else (iy, ix)
+            else:
+                a, b = (ix, iy) if cx < cy else (iy, ix)
+            succ[a].add(b)
+    indeg = [0] * n
+    for a in range(n):
+        for b in succ[a]:
+            indeg[b] += 1
+    ready = [i for i in range(n) if indeg[i] == 0]
+    out, level = [], 0
+    while ready:
+        micro = [i for i in ready if is_micro(ops[i])]
+        pick = sorted(micro, key=lambda i: ops[i]["seq"]) if micro else [min(ready, key=lambda i: ops[i]["seq"])]
+        for i in pick:
+            ready.remove(i)
+        for i in pick:
+            o = dict(ops[i])
+            o["level"], o["micro"] = level, is_micro(o)
+            out.append(o)
+            for j in succ[i]:
+                indeg[j] -= 1
+                if indeg[j] == 0:
+                    ready.append(j)
+        level += 1
+    if len(out) != n:
+        raise fe.BuildError("operator graph has a cycle within one timestep (a loop without a synapse)")
+    return out
+
+
+def build(network, dt=0.001, seed=None, n_eval_points=None, solver_backend="auto", vco_shard=None):
+    """Build ``network`` into a :class:`BuiltModel`."""
+    return Builder(network, dt=dt, seed=seed, n_eval_points=n_eval_points,
+                   solver_backend=solver_backend, vco_shard=vco_shard).build()

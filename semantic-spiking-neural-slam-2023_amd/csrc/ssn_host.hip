@@ -1,0 +1,798 @@
+// ssn_host.hip - C ABI (include/ssn.h) and step-loop executor of libssn_hip.so.
+//
+// ssn_create turns the host-built operator list into a launch plan:
+//   * runs of small vector operators become "programs" (one k_program launch each),
+//   * ensemble arrays, dense matvecs, neuron updates and learning rules become their own kernels,
+//   * the tail program of step s and the head program of step s+1 are fused into one launch,
+//   * `steps_per_graph` consecutive timesteps are captured into one hipGraph; ssn_run_steps
+//     replays it, so the host issues one graph launch per `steps_per_graph` simulated steps.
+// Every kernel reads the current step from device memory (StepCtx), which is what makes the
+// captured graph step-invariant.  There is no CPU fallback: without a HIP device ssn_create fails.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ssn.h"
+#include "ssn_launch.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess)                                                                        \
+      return fail(e__ == hipErrorOutOfMemory ? SSN_ENOMEM : SSN_EHIP, "%s failed: %s (%s:%d)",    \
+                  #expr, hipGetErrorString(e__), __FILE__, __LINE__);                             \
+  } while (0)
+
+#define CHK(expr)                     \
+  do {                                \
+    int rc__ = (expr);                \
+    if (rc__ != SSN_OK) return rc__;  \
+  } while (0)
+
+struct Buf {
+  void* d = nullptr;
+  int64_t count = 0;
+  int kind = 0;
+  int64_t rows = 1, cols = 0, ld = 0;     // device layout (row padded)
+  bool shaped = false;
+  bool keep = false;                      // keep host copy for reset (state / learned)
+  std::vector<double> host;               // initial contents if keep
+};
+
+enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA };
+
+}  // namespace
+
+struct ssn_sim {
+  virtual ~ssn_sim() {}
+  virtual int reset() = 0;
+  virtual int set_table(int id, const double* rows, const void* rows_dev, int64_t n_rows, int64_t width,
+                        const int32_t* idx, int64_t n_idx, int64_t first_step) = 0;
+  virtual int reserve_probes(int64_t n) = 0;
+  virtual int run_steps(int64_t n, int profile) = 0;
+  virtual int read_probe(int id, double* dst, void* dst_dev, int64_t first, int64_t count) = 0;
+  virtual int64_t probe_count(int id) = 0;
+  virtual int rw_signal(int64_t off, int64_t count, double* dst, const double* src) = 0;
+  virtual int rw_buffer(int id, double* dst, const double* src, int64_t count) = 0;
+  virtual int counters(ssn_counters* out) = 0;
+  virtual int64_t n_steps() = 0;
+};
+
+namespace {
+
+template <typename T>
+struct Sim final : ssn_sim {
+  using MOp = ssn::MicroOp<T>;
+  static constexpr int VW = 16 / sizeof(T);
+
+  struct Item {
+    int type = IT_PROGRAM;
+    int op_begin = 0, op_count = 0;          // program: range in d_mops
+    ssn::EnsArgs<T> ens;
+    bool dominant = false;
+    // matvec / pes / voja / neurons
+    T* Wm = nullptr; const T* src = nullptr; T* dst = nullptr; const T* aux0 = nullptr; const T* aux1 = nullptr;
+    const T* aux2 = nullptr; T* V = nullptr; T* R = nullptr;
+    int rows = 0, cols = 0, ld = 0, set = 0, n = 0;
+    T scalar = 0;
+    ssn::NeuronParams<T> np;
+  };
+
+  int device = 0;
+  double dt = 0.001;
+  hipStream_t stream = nullptr;
+  int64_t n_sig = 0;
+  T* sig = nullptr;
+  std::vector<double> sig_init;
+  std::vector<Buf> bufs;
+  std::vector<Item> items;                   // one timestep, unfused
+  std::vector<MOp> mops;                     // [head][middle programs...][tail][head copy]
+  MOp* d_mops = nullptr;
+  int head_begin = 0, head_count = 0, tail_begin = 0, tail_count = 0;
+  bool can_fuse = false;
+  ssn::StepCtx* d_ctx = nullptr;
+  std::vector<ssn::TableSlot> tables;
+  ssn::TableSlot* d_tables = nullptr;
+  std::vector<void*> table_rows;
+  std::vector<int*> table_idx;
+  std::vector<int64_t> table_rows_cap, table_idx_cap;
+  std::vector<ssn_probe_desc> probes;
+  std::vector<ssn::ProbeSlot> pslots;
+  ssn::ProbeSlot* d_pslots = nullptr;
+  std::vector<int64_t> probe_cap_bytes;
+  int64_t reserve_first = 0, reserve_n = 0;
+  int steps_per_graph = 0;
+  hipGraphExec_t graph_exec = nullptr;
+  hipGraph_t graph = nullptr;
+  int64_t steps_done = 0;
+  int64_t device_bytes = 0;
+  // timing
+  hipEvent_t ev_run0 = nullptr, ev_run1 = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  int64_t dom_launches = 0;
+  double dom_ms = 0.0, last_run_ms = 0.0;
+  double dom_bytes = 0.0;
+  int64_t dom_units = 0;
+  int launches_per_step = 0;
+
+  ~Sim() override {
+    hipSetDevice(device);
+    if (stream) hipStreamSynchronize(stream);
+    if (graph_exec) hipGraphExecDestroy(graph_exec);
+    if (graph) hipGraphDestroy(graph);
+    for (auto& b : bufs) if (b.d) hipFree(b.d);
+    for (auto p : table_rows) if (p) hipFree(p);
+    for (auto p : table_idx) if (p) hipFree(p);
+    for (auto& s : pslots) if (s.data) hipFree(s.data);
+    for (auto& it : items) if (it.type == IT_ENS && it.ens.partials) hipFree(it.ens.partials);
+    for (auto e : ev_pool) hipEventDestroy(e);
+    if (ev_run0) hipEventDestroy(ev_run0);
+    if (ev_run1) hipEventDestroy(ev_run1);
+    if (sig) hipFree(sig);
+    if (d_mops) hipFree(d_mops);
+    if (d_ctx) hipFree(d_ctx);
+    if (d_tables) hipFree(d_tables);
+    if (d_pslots) hipFree(d_pslots);
+    if (stream) hipStreamDestroy(stream);
+  }
+
+  template <typename P>
+  int dmalloc(P** p, int64_t bytes) {
+    if (bytes <= 0) bytes = 16;
+    HIPCHK(hipMalloc((void**)p, (size_t)bytes));
+    device_bytes += bytes;
+    return SSN_OK;
+  }
+
+  // host double[rows*cols] -> device T[rows*ld]
+  int upload(const double* src, T* dst, int64_t rows, int64_t cols, int64_t ld) {
+    const int64_t n = rows * cols;
+    if (n == 0) return SSN_OK;
+    double* stage = nullptr;
+    HIPCHK(hipMalloc((void**)&stage, (size_t)n * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(stage, src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = ssn::launch_convert_in<T>(stream, stage, dst, rows, cols, ld);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    hipFree(stage);
+    HIPCHK(e);
+    return SSN_OK;
+  }
+
+  int download(const T* src, double* dst, int64_t rows, int64_t cols, int64_t ld) {
+    const int64_t n = rows * cols;
+    if (n == 0) return SSN_OK;
+    double* stage = nullptr;
+    HIPCHK(hipMalloc((void**)&stage, (size_t)n * sizeof(double)));
+    hipError_t e = ssn::launch_convert_out<T>(stream, src, stage, rows, cols, ld);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, stage, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    hipFree(stage);
+    HIPCHK(e);
+    return SSN_OK;
+  }
+
+  int shape(int id, int64_t rows, int64_t cols, bool pad, bool keep) {
+    if (id < 0 || id >= (int)bufs.size()) return fail(SSN_EINVAL, "buffer id %d out of range", id);
+    Buf& b = bufs[id];
+    if (b.kind != SSN_BUF_REAL) return fail(SSN_EINVAL, "buffer %d is not a real buffer", id);
+    if (rows * cols != b.count) return fail(SSN_EINVAL, "buffer %d has %lld elements, operator expects %lld x %lld",
+                                            id, (long long)b.count, (long long)rows, (long long)cols);
+    const int64_t ld = pad ? (cols + VW - 1) / VW * VW : cols;
+    if (b.shaped && (b.rows != rows || b.cols != cols || b.ld != ld))
+      return fail(SSN_EINVAL, "buffer %d is used with two different layouts", id);
+    b.rows = rows; b.cols = cols; b.ld = ld; b.shaped = true;
+    b.keep = b.keep || keep;
+    return SSN_OK;
+  }
+
+  static bool is_micro(const ssn_op_desc& o) {
+    switch (o.kind) {
+      case SSN_OP_FILL: case SSN_OP_TABLE: case SSN_OP_AXPY: case SSN_OP_LOWPASS: case SSN_OP_GATE: return true;
+      case SSN_OP_MATVEC: return o.i[3] <= 16 && o.i[2] <= 8192;
+      default: return false;
+    }
+  }
+
+  int check_range(int64_t off, int64_t len, const char* what) {
+    if (off < 0 || len < 0 || off + len > n_sig) return fail(SSN_EINVAL, "%s range [%lld,+%lld) outside the %lld signals",
+                                                             what, (long long)off, (long long)len, (long long)n_sig);
+    return SSN_OK;
+  }
+
+  int create(const ssn_model_desc* m) {
+    device = m->device;
+    dt = m->dt;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&ev_run0));
+    HIPCHK(hipEventCreate(&ev_run1));
+    n_sig = m->n_signals;
+    sig_init.assign(m->signal_init, m->signal_init + n_sig);
+    CHK(dmalloc(&sig, (n_sig + 8) * (int64_t)sizeof(T)));
+    bufs.resize(m->n_buffers);
+    for (int i = 0; i < m->n_buffers; ++i) {
+      bufs[i].count = m->buffers[i].count;
+      bufs[i].kind = m->buffers[i].kind;
+      bufs[i].cols = bufs[i].ld = bufs[i].count;
+      if (!m->buffers[i].data && bufs[i].count) return fail(SSN_EINVAL, "buffer %d has no data", i);
+    }
+    // pass 1: buffer layouts
+    for (int i = 0; i < m->n_ops; ++i) {
+      const ssn_op_desc& o = m->ops[i];
+      switch (o.kind) {
+        case SSN_OP_ENSARRAY: {
+          const int64_t K = o.i[1], n = o.i[2], din = o.i[3], dout = o.i[4];
+          if (din < 1 || din > 4 || dout < 1 || dout > 8)
+            return fail(SSN_EUNSUPPORTED, "ensemble array with din=%lld dout=%lld (kernels cover din<=4, dout<=8)",
+                        (long long)din, (long long)dout);
+          CHK(shape((int)o.i[5], K * din, n, true, false));
+          CHK(shape((int)o.i[6], K, n, true, false));
+          CHK(shape((int)o.i[7], K * dout, n, true, false));
+          CHK(shape((int)o.i[9], K, n, true, true));
+          CHK(shape((int)o.i[10], K, n, true, true));
+          if (o.i[8] < 0 || o.i[8] >= m->n_buffers || bufs[o.i[8]].kind != SSN_BUF_I32 || bufs[o.i[8]].count != K * dout)
+            return fail(SSN_EINVAL, "ensemble array dst_idx buffer must be int32 [K*dout]");
+          const int32_t* di = (const int32_t*)m->buffers[o.i[8]].data;
+          for (int64_t j = 0; j < K * dout; ++j)
+            if (di[j] < 0 || di[j] >= n_sig) return fail(SSN_EINVAL, "ensemble array destination index out of range");
+          CHK(check_range(o.i[0], K * din, "ensarray x"));
+          break;
+        }
+        case SSN_OP_MATVEC:
+          CHK(shape((int)o.i[4], o.i[2], o.i[3], !is_micro(o), false));
+          CHK(check_range(o.i[0], o.i[2], "matvec dst"));
+          CHK(check_range(o.i[1], o.i[3], "matvec src"));
+          break;
+        case SSN_OP_NEURONS:
+          CHK(shape((int)o.i[3], 1, o.i[2], false, true));
+          CHK(shape((int)o.i[4], 1, o.i[2], false, true));
+          CHK(check_range(o.i[0], o.i[2], "neurons J"));
+          CHK(check_range(o.i[1], o.i[2], "neurons out"));
+          break;
+        case SSN_OP_PES:
+          CHK(shape((int)o.i[0], o.i[1], o.i[2], true, true));
+          CHK(check_range(o.i[3], o.i[1], "pes err"));
+          CHK(check_range(o.i[4], o.i[2], "pes act"));
+          break;
+        case SSN_OP_VOJA:
+          CHK(shape((int)o.i[0], o.i[1], o.i[2], true, true));
+          CHK(shape((int)o.i[6], 1, o.i[1], false, false));
+          CHK(check_range(o.i[3], o.i[1], "voja spikes"));
+          CHK(check_range(o.i[4], o.i[2], "voja key"));
+          CHK(check_range(o.i[5], 1, "voja learn"));
+          break;
+        case SSN_OP_CLEANUP:
+          CHK(shape((int)o.i[4], o.i[2], o.i[3], true, false));
+          CHK(check_range(o.i[0], o.i[3], "cleanup dst"));
+          CHK(check_range(o.i[1], o.i[3], "cleanup src"));
+          break;
+        case SSN_OP_FILL: CHK(check_range(o.i[0], o.i[1], "fill")); break;
+        case SSN_OP_TABLE:
+          CHK(check_range(o.i[0], o.i[1], "table"));
+          if (o.i[2] < 0 || o.i[2] >= m->n_tables) return fail(SSN_EINVAL, "table id out of range");
+          break;
+        case SSN_OP_AXPY: CHK(check_range(o.i[0], o.i[2], "axpy dst")); CHK(check_range(o.i[1], o.i[2], "axpy src")); break;
+        case SSN_OP_LOWPASS: CHK(check_range(o.i[0], o.i[2], "lowpass dst")); CHK(check_range(o.i[1], o.i[2], "lowpass src")); break;
+        case SSN_OP_GATE: CHK(check_range(o.i[0], o.i[2], "gate dst")); CHK(check_range(o.i[1], 2 * o.i[2] + 1, "gate src")); break;
+        default: return fail(SSN_EINVAL, "unknown operator kind %d", o.kind);
+      }
+    }
+    // uploads
+    for (int i = 0; i < m->n_buffers; ++i) {
+      Buf& b = bufs[i];
+      if (b.kind == SSN_BUF_I32) {
+        CHK(dmalloc((int32_t**)&b.d, b.count * 4));
+        HIPCHK(hipMemcpy(b.d, m->buffers[i].data, (size_t)b.count * 4, hipMemcpyHostToDevice));
+      } else {
+        CHK(dmalloc((T**)&b.d, b.rows * b.ld * (int64_t)sizeof(T)));
+        CHK(upload((const double*)m->buffers[i].data, (T*)b.d, b.rows, b.cols, b.ld));
+        if (b.keep) b.host.assign((const double*)m->buffers[i].data, (const double*)m->buffers[i].data + b.count);
+      }
+    }
+    CHK(upload(sig_init.data(), sig, 1, n_sig, n_sig));
+    CHK(dmalloc(&d_ctx, sizeof(ssn::StepCtx)));
+    HIPCHK(hipMemset(d_ctx, 0, sizeof(ssn::StepCtx)));
+    // tables and probes
+    tables.assign(m->n_tables, ssn::TableSlot{nullptr, nullptr, 0, 0, 0, 0});
+    table_rows.assign(m->n_tables, nullptr);
+    table_idx.assign(m->n_tables, nullptr);
+    table_rows_cap.assign(m->n_tables, 0);
+    table_idx_cap.assign(m->n_tables, 0);
+    CHK(dmalloc(&d_tables, std::max<int64_t>(1, m->n_tables) * (int64_t)sizeof(ssn::TableSlot)));
+    if (m->n_tables) HIPCHK(hipMemcpy(d_tables, tables.data(), tables.size() * sizeof(ssn::TableSlot), hipMemcpyHostToDevice));
+    probes.assign(m->probes, m->probes + m->n_probes);
+    for (auto& p : probes) {
+      if (p.every < 1) return fail(SSN_EINVAL, "probe 'every' must be >= 1");
+      CHK(check_range(p.src, p.width, "probe"));
+    }
+    pslots.assign(m->n_probes, ssn::ProbeSlot{nullptr, 1, 0, 0});
+    probe_cap_bytes.assign(m->n_probes, 0);
+    for (int i = 0; i < m->n_probes; ++i) pslots[i].every = probes[i].every;
+    CHK(dmalloc(&d_pslots, std::max<int64_t>(1, m->n_probes) * (int64_t)sizeof(ssn::ProbeSlot)));
+    if (m->n_probes) HIPCHK(hipMemcpy(d_pslots, pslots.data(), pslots.size() * sizeof(ssn::ProbeSlot), hipMemcpyHostToDevice));
+    CHK(plan(m));
+    steps_per_graph = m->steps_per_graph > 0 ? m->steps_per_graph : 16;
+    CHK(capture());
+    HIPCHK(hipStreamSynchronize(stream));
+    return SSN_OK;
+  }
+
+  // ---- planning ---------------------------------------------------------------------------
+  ssn::NeuronParams<T> neuron_params(int64_t type, const double* f) const {
+    ssn::NeuronParams<T> np;
+    np.type = (int)type; np.dt = (T)dt; np.tau_rc = (T)f[0]; np.tau_ref = (T)f[1]; np.min_voltage = (T)f[2];
+    return np;
+  }
+
+  int plan(const ssn_model_desc* m) {
+    std::vector<std::vector<MOp>> programs;   // programs in step order
+    std::vector<int> item_prog;               // for IT_PROGRAM items: index into programs
+    std::vector<MOp> cur;
+    int prev_level = -1;
+    bool force_barrier = false;
+    auto push_micro = [&](MOp op, int level, bool exec_inserted) {
+      op.barrier = cur.empty() ? 0 : ((force_barrier || exec_inserted || level != prev_level) ? 1 : 0);
+      force_barrier = exec_inserted;
+      prev_level = level;
+      cur.push_back(op);
+    };
+    auto flush = [&]() {
+      if (cur.empty()) return;
+      Item it; it.type = IT_PROGRAM;
+      item_prog.push_back((int)programs.size());
+      programs.push_back(cur);
+      items.push_back(it);
+      cur.clear();
+      force_barrier = false;
+      prev_level = -1;
+    };
+    int64_t best_units = -1;
+    int best_item = -1;
+    for (int i = 0; i < m->n_ops; ++i) {
+      const ssn_op_desc& o = m->ops[i];
+      MOp op{};
+      switch (o.kind) {
+        case SSN_OP_FILL:
+          op.kind = ssn::M_FILL; op.dst = o.i[0]; op.len = o.i[1]; op.a = (T)o.f[0];
+          push_micro(op, o.level, false); break;
+        case SSN_OP_TABLE:
+          op.kind = ssn::M_TABLE; op.dst = o.i[0]; op.len = o.i[1]; op.p0 = d_tables + o.i[2];
+          tables[o.i[2]].width = o.i[1];
+          push_micro(op, o.level, false); break;
+        case SSN_OP_AXPY:
+          op.kind = o.i[3] ? ssn::M_AXPY_SET : ssn::M_AXPY_INC; op.dst = o.i[0]; op.src = o.i[1]; op.len = o.i[2]; op.a = (T)o.f[0];
+          push_micro(op, o.level, false); break;
+        case SSN_OP_LOWPASS:
+          op.kind = ssn::M_LOWPASS; op.dst = o.i[0]; op.src = o.i[1]; op.len = o.i[2];
+          op.a = (T)o.f[0]; op.b = (T)((1.0 - o.f[0]) * o.f[1]);
+          push_micro(op, o.level, false); break;
+        case SSN_OP_GATE:
+          op.kind = ssn::M_GATE; op.dst = o.i[0]; op.src = o.i[1]; op.len = o.i[2]; op.a = (T)o.f[0]; op.b = (T)o.f[1];
+          push_micro(op, o.level, true); break;
+        case SSN_OP_MATVEC: {
+          const Buf& w = bufs[o.i[4]];
+          if (is_micro(o)) {
+            op.kind = o.i[5] ? ssn::M_MATVEC_SET : ssn::M_MATVEC_INC;
+            op.dst = o.i[0]; op.src = o.i[1]; op.len = o.i[2]; op.i0 = o.i[3]; op.i1 = w.ld; op.p0 = w.d;
+            push_micro(op, o.level, false);
+          } else {
+            flush();
+            Item it; it.type = IT_MATVEC; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.dst = sig + o.i[0];
+            it.rows = (int)o.i[2]; it.cols = (int)o.i[3]; it.ld = (int)w.ld; it.set = (int)o.i[5];
+            items.push_back(it);
+          }
+          break;
+        }
+        case SSN_OP_ENSARRAY: {
+          flush();
+          Item it; it.type = IT_ENS;
+          ssn::EnsArgs<T>& a = it.ens;
+          a.K = (int)o.i[1]; a.n = (int)o.i[2]; a.din = (int)o.i[3]; a.dout = (int)o.i[4];
+          a.n_pad = (int)bufs[o.i[5]].ld;
+          a.enc = (const T*)bufs[o.i[5]].d; a.bias = (const T*)bufs[o.i[6]].d; a.dec = (const T*)bufs[o.i[7]].d;
+          a.V = (T*)bufs[o.i[9]].d; a.R = (T*)bufs[o.i[10]].d;
+          a.sig = sig; a.x_off = o.i[0];
+          a.np = neuron_params(o.i[11], o.f);
+          // chunking: whole 256-thread sweeps per workgroup; aim for >= ~8 workgroups per CU chip-wide
+          const int n_vec = a.n_pad / VW;
+          int sweeps = 1;
+          const int max_sweeps = (n_vec + 255) / 256;
+          while (sweeps < max_sweeps && (int64_t)a.K * ((n_vec + 256 * (sweeps + 1) - 1) / (256 * (sweeps + 1))) >= 4096) ++sweeps;
+          a.chunk_vec = 256 * sweeps;
+          a.P = (n_vec + a.chunk_vec - 1) / a.chunk_vec;
+          CHK(dmalloc(&a.partials, (int64_t)a.K * a.P * a.dout * (int64_t)sizeof(T)));
+          const int64_t units = (int64_t)a.K * a.n;
+          if (units > best_units) { best_units = units; best_item = (int)items.size(); }
+          items.push_back(it);
+          MOp f{};
+          f.kind = ssn::M_ENS_FINISH; f.len = (int64_t)a.K * a.dout; f.i0 = a.P; f.i1 = a.dout;
+          f.p0 = a.partials; f.p1 = bufs[o.i[8]].d;
+          push_micro(f, o.level, true);
+          break;
+        }
+        case SSN_OP_NEURONS: {
+          flush();
+          Item it; it.type = IT_NEURONS; it.src = sig + o.i[0]; it.dst = sig + o.i[1]; it.n = (int)o.i[2];
+          it.V = (T*)bufs[o.i[3]].d; it.R = (T*)bufs[o.i[4]].d; it.np = neuron_params(o.i[5], o.f); it.scalar = (T)o.f[3];
+          items.push_back(it);
+          break;
+        }
+        case SSN_OP_PES: {
+          flush();
+          const Buf& w = bufs[o.i[0]];
+          Item it; it.type = IT_PES; it.Wm = (T*)w.d; it.rows = (int)o.i[1]; it.cols = (int)o.i[2]; it.ld = (int)w.ld;
+          it.aux0 = sig + o.i[3]; it.aux1 = sig + o.i[4]; it.scalar = (T)o.f[0];
+          items.push_back(it);
+          break;
+        }
+        case SSN_OP_VOJA: {
+          flush();
+          const Buf& w = bufs[o.i[0]];
+          Item it; it.type = IT_VOJA; it.Wm = (T*)w.d; it.rows = (int)o.i[1]; it.cols = (int)o.i[2]; it.ld = (int)w.ld;
+          it.src = sig + o.i[3]; it.aux0 = sig + o.i[4]; it.aux1 = sig + o.i[5]; it.aux2 = (const T*)bufs[o.i[6]].d;
+          it.scalar = (T)o.f[0];
+          items.push_back(it);
+          break;
+        }
+        case SSN_OP_CLEANUP: {
+          // similarities into a scratch region appended to the signal vector, then argmax + row gather
+          return fail(SSN_EUNSUPPORTED, "cleanup operator: use ssn built with the SLAM operator set");
+        }
+        default: return fail(SSN_EINVAL, "unknown operator kind %d", o.kind);
+      }
+    }
+    for (size_t p = 0; p < probes.size(); ++p) {
+      MOp op{};
+      op.kind = ssn::M_PROBE; op.src = probes[p].src; op.len = probes[p].width; op.p0 = d_pslots + p;
+      push_micro(op, -2, p == 0);
+    }
+    MOp end{};
+    end.kind = ssn::M_STEP_END;
+    push_micro(end, -3, false);
+    force_barrier = true;
+    flush();
+    if (best_item >= 0) {
+      items[best_item].dominant = true;
+      const ssn::EnsArgs<T>& a = items[best_item].ens;
+      dom_units = (int64_t)a.K * a.n;
+      dom_bytes = (double)dom_units * (a.din + a.dout + 5) * sizeof(T);
+    }
+    // micro-op storage: programs in order, then a copy of the head behind the tail for the fused launch
+    int n_prog = (int)programs.size();
+    std::vector<int> begin(n_prog, 0);
+    mops.clear();
+    for (int p = 0; p < n_prog; ++p) {
+      begin[p] = (int)mops.size();
+      mops.insert(mops.end(), programs[p].begin(), programs[p].end());
+    }
+    int pi = 0;
+    for (auto& it : items)
+      if (it.type == IT_PROGRAM) { it.op_begin = begin[pi]; it.op_count = (int)programs[pi].size(); ++pi; }
+    can_fuse = items.size() >= 2 && items.front().type == IT_PROGRAM && items.back().type == IT_PROGRAM;
+    if (can_fuse) {
+      head_begin = items.front().op_begin; head_count = items.front().op_count;
+      tail_begin = items.back().op_begin; tail_count = items.back().op_count;
+      // tail is the last program, so appending a copy of the head makes [tail][head] contiguous
+      std::vector<MOp> head(programs.front());
+      head[0].barrier = 1;
+      mops.insert(mops.end(), head.begin(), head.end());
+    }
+    CHK(dmalloc(&d_mops, (int64_t)mops.size() * (int64_t)sizeof(MOp)));
+    HIPCHK(hipMemcpy(d_mops, mops.data(), mops.size() * sizeof(MOp), hipMemcpyHostToDevice));
+    launches_per_step = (int)items.size() - (can_fuse ? 1 : 0);
+    return SSN_OK;
+  }
+
+  // ---- launching --------------------------------------------------------------------------
+  hipError_t launch_item(const Item& it, hipEvent_t e0, hipEvent_t e1) {
+    switch (it.type) {
+      case IT_PROGRAM: return ssn::launch_program<T>(stream, d_mops + it.op_begin, it.op_count, sig, d_ctx);
+      case IT_ENS: {
+        if (e0) { hipError_t e = hipEventRecord(e0, stream); if (e != hipSuccess) return e; }
+        hipError_t e = ssn::launch_ensarray<T>(stream, it.ens);
+        if (e != hipSuccess) return e;
+        if (e1) return hipEventRecord(e1, stream);
+        return hipSuccess;
+      }
+      case IT_MATVEC: return ssn::launch_matvec<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set);
+      case IT_NEURONS: return ssn::launch_neurons<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar);
+      case IT_PES: return ssn::launch_pes<T>(stream, it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar);
+      case IT_VOJA: return ssn::launch_voja<T>(stream, it.Wm, it.src, it.aux0, it.aux1, it.aux2, it.rows, it.cols, it.ld, it.scalar);
+    }
+    return hipErrorInvalidValue;
+  }
+
+  // `count` consecutive steps; fused = tail(s)+head(s+1) in one launch
+  hipError_t launch_steps(int count, bool fused) {
+    const int n_items = (int)items.size();
+    for (int s = 0; s < count; ++s) {
+      for (int i = 0; i < n_items; ++i) {
+        const Item& it = items[i];
+        hipError_t e = hipSuccess;
+        if (fused && can_fuse && i == 0 && s > 0) continue;               // head already ran with the previous tail
+        if (fused && can_fuse && i == n_items - 1 && s + 1 < count)
+          e = ssn::launch_program<T>(stream, d_mops + tail_begin, tail_count + head_count, sig, d_ctx);
+        else
+          e = launch_item(it, nullptr, nullptr);
+        if (e != hipSuccess) return e;
+      }
+    }
+    return hipSuccess;
+  }
+
+  int capture() {
+    if (steps_per_graph <= 1) return SSN_OK;
+    HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    hipError_t e = launch_steps(steps_per_graph, true);
+    hipError_t e2 = hipStreamEndCapture(stream, &graph);
+    HIPCHK(e);
+    HIPCHK(e2);
+    HIPCHK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+    return SSN_OK;
+  }
+
+  int run_steps(int64_t n, int profile) override {
+    HIPCHK(hipSetDevice(device));
+    if (n < 0) return fail(SSN_EINVAL, "negative step count");
+    if (n == 0) return SSN_OK;
+    HIPCHK(hipEventRecord(ev_run0, stream));
+    if (profile) {
+      int n_dom = 0;
+      for (auto& it : items) n_dom += it.dominant ? 1 : 0;
+      const size_t need = (size_t)(2 * n * std::max(1, n_dom));
+      if (need > 400000) return fail(SSN_EINVAL, "profile run too long (%lld steps): at most 200000 timed launches", (long long)n);
+      while (ev_pool.size() < need) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreate(&ev));
+        ev_pool.push_back(ev);
+      }
+      size_t k = 0;
+      for (int64_t s = 0; s < n; ++s)
+        for (auto& it : items) {
+          if (it.dominant) { HIPCHK(launch_item(it, ev_pool[k], ev_pool[k + 1])); k += 2; }
+          else HIPCHK(launch_item(it, nullptr, nullptr));
+        }
+      HIPCHK(hipEventRecord(ev_run1, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      for (size_t j = 0; j < k; j += 2) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev_pool[j], ev_pool[j + 1]));
+        dom_ms += ms;
+        dom_launches += 1;
+      }
+    } else {
+      int64_t left = n;
+      if (graph_exec)
+        for (; left >= steps_per_graph; left -= steps_per_graph) HIPCHK(hipGraphLaunch(graph_exec, stream));
+      if (left > 0) HIPCHK(launch_steps((int)left, true));
+      HIPCHK(hipEventRecord(ev_run1, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ev_run0, ev_run1));
+    last_run_ms = ms;
+    steps_done += n;
+    ssn::StepCtx ctx;
+    HIPCHK(hipMemcpy(&ctx, d_ctx, sizeof ctx, hipMemcpyDeviceToHost));
+    if (ctx.step != steps_done) return fail(SSN_EHIP, "device step counter %lld != host %lld", (long long)ctx.step, (long long)steps_done);
+    if (ctx.probe_overflow) return fail(SSN_EINVAL, "probe storage overflow: call ssn_reserve_probes before ssn_run_steps");
+    return SSN_OK;
+  }
+
+  int reset() override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(stream));
+    CHK(upload(sig_init.data(), sig, 1, n_sig, n_sig));
+    for (auto& b : bufs)
+      if (b.keep) CHK(upload(b.host.data(), (T*)b.d, b.rows, b.cols, b.ld));
+    HIPCHK(hipMemset(d_ctx, 0, sizeof(ssn::StepCtx)));
+    steps_done = 0;
+    reserve_first = reserve_n = 0;
+    for (auto& s : pslots) { s.base_slot = 0; s.capacity = 0; }
+    if (!pslots.empty()) HIPCHK(hipMemcpy(d_pslots, pslots.data(), pslots.size() * sizeof(ssn::ProbeSlot), hipMemcpyHostToDevice));
+    dom_launches = 0; dom_ms = 0.0;
+    return SSN_OK;
+  }
+
+  int set_table(int id, const double* rows, const void* rows_dev, int64_t n_rows, int64_t width,
+                const int32_t* idx, int64_t n_idx, int64_t first_step) override {
+    HIPCHK(hipSetDevice(device));
+    if (id < 0 || id >= (int)tables.size()) return fail(SSN_EINVAL, "table id %d out of range", id);
+    if (width != tables[id].width) return fail(SSN_EINVAL, "table %d is %lld wide, got %lld", id, (long long)tables[id].width, (long long)width);
+    if (n_rows < 0 || n_idx < 0 || (!idx && n_idx)) return fail(SSN_EINVAL, "bad table arguments");
+    for (int64_t i = 0; i < n_idx; ++i)
+      if (idx[i] >= n_rows) return fail(SSN_EINVAL, "table row index %d >= n_rows %lld", idx[i], (long long)n_rows);
+    HIPCHK(hipStreamSynchronize(stream));
+    const int64_t need = std::max<int64_t>(1, n_rows * width);
+    if (need > table_rows_cap[id]) {
+      if (table_rows[id]) hipFree(table_rows[id]);
+      table_rows[id] = nullptr;
+      CHK(dmalloc((T**)&table_rows[id], need * (int64_t)sizeof(T)));
+      table_rows_cap[id] = need;
+    }
+    if (n_idx > table_idx_cap[id]) {
+      if (table_idx[id]) hipFree(table_idx[id]);
+      table_idx[id] = nullptr;
+      CHK(dmalloc(&table_idx[id], n_idx * 4));
+      table_idx_cap[id] = n_idx;
+    }
+    if (rows_dev) HIPCHK(hipMemcpy(table_rows[id], rows_dev, (size_t)(n_rows * width) * sizeof(T), hipMemcpyDeviceToDevice));
+    else if (n_rows) CHK(upload(rows, (T*)table_rows[id], n_rows, width, width));
+    if (n_idx) HIPCHK(hipMemcpy(table_idx[id], idx, (size_t)n_idx * 4, hipMemcpyHostToDevice));
+    tables[id] = ssn::TableSlot{table_rows[id], table_idx[id], n_rows, width, n_idx, first_step};
+    HIPCHK(hipMemcpy(d_tables + id, &tables[id], sizeof(ssn::TableSlot), hipMemcpyHostToDevice));
+    return SSN_OK;
+  }
+
+  int reserve_probes(int64_t n) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(stream));
+    reserve_first = steps_done;
+    reserve_n = n;
+    for (size_t p = 0; p < pslots.size(); ++p) {
+      const int64_t every = probes[p].every;
+      const int64_t base = steps_done / every;
+      const int64_t cap = (steps_done + n) / every - base;
+      const int64_t bytes = std::max<int64_t>(1, cap * probes[p].width) * (int64_t)sizeof(T);
+      if (bytes > probe_cap_bytes[p]) {
+        if (pslots[p].data) hipFree(pslots[p].data);
+        pslots[p].data = nullptr;
+        CHK(dmalloc((T**)&pslots[p].data, bytes));
+        probe_cap_bytes[p] = bytes;
+      }
+      pslots[p].base_slot = base;
+      pslots[p].capacity = cap;
+    }
+    if (!pslots.empty()) HIPCHK(hipMemcpy(d_pslots, pslots.data(), pslots.size() * sizeof(ssn::ProbeSlot), hipMemcpyHostToDevice));
+    return SSN_OK;
+  }
+
+  int64_t probe_count(int id) override {
+    if (id < 0 || id >= (int)pslots.size()) return -1;
+    const int64_t every = probes[id].every;
+    return std::min<int64_t>(pslots[id].capacity, steps_done / every - pslots[id].base_slot);
+  }
+
+  int read_probe(int id, double* dst, void* dst_dev, int64_t first, int64_t count) override {
+    HIPCHK(hipSetDevice(device));
+    if (id < 0 || id >= (int)pslots.size()) return fail(SSN_EINVAL, "probe id %d out of range", id);
+    if (first < 0 || count < 0 || first + count > probe_count(id))
+      return fail(SSN_EINVAL, "probe %d holds %lld samples, asked for [%lld,+%lld)", id, (long long)probe_count(id), (long long)first, (long long)count);
+    const int64_t w = probes[id].width;
+    const T* src = (const T*)pslots[id].data + first * w;
+    if (dst_dev) {
+      HIPCHK(hipMemcpyAsync(dst_dev, src, (size_t)(count * w) * sizeof(T), hipMemcpyDeviceToDevice, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      return SSN_OK;
+    }
+    return download(src, dst, count, w, w);
+  }
+
+  int rw_signal(int64_t off, int64_t count, double* dst, const double* src) override {
+    HIPCHK(hipSetDevice(device));
+    CHK(check_range(off, count, "signal access"));
+    return dst ? download(sig + off, dst, 1, count, count) : upload(src, sig + off, 1, count, count);
+  }
+
+  int rw_buffer(int id, double* dst, const double* src, int64_t count) override {
+    HIPCHK(hipSetDevice(device));
+    if (id < 0 || id >= (int)bufs.size()) return fail(SSN_EINVAL, "buffer id %d out of range", id);
+    Buf& b = bufs[id];
+    if (b.kind != SSN_BUF_REAL || count != b.count) return fail(SSN_EINVAL, "buffer %d: real buffer of %lld elements expected", id, (long long)b.count);
+    return dst ? download((const T*)b.d, dst, b.rows, b.cols, b.ld) : upload(src, (T*)b.d, b.rows, b.cols, b.ld);
+  }
+
+  int counters(ssn_counters* out) override {
+    out->n_steps = steps_done;
+    out->launches_per_step = launches_per_step;
+    out->dominant_launches = dom_launches;
+    out->dominant_ms_total = dom_ms;
+    out->dominant_bytes_per_launch = dom_bytes;
+    out->dominant_units_per_launch = dom_units;
+    out->last_run_ms = last_run_ms;
+    out->device_bytes = device_bytes;
+    return SSN_OK;
+  }
+
+  int64_t n_steps() override { return steps_done; }
+};
+
+template <typename T>
+int create_sim(const ssn_model_desc* desc, ssn_sim** out) {
+  auto s = std::make_unique<Sim<T>>();
+  int rc = s->create(desc);
+  if (rc != SSN_OK) return rc;
+  *out = s.release();
+  return SSN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssn_create(const ssn_model_desc* desc, ssn_sim** out) {
+  if (!desc || !out) return fail(SSN_EINVAL, "null argument");
+  *out = nullptr;
+  if (desc->abi_version != SSN_ABI_VERSION) return fail(SSN_EINVAL, "ABI version %d != %d", desc->abi_version, SSN_ABI_VERSION);
+  if (desc->n_signals <= 0 || !desc->signal_init || desc->n_ops <= 0 || !desc->ops || desc->dt <= 0)
+    return fail(SSN_EINVAL, "empty or inconsistent model description");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SSN_EHIP, "no HIP device available (there is no CPU fallback)");
+  if (desc->device < 0 || desc->device >= ndev) return fail(SSN_EINVAL, "device %d out of range (%d devices)", desc->device, ndev);
+  if (desc->dtype == SSN_F32) return create_sim<float>(desc, out);
+  if (desc->dtype == SSN_F64) return create_sim<double>(desc, out);
+  return fail(SSN_EINVAL, "unknown dtype %d", desc->dtype);
+}
+
+void ssn_destroy(ssn_sim* sim) { delete sim; }
+int ssn_reset(ssn_sim* sim) { return sim ? sim->reset() : fail(SSN_EINVAL, "null simulator"); }
+int ssn_set_table(ssn_sim* sim, int32_t id, const double* rows, int64_t n_rows, int64_t width, const int32_t* idx,
+                  int64_t n_idx, int64_t first_step) {
+  if (!sim || (!rows && n_rows)) return fail(SSN_EINVAL, "null argument");
+  return sim->set_table(id, rows, nullptr, n_rows, width, idx, n_idx, first_step);
+}
+int ssn_set_table_device(ssn_sim* sim, int32_t id, const void* rows_dev, int64_t n_rows, int64_t width,
+                         const int32_t* idx, int64_t n_idx, int64_t first_step) {
+  if (!sim || !rows_dev) return fail(SSN_EINVAL, "null argument");
+  return sim->set_table(id, nullptr, rows_dev, n_rows, width, idx, n_idx, first_step);
+}
+int ssn_reserve_probes(ssn_sim* sim, int64_t n) { return sim ? sim->reserve_probes(n) : fail(SSN_EINVAL, "null simulator"); }
+int ssn_run_steps(ssn_sim* sim, int64_t n, int32_t profile) { return sim ? sim->run_steps(n, profile) : fail(SSN_EINVAL, "null simulator"); }
+int ssn_read_probe(ssn_sim* sim, int32_t id, double* dst, int64_t first, int64_t count) {
+  if (!sim || (!dst && count)) return fail(SSN_EINVAL, "null argument");
+  return sim->read_probe(id, dst, nullptr, first, count);
+}
+int ssn_read_probe_device(ssn_sim* sim, int32_t id, void* dst_dev, int64_t first, int64_t count) {
+  if (!sim || !dst_dev) return fail(SSN_EINVAL, "null argument");
+  return sim->read_probe(id, nullptr, dst_dev, first, count);
+}
+int64_t ssn_probe_count(ssn_sim* sim, int32_t id) { return sim ? sim->probe_count(id) : -1; }
+int ssn_read_signal(ssn_sim* sim, int64_t off, int64_t count, double* dst) {
+  if (!sim || !dst) return fail(SSN_EINVAL, "null argument");
+  return sim->rw_signal(off, count, dst, nullptr);
+}
+int ssn_write_signal(ssn_sim* sim, int64_t off, int64_t count, const double* src) {
+  if (!sim || !src) return fail(SSN_EINVAL, "null argument");
+  return sim->rw_signal(off, count, nullptr, src);
+}
+int ssn_read_buffer(ssn_sim* sim, int32_t id, double* dst, int64_t count) {
+  if (!sim || !dst) return fail(SSN_EINVAL, "null argument");
+  return sim->rw_buffer(id, dst, nullptr, count);
+}
+int ssn_write_buffer(ssn_sim* sim, int32_t id, const double* src, int64_t count) {
+  if (!sim || !src) return fail(SSN_EINVAL, "null argument");
+  return sim->rw_buffer(id, nullptr, src, count);
+}
+int ssn_get_counters(ssn_sim* sim, ssn_counters* out) {
+  if (!sim || !out) return fail(SSN_EINVAL, "null argument");
+  return sim->counters(out);
+}
+int64_t ssn_n_steps(ssn_sim* sim) { return sim ? sim->n_steps() : -1; }
+int ssn_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+const char* ssn_last_error(void) { return g_err.c_str(); }
+const char* ssn_version(void) { return "libssn_hip 0.1 (gfx950, ABI 1)"; }
+
+}  // extern "C"

@@ -1,0 +1,440 @@
+// ssn_kernels.hpp - gfx950 (MI355X, CDNA4) kernels of the SSP-SLAM step loop, templated on the
+// arithmetic type T (float = fast mode, double = parity mode).  Included by ssn_f32.hip / ssn_f64.hip,
+// which explicitly instantiate the launchers declared in ssn_launch.hpp.
+//
+// Kernel             replaces (merged nengo operators)                       bound
+// k_ensarray<T,..>   Reset+DotInc(enc)+SimNeurons(LIF)+DotInc(dec) of an EnsembleArray    HBM stream
+// k_program<T>       every small vector op of a step (fill/table/axpy/lowpass/...)        latency
+// k_matvec<T>        dense DotInc (one 64-lane wave per output row)                       HBM / L2
+// k_neurons<T>       SimNeurons on a current vector                                       HBM
+// k_pes<T>           SimPES + weight increment (fused outer-product update)               HBM
+// k_voja<T>          SimVoja + encoder increment (rows of spiking neurons only)           spike-sparse
+//
+// All kernels are wave64: reductions use 64-lane shuffles, block sizes are multiples of 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ssn_launch.hpp"
+
+namespace ssn {
+
+template <typename T> struct VecT;
+template <> struct VecT<float>  { using type = float4;  static constexpr int W = 4; };
+template <> struct VecT<double> { using type = double2; static constexpr int W = 2; };
+
+__device__ inline float  expm1_(float x)  { return expm1f(x); }
+__device__ inline double expm1_(double x) { return expm1(x); }
+__device__ inline float  log1p_(float x)  { return log1pf(x); }
+__device__ inline double log1p_(double x) { return log1p(x); }
+
+// ---------------------------------------------------------------------------------------------
+// neuron models.  Returns the unit-amplitude activity: spike 0/1 or rate.
+// Operation order follows the oracle (oracle/stepper.py lif_step) so that the f64 build, compiled
+// with -ffp-contract=off, tracks it to rounding.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ inline T neuron_step(const NeuronParams<T>& p, T J, T& V, T& R) {
+  if (p.type == 0) {                                   // LIF
+    R = R - p.dt;
+    T delta = p.dt - R;
+    delta = delta < T(0) ? T(0) : (delta > p.dt ? p.dt : delta);
+    V = V - (J - V) * expm1_(-delta / p.tau_rc);
+    if (V > T(1)) {
+      T t_spike = p.dt + p.tau_rc * log1p_(-(V - T(1)) / (J - T(1)));
+      V = T(0);
+      R = p.tau_ref + t_spike;
+      return T(1);
+    }
+    if (V < p.min_voltage) V = p.min_voltage;
+    return T(0);
+  } else if (p.type == 1) {                            // LIFRate
+    T j = J - T(1);
+    return j > T(0) ? T(1) / (p.tau_ref + p.tau_rc * log1p_(T(1) / j)) : T(0);
+  }
+  return J > T(0) ? J : T(0);                          // ReLU
+}
+
+template <typename T>
+__device__ inline T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ensarray: K equal ensembles of n neurons, din-dimensional, dout decoded rows each.
+//   grid = K * P workgroups of 256 threads; workgroup (k, p) streams a contiguous chunk of
+//   ensemble k's neurons once: enc[din] + bias + V + R in, V + R out, dec[dout] in -
+//   (din + dout + 5) words per neuron-step, every access a 16-byte-per-lane coalesced vector.
+//   Spikes never leave registers.  Each workgroup leaves dout partial sums; the P partials of an
+//   ensemble are added in fixed order by the ENS_FINISH micro-op of the following program
+//   (deterministic, no atomics).
+// Layout: enc [K][DIN][n_pad], bias/V/R [K][n_pad], dec [K][DOUT][n_pad], n_pad % W == 0.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int DIN, int DOUT>
+__global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
+  using vec = typename VecT<T>::type;
+  constexpr int W = VecT<T>::W;
+  const int k = blockIdx.x / a.P;
+  const int p = blockIdx.x - k * a.P;
+  const size_t row = (size_t)a.n_pad;
+  const T* __restrict__ enc = a.enc + (size_t)k * DIN * row;
+  const T* __restrict__ bias = a.bias + (size_t)k * row;
+  const T* __restrict__ dec = a.dec + (size_t)k * DOUT * row;
+  T* __restrict__ Vp = a.V + (size_t)k * row;
+  T* __restrict__ Rp = a.R + (size_t)k * row;
+
+  T x[DIN];
+#pragma unroll
+  for (int d = 0; d < DIN; ++d) x[d] = a.sig[a.x_off + (int64_t)k * DIN + d];
+
+  T acc[DOUT];
+#pragma unroll
+  for (int r = 0; r < DOUT; ++r) acc[r] = T(0);
+
+  const int n_vec = a.n_pad / W;
+  const int v_begin = p * a.chunk_vec;
+  const int v_end = min(n_vec, v_begin + a.chunk_vec);
+  for (int v = v_begin + (int)threadIdx.x; v < v_end; v += 256) {
+    const size_t o = (size_t)v * W;
+    T e[DIN][W], b[W], Vv[W], Rv[W], dd[DOUT][W];
+#pragma unroll
+    for (int d = 0; d < DIN; ++d) *(vec*)e[d] = *(const vec*)(enc + d * row + o);
+    *(vec*)b = *(const vec*)(bias + o);
+    *(vec*)Vv = *(const vec*)(Vp + o);
+    *(vec*)Rv = *(const vec*)(Rp + o);
+#pragma unroll
+    for (int r = 0; r < DOUT; ++r) *(vec*)dd[r] = *(const vec*)(dec + r * row + o);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      if ((int)o + j < a.n) {
+        T J = b[j];
+#pragma unroll
+        for (int d = 0; d < DIN; ++d) J += e[d][j] * x[d];
+        const T act = neuron_step(a.np, J, Vv[j], Rv[j]);
+#pragma unroll
+        for (int r = 0; r < DOUT; ++r) acc[r] += act * dd[r][j];
+      }
+    }
+    *(vec*)(Vp + o) = *(vec*)Vv;
+    *(vec*)(Rp + o) = *(vec*)Rv;
+  }
+
+  __shared__ T red[4][DOUT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < DOUT; ++r) {
+    const T s = wave_sum(acc[r]);
+    if (lane == 0) red[wave][r] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < DOUT) {
+    const int r = threadIdx.x;
+    a.partials[((size_t)k * a.P + p) * DOUT + r] = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+  }
+}
+
+template <typename T, int DIN>
+static hipError_t launch_ens_dout(hipStream_t s, const EnsArgs<T>& a) {
+  const dim3 grid((unsigned)(a.K * a.P)), block(256);
+  switch (a.dout) {
+#define SSN_CASE(D) case D: hipLaunchKernelGGL((k_ensarray<T, DIN, D>), grid, block, 0, s, a); break;
+    SSN_CASE(1) SSN_CASE(2) SSN_CASE(3) SSN_CASE(4) SSN_CASE(5) SSN_CASE(6) SSN_CASE(7) SSN_CASE(8)
+#undef SSN_CASE
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_ensarray(hipStream_t s, const EnsArgs<T>& a) {
+  switch (a.din) {
+    case 1: return launch_ens_dout<T, 1>(s, a);
+    case 2: return launch_ens_dout<T, 2>(s, a);
+    case 3: return launch_ens_dout<T, 3>(s, a);
+    case 4: return launch_ens_dout<T, 4>(s, a);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_program: one workgroup interprets a list of small vector operators back to back, with a
+// workgroup barrier only where the host scheduler found a dependency (level change).  This turns
+// the dozen tiny nengo operators between two big kernels into a single launch.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__ ops, int n_ops,
+                                                  T* __restrict__ sig, StepCtx* __restrict__ ctx) {
+  __shared__ T sred[16];
+  __shared__ int sidx[16];
+  const int tid = threadIdx.x;
+  long long step = ctx->step;          // steps completed before the one being executed
+  for (int o = 0; o < n_ops; ++o) {
+    const MicroOp<T> op = ops[o];
+    if (op.barrier) __syncthreads();
+    switch (op.kind) {
+      case M_FILL:
+        for (long long i = tid; i < op.len; i += 1024) sig[op.dst + i] = op.a;
+        break;
+      case M_AXPY_INC:
+        for (long long i = tid; i < op.len; i += 1024) sig[op.dst + i] += op.a * sig[op.src + i];
+        break;
+      case M_AXPY_SET:
+        for (long long i = tid; i < op.len; i += 1024) sig[op.dst + i] = op.a * sig[op.src + i];
+        break;
+      case M_LOWPASS:   // dst = a*dst + b*src, b = (1-a)*gain
+        for (long long i = tid; i < op.len; i += 1024)
+          sig[op.dst + i] = op.a * sig[op.dst + i] + op.b * sig[op.src + i];
+        break;
+      case M_TABLE: {   // p0 = TableSlot*
+        const TableSlot* t = (const TableSlot*)op.p0;
+        const long long rel = step - t->first_step;
+        int row = -1;
+        if (rel >= 0 && rel < t->n_idx) row = t->idx[rel];
+        const T* rows = (const T*)t->rows;
+        for (long long i = tid; i < op.len; i += 1024)
+          sig[op.dst + i] = (row >= 0 && row < t->n_rows) ? rows[(size_t)row * t->width + i] : T(0);
+        break;
+      }
+      case M_MATVEC_INC:
+      case M_MATVEC_SET: {   // p0 = W (rows x ld), i0 = cols, i1 = ld; len = rows
+        const T* Wm = (const T*)op.p0;
+        for (long long r = tid; r < op.len; r += 1024) {
+          T s = T(0);
+          for (int c = 0; c < (int)op.i0; ++c) s += Wm[(size_t)r * op.i1 + c] * sig[op.src + c];
+          if (op.kind == M_MATVEC_INC) sig[op.dst + r] += s; else sig[op.dst + r] = s;
+        }
+        break;
+      }
+      case M_ENS_FINISH: {   // p0 = partials [K][P][dout], p1 = dst_idx int32 [K*dout]; len = K*dout, i0 = P, i1 = dout
+        const T* part = (const T*)op.p0;
+        const int* didx = (const int*)op.p1;
+        const int P = (int)op.i0, dout = (int)op.i1;
+        for (long long i = tid; i < op.len; i += 1024) {
+          const long long k = i / dout, r = i - k * dout;
+          T s = T(0);
+          for (int p = 0; p < P; ++p) s += part[((size_t)k * P + p) * dout + r];
+          sig[didx[i]] = s;
+        }
+        break;
+      }
+      case M_GATE: {   // src = [est(d), cur(d), flag], len = d, a = thres, b = rate
+        T part = T(0);
+        for (long long i = tid; i < op.len; i += 1024) part += sig[op.src + i] * sig[op.src + op.len + i];
+        part = wave_sum(part);
+        if ((tid & 63) == 0) sred[tid >> 6] = part;
+        __syncthreads();
+        T dot = T(0);
+        for (int w = 0; w < 16; ++w) dot += sred[w];
+        const T flag = sig[op.src + 2 * op.len];
+        const bool open = (flag <= T(1e-3) && flag >= T(-1e-3)) && dot > op.a;
+        for (long long i = tid; i < op.len; i += 1024)
+          sig[op.dst + i] = open ? op.b * (sig[op.src + i] - sig[op.src + op.len + i]) : T(0);
+        __syncthreads();
+        break;
+      }
+      case M_ARGMAX_GATHER: {   // src = sims (i0 rows), p0 = table (i0 x ld=i1), len = cols: dst = table[argmax]
+        T best = T(-INFINITY);
+        int bi = 0x7fffffff;
+        for (int i = tid; i < (int)op.i0; i += 1024) {
+          const T v = sig[op.src + i];
+          if (v > best) { best = v; bi = i; }     // first maximum within a thread (ascending i)
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const T ov = __shfl_down(best, off, 64);
+          const int oi = __shfl_down(bi, off, 64);
+          if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if ((tid & 63) == 0) { sred[tid >> 6] = best; sidx[tid >> 6] = bi; }
+        __syncthreads();
+        best = sred[0]; bi = sidx[0];
+        for (int w = 1; w < 16; ++w)
+          if (sred[w] > best || (sred[w] == best && sidx[w] < bi)) { best = sred[w]; bi = sidx[w]; }
+        if (bi == 0x7fffffff) bi = 0;
+        const T* tab = (const T*)op.p0;
+        for (long long i = tid; i < op.len; i += 1024) sig[op.dst + i] = tab[(size_t)bi * op.i1 + i];
+        __syncthreads();
+        break;
+      }
+      case M_PROBE: {   // p0 = ProbeSlot*; src, len = width
+        const ProbeSlot* ps = (const ProbeSlot*)op.p0;
+        const long long s1 = step + 1;
+        if (s1 % ps->every == 0) {
+          const long long slot = s1 / ps->every - 1 - ps->base_slot;
+          if (slot >= 0 && slot < ps->capacity) {
+            T* out = (T*)ps->data + (size_t)slot * op.len;
+            for (long long i = tid; i < op.len; i += 1024) out[i] = sig[op.src + i];
+          } else if (tid == 0) {
+            ctx->probe_overflow = 1;
+          }
+        }
+        break;
+      }
+      case M_STEP_END:
+        step += 1;
+        if (tid == 0) ctx->step = step;
+        break;
+      default:
+        break;
+    }
+  }
+}
+
+template <typename T>
+hipError_t launch_program(hipStream_t s, const MicroOp<T>* d_ops, int n_ops, T* sig, StepCtx* ctx) {
+  hipLaunchKernelGGL((k_program<T>), dim3(1), dim3(1024), 0, s, d_ops, n_ops, sig, ctx);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_matvec: y (+)= W x, W row-major [rows][ld].  One wave per row, 16-byte vector loads of W,
+// x re-read through L1/L2 (it is a few KB).  If x is identically zero (the correction input of the
+// path integrator outside loop closures) the wave skips W entirely - exact, and it saves the
+// whole matrix read.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_matvec(const T* __restrict__ Wm, const T* __restrict__ sig_src,
+                                                T* __restrict__ sig_dst, int rows, int cols, int ld, int set) {
+  using vec = typename VecT<T>::type;
+  constexpr int W = VecT<T>::W;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  int nz = 0;
+  for (int c = lane; c < cols; c += 64) nz |= (sig_src[c] != T(0));
+  if (!__any(nz)) {
+    if (set && lane == 0) sig_dst[row] = T(0);
+    return;
+  }
+  const T* wr = Wm + (size_t)row * ld;
+  T s = T(0);
+  const int n_vec = cols / W;
+  for (int v = lane; v < n_vec; v += 64) {
+    T w[W];
+    *(vec*)w = *(const vec*)(wr + (size_t)v * W);
+#pragma unroll
+    for (int j = 0; j < W; ++j) s += w[j] * sig_src[v * W + j];
+  }
+  for (int c = n_vec * W + lane; c < cols; c += 64) s += wr[c] * sig_src[c];
+  s = wave_sum(s);
+  if (lane == 0) { if (set) sig_dst[row] = s; else sig_dst[row] += s; }
+}
+
+template <typename T>
+hipError_t launch_matvec(hipStream_t s, const T* Wm, const T* src, T* dst, int rows, int cols, int ld, int set) {
+  hipLaunchKernelGGL((k_matvec<T>), dim3((rows + 3) / 4), dim3(256), 0, s, Wm, src, dst, rows, cols, ld, set);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_neurons(NeuronParams<T> np, const T* __restrict__ J, T* __restrict__ out,
+                                                 T* __restrict__ V, T* __restrict__ R, int n, T amp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  T v = V[i], r = R[i];
+  const T a = neuron_step(np, J[i], v, r);
+  V[i] = v; R[i] = r;
+  out[i] = amp * a;
+}
+
+template <typename T>
+hipError_t launch_neurons(hipStream_t s, const NeuronParams<T>& np, const T* J, T* out, T* V, T* R, int n, T amp) {
+  hipLaunchKernelGGL((k_neurons<T>), dim3((n + 255) / 256), dim3(256), 0, s, np, J, out, V, R, n, amp);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pes: W[r][c] += kappa * err[r] * act[c]   (fused delta + increment).
+// One workgroup per (row, 1024-column tile): act is read once per tile, W streamed once.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_pes(T* __restrict__ Wm, const T* __restrict__ err, const T* __restrict__ act,
+                                             int rows, int cols, int ld, T kappa) {
+  const int r = blockIdx.y;
+  const T e = kappa * err[r];
+  if (e == T(0)) return;
+  T* wr = Wm + (size_t)r * ld;
+  const int c0 = blockIdx.x * 1024;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + j * 256 + threadIdx.x;
+    if (c < cols) wr[c] += e * act[c];
+  }
+}
+
+template <typename T>
+hipError_t launch_pes(hipStream_t s, T* Wm, const T* err, const T* act, int rows, int cols, int ld, T kappa) {
+  hipLaunchKernelGGL((k_pes<T>), dim3((cols + 1023) / 1024, rows), dim3(256), 0, s, Wm, err, act, rows, cols, ld, kappa);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_voja: for each neuron i that spiked (a_i != 0):
+//   E[i][:] += lr_dt * (1 + learn) * (scale_i * a_i * key[:] - a_i * E[i][:])      (Appendix A.8)
+// One wave per neuron row; silent neurons exit after one load.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_voja(T* __restrict__ E, const T* __restrict__ spk, const T* __restrict__ key,
+                                              const T* __restrict__ learn, const T* __restrict__ scale,
+                                              int rows, int cols, int ld, T lr_dt) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= rows) return;
+  const T a = spk[i];
+  if (a == T(0)) return;
+  const T g = lr_dt * (T(1) + learn[0]);
+  const T sa = scale[i] * a;
+  T* er = E + (size_t)i * ld;
+  for (int c = lane; c < cols; c += 64) er[c] += g * (sa * key[c] - a * er[c]);
+}
+
+template <typename T>
+hipError_t launch_voja(hipStream_t s, T* E, const T* spk, const T* key, const T* learn, const T* scale,
+                       int rows, int cols, int ld, T lr_dt) {
+  hipLaunchKernelGGL((k_voja<T>), dim3((rows + 3) / 4), dim3(256), 0, s, E, spk, key, learn, scale, rows, cols, ld, lr_dt);
+  return hipGetLastError();
+}
+
+// conversion helpers for uploads / downloads (host double <-> device T), row-padded
+template <typename T>
+__global__ void k_convert_in(const double* __restrict__ src, T* __restrict__ dst, int64_t rows, int64_t cols, int64_t ld) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * ld) return;
+  const int64_t r = i / ld, c = i - r * ld;
+  dst[i] = c < cols ? (T)src[r * cols + c] : T(0);
+}
+template <typename T>
+__global__ void k_convert_out(const T* __restrict__ src, double* __restrict__ dst, int64_t rows, int64_t cols, int64_t ld) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int64_t r = i / cols, c = i - r * cols;
+  dst[i] = (double)src[r * ld + c];
+}
+template <typename T>
+hipError_t launch_convert_in(hipStream_t s, const double* src, T* dst, int64_t rows, int64_t cols, int64_t ld) {
+  const int64_t n = rows * ld;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((k_convert_in<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, cols, ld);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_convert_out(hipStream_t s, const T* src, double* dst, int64_t rows, int64_t cols, int64_t ld) {
+  const int64_t n = rows * cols;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((k_convert_out<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, cols, ld);
+  return hipGetLastError();
+}
+
+#define SSN_INSTANTIATE(T)                                                                                   \
+  template hipError_t launch_ensarray<T>(hipStream_t, const EnsArgs<T>&);                                    \
+  template hipError_t launch_program<T>(hipStream_t, const MicroOp<T>*, int, T*, StepCtx*);                  \
+  template hipError_t launch_matvec<T>(hipStream_t, const T*, const T*, T*, int, int, int, int);            \
+  template hipError_t launch_neurons<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T); \
+  template hipError_t launch_pes<T>(hipStream_t, T*, const T*, const T*, int, int, int, T);                 \
+  template hipError_t launch_voja<T>(hipStream_t, T*, const T*, const T*, const T*, const T*, int, int, int, T); \
+  template hipError_t launch_convert_in<T>(hipStream_t, const double*, T*, int64_t, int64_t, int64_t);      \
+  template hipError_t launch_convert_out<T>(hipStream_t, const T*, double*, int64_t, int64_t, int64_t);
+
+}  // namespace ssn

@@ -1,0 +1,74 @@
+// ssn_launch.hpp - argument structs and launcher declarations shared by the host executor
+// (ssn_host.hip) and the kernel translation units (ssn_f32.hip, ssn_f64.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ssn {
+
+template <typename T>
+struct NeuronParams {
+  int type;            // 0 LIF, 1 LIFRate, 2 ReLU
+  T dt, tau_rc, tau_ref, min_voltage;
+};
+
+template <typename T>
+struct EnsArgs {
+  const T* enc;        // [K][din][n_pad]
+  const T* bias;       // [K][n_pad]
+  const T* dec;        // [K][dout][n_pad]   (pre-scaled by amplitude/dt)
+  T* V;                // [K][n_pad]
+  T* R;                // [K][n_pad]
+  const T* sig;        // signal vector (reads x)
+  T* partials;         // [K][P][dout]
+  int64_t x_off;
+  int K, n, n_pad, din, dout;
+  int P;               // chunks (workgroups) per ensemble
+  int chunk_vec;       // 16-byte vectors per chunk
+  NeuronParams<T> np;
+};
+
+enum MicroKind {
+  M_FILL = 1, M_AXPY_INC, M_AXPY_SET, M_LOWPASS, M_TABLE, M_MATVEC_INC, M_MATVEC_SET, M_ENS_FINISH,
+  M_GATE, M_ARGMAX_GATHER, M_PROBE, M_STEP_END
+};
+
+template <typename T>
+struct MicroOp {
+  int kind;
+  int barrier;         // workgroup barrier before this op
+  long long dst, src, len;
+  T a, b;
+  const void* p0;
+  const void* p1;
+  long long i0, i1;
+};
+
+struct TableSlot {     // lives in device memory; re-pointed by ssn_set_table without re-planning
+  const void* rows;    // [n_rows][width] in simulator dtype
+  const int* idx;      // [n_idx]
+  long long n_rows, width, n_idx, first_step;
+};
+
+struct ProbeSlot {
+  void* data;          // [capacity][width]
+  long long every, base_slot, capacity;
+};
+
+struct StepCtx {
+  long long step;      // steps completed
+  int probe_overflow;
+  int pad;
+};
+
+template <typename T> hipError_t launch_ensarray(hipStream_t, const EnsArgs<T>&);
+template <typename T> hipError_t launch_program(hipStream_t, const MicroOp<T>*, int, T*, StepCtx*);
+template <typename T> hipError_t launch_matvec(hipStream_t, const T* W, const T* src, T* dst, int rows, int cols, int ld, int set);
+template <typename T> hipError_t launch_neurons(hipStream_t, const NeuronParams<T>&, const T* J, T* out, T* V, T* R, int n, T amp);
+template <typename T> hipError_t launch_pes(hipStream_t, T* W, const T* err, const T* act, int rows, int cols, int ld, T kappa);
+template <typename T> hipError_t launch_voja(hipStream_t, T* E, const T* spk, const T* key, const T* learn, const T* scale,
+                                            int rows, int cols, int ld, T lr_dt);
+template <typename T> hipError_t launch_convert_in(hipStream_t, const double* src, T* dst, int64_t rows, int64_t cols, int64_t ld);
+template <typename T> hipError_t launch_convert_out(hipStream_t, const T* src, double* dst, int64_t rows, int64_t cols, int64_t ld);
+
+}  // namespace ssn

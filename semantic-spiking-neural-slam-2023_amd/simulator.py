@@ -1,0 +1,328 @@
+"""``Simulator``: the ``nengo.Simulator`` API on top of the HIP step loop (libssn_hip.so).
+
+Mirrors the simulator surface the reference's scripts use (SURVEY §8b;
+``experiments/run_pathint.py:147-165,171-181``, ``experiments/run_slam.py:198-235,250-268``):
+
+    sim = Simulator(model, dt=0.001)        # build + upload + plan + capture the step graph
+    with sim:
+        sim.run(T)                          # == run_steps(round(T/dt))
+    sim.data[probe]                         # (n_samples, size) float64 ndarray
+    sim.trange()                            # dt * arange(1, n_steps + 1)
+    sim.data[ensemble].gain / .bias / .encoders / .scaled_encoders / ...
+
+Python never runs inside the step loop: Nodes that are functions of ``t`` only are evaluated once
+per step *before* the run and uploaded as tables (``prepare``); function nodes with inputs must map
+to a kernel (``node.native``).  Errors from the library surface as ``SimulationError`` /
+``BuildError`` (nengo's exception names).
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib
+from . import frontend as fe
+from .builder import BuiltModel, build
+
+
+class SimulationData(dict):
+    """``sim.data``: probes map to sample arrays, model objects to their built parameters."""
+
+    def __init__(self, sim):
+        super().__init__()
+        self._sim = sim
+
+    def __getitem__(self, key):
+        sim = self._sim
+        if key in sim._probe_index:
+            return sim._probe_array(key)
+        if key in sim.model.params:
+            return sim.model.params[key]
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key in self._sim._probe_index or key in self._sim.model.params
+
+
+def pack_model(model, dtype, device=0, steps_per_graph=0):
+    """BuiltModel -> (ssn_model_desc, keep-alive list) for ``ssn_create``."""
+    keep = []
+    sig_init = np.ascontiguousarray(model.sig_init, dtype=np.float64)
+    keep.append(sig_init)
+    bufs = (_lib.BufferDesc * max(1, len(model.buffers)))()
+    for i, b in enumerate(model.buffers):
+        if b.dtype.kind in "iu":
+            arr = np.ascontiguousarray(b, dtype=np.int32)
+            kind = _lib.SSN_BUF_I32
+        else:
+            arr = np.ascontiguousarray(b, dtype=np.float64)
+            kind = _lib.SSN_BUF_REAL
+        keep.append(arr)
+        bufs[i].data = arr.ctypes.data
+        bufs[i].count = arr.size
+        bufs[i].kind = kind
+    ops = (_lib.OpDesc * len(model.ops))()
+    for j, o in enumerate(model.ops):
+        k = o["kind"]
+        d = ops[j]
+        d.kind = _lib.OP_CODE[k]
+        d.level = int(o.get("level", 0))
+        ii, ff = [0] * 12, [0.0] * 4
+        if k == "fill":
+            ii[:2] = [o["dst"], o["len"]]
+            ff[0] = o["value"]
+        elif k == "table":
+            ii[:3] = [o["dst"], o["width"], o["table"]]
+        elif k == "axpy":
+            ii[:4] = [o["dst"], o["src"], o["len"], 1 if o["mode"] == "set" else 0]
+            ff[0] = o["alpha"]
+        elif k == "matvec":
+            ii[:6] = [o["dst"], o["src"], o["rows"], o["cols"], o["w"], 1 if o["mode"] == "set" else 0]
+        elif k == "lowpass":
+            ii[:3] = [o["dst"], o["src"], o["len"]]
+            ff[:2] = [o["a"], o["gain"]]
+        elif k == "ensarray":
+            nd = o["neuron"]
+            ii[:12] = [o["x"], o["K"], o["n"], o["din"], o["dout"], o["enc"], o["bias"], o["dec"], o["dst_idx"],
+                       o["v"], o["r"], _lib.NEURON_CODE[nd["type"]]]
+            ff[:3] = [nd["tau_rc"], nd["tau_ref"], nd["min_voltage"]]
+        elif k == "neurons":
+            nd = o["neuron"]
+            ii[:6] = [o["j"], o["out"], o["n"], o["v"], o["r"], _lib.NEURON_CODE[nd["type"]]]
+            ff[:4] = [nd["tau_rc"], nd["tau_ref"], nd["min_voltage"], o["amp"]]
+        elif k == "pes":
+            ii[:5] = [o["w"], o["rows"], o["cols"], o["err"], o["act"]]
+            ff[0] = o["kappa"]
+        elif k == "voja":
+            ii[:7] = [o["w"], o["rows"], o["cols"], o["spk"], o["key"], o["learn"], o["scale_buf"]]
+            ff[0] = o["lr_dt"]
+        elif k == "cleanup":
+            ii[:5] = [o["dst"], o["src"], o["rows"], o["cols"], o["w"]]
+        elif k == "gate":
+            ii[:3] = [o["dst"], o["src"], o["d"]]
+            ff[:2] = [o["thres"], o["rate"]]
+        else:
+            raise fe.BuildError(f"operator {k!r} has no device encoding")
+        for a in range(12):
+            d.i[a] = int(ii[a])
+        for a in range(4):
+            d.f[a] = float(ff[a])
+    sig_probes = [p for p in model.probes if "src" in p]
+    probes = (_lib.ProbeDesc * max(1, len(sig_probes)))()
+    for j, p in enumerate(sig_probes):
+        probes[j].src, probes[j].width, probes[j].every = int(p["src"]), int(p["width"]), int(p["every"])
+    desc = _lib.ModelDesc()
+    desc.abi_version = _lib.SSN_ABI_VERSION
+    desc.dtype = _lib.SSN_F64 if dtype in ("f64", "float64", np.float64) else _lib.SSN_F32
+    desc.device = int(device)
+    desc.n_tables = len(model.tables)
+    desc.dt = model.dt
+    desc.n_signals = model.sig_size
+    desc.signal_init = sig_init.ctypes.data_as(C.POINTER(C.c_double))
+    desc.n_buffers, desc.n_ops, desc.n_probes = len(model.buffers), len(model.ops), len(sig_probes)
+    desc.steps_per_graph = int(steps_per_graph)
+    desc.buffers, desc.ops, desc.probes = bufs, ops, probes
+    keep += [bufs, ops, probes]
+    return desc, keep, sig_probes
+
+
+def tabulate(fn, width, steps, dt):
+    """Evaluate a t-only node function for 1-based step numbers ``steps`` with nengo's time
+    ``t = step*dt`` (float64) and run-length-encode equal consecutive rows."""
+    rows, idx = [], np.empty(len(steps), dtype=np.int32)
+    prev = None
+    for j, s in enumerate(steps):
+        v = np.asarray(fn(s * dt), dtype=np.float64).reshape(-1)
+        if v.size != width:
+            raise fe.SimulationError(f"node function returned {v.size} values, expected {width}")
+        if prev is None or not np.array_equal(v, prev):
+            rows.append(v)
+            prev = v
+        idx[j] = len(rows) - 1
+    return (np.stack(rows) if rows else np.zeros((0, width))), idx
+
+
+class Simulator:
+    def __init__(self, network, dt=0.001, seed=None, progress_bar=None, dtype="f32", device=0,
+                 n_eval_points=None, steps_per_graph=0, model=None, vco_shard=None):
+        self.dt = float(dt)
+        self.closed = True
+        self._lib = _lib.load()          # fails loudly when the HIP library is not built
+        if model is None:
+            if isinstance(network, BuiltModel):
+                model = network
+            else:
+                model = build(network, dt=dt, seed=seed, n_eval_points=n_eval_points, vco_shard=vco_shard)
+        self.model = model
+        self.dtype = "f64" if dtype in ("f64", "float64", np.float64) else "f32"
+        desc, keep, self._sig_probes = pack_model(model, self.dtype, device, steps_per_graph)
+        self._h = C.c_void_p()
+        t0 = time.time()
+        self._check(self._lib.ssn_create(C.byref(desc), C.byref(self._h)), build=True)
+        self.upload_seconds = time.time() - t0
+        del keep
+        self.closed = False
+        self._probe_index = {}
+        self._chunks = {}
+        for j, p in enumerate(self._sig_probes):
+            self._probe_index[p["probe"]] = ("sig", j, p)
+        for p in model.probes:
+            if "src" not in p:
+                self._probe_index[p["probe"]] = ("buf", None, p)
+        for key in self._probe_index:
+            self._chunks[key] = []
+        self.data = SimulationData(self)
+        self._prepared_until = 0
+        self.n_steps = 0
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc, build=False):
+        if rc != 0:
+            msg = f"{_lib.STATUS.get(rc, rc)}: {_lib.last_error()}"
+            raise (fe.BuildError if build else fe.SimulationError)(msg)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def close(self):
+        if not self.closed:
+            self._lib.ssn_destroy(self._h)
+            self.closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def time(self):
+        return self.n_steps * self.dt
+
+    def trange(self, sample_every=None):
+        every = 1 if sample_every is None else max(1, int(round(sample_every / self.dt)))
+        return self.dt * every * np.arange(1, self.n_steps // every + 1)
+
+    # -- inputs --------------------------------------------------------------------------------
+    def prepare(self, n_steps):
+        """Tabulate every t-only node for the next ``n_steps`` steps, upload the tables and reserve
+        probe storage, so that ``run_steps(n_steps)`` starts with all inputs resident in HBM."""
+        n_steps = int(n_steps)
+        first = self.n_steps
+        steps = np.arange(first + 1, first + n_steps + 1)
+        for tid, tb in enumerate(self.model.tables):
+            rows, idx = tabulate(tb["fn"], tb["width"], steps, self.dt)
+            rows = np.ascontiguousarray(rows, dtype=np.float64)
+            self._check(self._lib.ssn_set_table(self._h, tid, rows.ctypes.data, rows.shape[0], tb["width"],
+                                                idx.ctypes.data, idx.size, first))
+        self._check(self._lib.ssn_reserve_probes(self._h, n_steps))
+        self._prepared_until = first + n_steps
+
+    def set_table_device(self, table_id, rows_dev_ptr, n_rows, idx, first_step):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        tb = self.model.tables[table_id]
+        self._check(self._lib.ssn_set_table_device(self._h, table_id, C.c_void_p(rows_dev_ptr), n_rows, tb["width"],
+                                                   idx.ctypes.data, idx.size, first_step))
+
+    # -- running -------------------------------------------------------------------------------
+    def run(self, time_in_seconds, progress_bar=None):
+        self.run_steps(int(np.round(float(time_in_seconds) / self.dt)))
+
+    def step(self):
+        self.run_steps(1)
+
+    def run_steps(self, steps, profile=False, collect=True):
+        steps = int(steps)
+        if steps <= 0:
+            return
+        if self.closed:
+            raise fe.SimulationError("simulator is closed")
+        if self._prepared_until < self.n_steps + steps or self._prepared_until == 0:
+            self.prepare(steps)
+        buf_probes = [(k, v[2]) for k, v in self._probe_index.items() if v[0] == "buf"]
+        done = 0
+        while done < steps:
+            chunk = steps - done
+            for _, p in buf_probes:
+                chunk = min(chunk, p["every"] - (self.n_steps % p["every"]))
+            self._check(self._lib.ssn_run_steps(self._h, chunk, 1 if profile else 0))
+            self.n_steps += chunk
+            done += chunk
+            for key, p in buf_probes:
+                if self.n_steps % p["every"] == 0:
+                    self._chunks[key].append(self.read_buffer(self._probe_buffer_id(p))[None])
+        if collect:
+            self._collect()
+        self._prepared_until = max(self._prepared_until, self.n_steps)
+
+    def _probe_buffer_id(self, p):
+        b = p["buf"]
+        if isinstance(b, tuple):
+            return self.model.params[p["ens"]].encoder_buffer
+        return b
+
+    def _collect(self):
+        # samples of the current reservation are re-read in full and replace its previous chunk
+        for key, (kind, j, p) in self._probe_index.items():
+            if kind != "sig":
+                continue
+            n = int(self._lib.ssn_probe_count(self._h, j))
+            out = np.empty((n, p["width"]), dtype=np.float64)
+            if n:
+                self._check(self._lib.ssn_read_probe(self._h, j, out.ctypes.data, 0, n))
+            tag = self._reservation_tag()
+            chunks = self._chunks[key]
+            if chunks and isinstance(chunks[-1], tuple) and chunks[-1][0] == tag:
+                chunks[-1] = (tag, out)
+            else:
+                chunks.append((tag, out))
+
+    def _reservation_tag(self):
+        return self._prepared_until
+
+    def _probe_array(self, key):
+        kind, j, p = self._probe_index[key]
+        chunks = [c[1] if isinstance(c, tuple) else c for c in self._chunks[key]]
+        if not chunks:
+            width = p.get("width")
+            return np.zeros((0, width)) if width else np.zeros((0,) + tuple(p["shape"]))
+        return np.concatenate(chunks, axis=0)
+
+    # -- state access ----------------------------------------------------------------------------
+    def read_signal(self, off, count):
+        out = np.empty(count, dtype=np.float64)
+        self._check(self._lib.ssn_read_signal(self._h, off, count, out.ctypes.data))
+        return out
+
+    def write_signal(self, off, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._check(self._lib.ssn_write_signal(self._h, off, v.size, v.ctypes.data))
+
+    def read_buffer(self, buffer_id):
+        shape = self.model.buffers[buffer_id].shape
+        out = np.empty(shape, dtype=np.float64)
+        self._check(self._lib.ssn_read_buffer(self._h, buffer_id, out.ctypes.data, out.size))
+        return out
+
+    def write_buffer(self, buffer_id, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._check(self._lib.ssn_write_buffer(self._h, buffer_id, v.ctypes.data, v.size))
+
+    def read_probe_device(self, probe, dst_ptr, first, count):
+        kind, j, p = self._probe_index[probe]
+        self._check(self._lib.ssn_read_probe_device(self._h, j, C.c_void_p(dst_ptr), first, count))
+
+    def counters(self):
+        c = _lib.Counters()
+        self._check(self._lib.ssn_get_counters(self._h, C.byref(c)))
+        return {f: getattr(c, f) for f, _ in c._fields_}
+
+    def reset(self, seed=None):
+        self._check(self._lib.ssn_reset(self._h))
+        self.n_steps = 0
+        self._prepared_until = 0
+        for k in self._chunks:
+            self._chunks[k] = []
