@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py - simulated seconds per wall-clock second of the SSP-SLAM path integrator on MI355X.
+
+Metric (BASELINE.json): sim-sec / wall-sec of the simulator step loop (``n_steps*dt / wall(sim.run)``,
+build excluded - reference ``experiments/run_pathint.py:160-165``) for ``PathIntegration`` 2-D,
+``ssp_dim=1015``, ``pi_n_neurons=10000`` per VCO (508 VCO ensembles, 5.08 M LIF neurons), synthetic
+band-limited random path, random-seed 0.
+
+    python bench.py --gpus 1 --steps K --warmup W
+
+One "step" = one block of ``--block`` simulator timesteps (default 1000 = one simulated second) with all
+inputs already resident in HBM.  The timed region is exactly K blocks between barrier +
+torch.cuda.synchronize() pairs; the max over ranks is taken; rank 0 prints one JSON line.
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) the 508 VCO ensembles of the SAME
+model are sharded over the ranks (strong scaling): each rank steps its VCOs, the decoded
+oscillator states are all-gathered once per block (RCCL) and rank 0 applies the linear read-out.
+
+Extra legs on rank 0 at N = 1 (both outside the timed region):
+  * roofline: every launch of the dominant kernel (k_ensarray) of a 500-step pass is bracketed with HIP
+    events on the simulator's stream; achieved = algorithmic bytes per launch / average duration.
+  * cpu_baseline: the NumPy float64 oracle (oracle/stepper.py, a restatement of nengo's reference
+    simulator) stepping the same built model for a bounded sample of timesteps on the host cores; the
+    GPU trajectory is checked against it on that window (parity, cosine error).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10, help="timed blocks")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed blocks")
+    ap.add_argument("--block", type=int, default=1000, help="simulator timesteps per block")
+    ap.add_argument("--ssp-dim", type=int, default=1015)
+    ap.add_argument("--pi-n-neurons", type=int, default=10000)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--eval-points", type=int, default=4000,
+                    help="decoder-solve eval points per VCO (nengo's default max(1500, 2n) = 20000 costs ~10x the build)")
+    ap.add_argument("--cpu-steps", type=int, default=60, help="oracle timesteps for the cpu_baseline / parity leg (0 = skip)")
+    ap.add_argument("--profile-steps", type=int, default=500)
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from sspslam_amd import harness as H
+    from sspslam_amd.builder import build
+    from sspslam_amd.simulator import Simulator
+    from sspslam_amd.sharding import ShardedPathIntegration
+
+    dt = 0.001
+    n_total = (args.steps + args.warmup) * args.block
+    T_path = max(20.0, (n_total + args.profile_steps + 10) * dt)
+    space = H.make_ssp_space(2, args.ssp_dim)
+    path, vels = H.make_random_path(T_path, dt=dt, limit=0.1, seed=args.seed)
+    pm = H.make_pathint_model(space, path, vels, args.pi_n_neurons, seed=args.seed)
+    K = (space.ssp_dim + 1) // 2
+    N = K * args.pi_n_neurons
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t0 = time.time()
+    if world == 1:
+        model = build(pm.model, dt=dt, n_eval_points=args.eval_points)
+        sim = Simulator(None, model=model, dtype=args.dtype, device=local_rank)
+        runner = None
+    else:
+        runner = ShardedPathIntegration(pm, rank, world, dt=dt, dtype=args.dtype, device=local_rank,
+                                        n_eval_points=args.eval_points, block=args.block)
+        sim, model = runner.sim, runner.model
+    build_s = time.time() - t0
+
+    def run_block():
+        if runner is None:
+            sim.run_steps(args.block, collect=False)
+        else:
+            runner.run_block()
+
+    if runner is None:
+        sim.prepare(n_total)
+    else:
+        runner.prepare(n_total)
+    for _ in range(args.warmup):
+        run_block()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_block()
+    barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        w = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+    sim_seconds = args.steps * args.block * dt
+    value = sim_seconds / wall
+
+    out = {
+        "metric": "sim-sec/wall-sec, SSP-SLAM ssp_dim=1015 10k PI neurons, 1/2/4/8 MI355X",
+        "value": round(value, 4), "unit": "sim-sec/wall-sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"PathIntegration 2-D ssp_dim={space.ssp_dim} pi_n_neurons={args.pi_n_neurons}/VCO "
+                               f"({K} VCOs, {N} LIF neurons), configs[1]",
+                   "timesteps_per_step": args.block, "dt": dt, "eval_points_per_vco": args.eval_points,
+                   "parallelism": "1 GPU" if world == 1 else f"VCO-sharded x{world}, all-gather per {args.block} steps",
+                   "build_seconds": round(build_s, 1)},
+    }
+
+    if rank == 0 and world == 1:
+        # ---- roofline leg: HIP events around every launch of the dominant kernel ----------------------
+        sim.run_steps(args.profile_steps, profile=True, collect=False)
+        c = sim.counters()
+        if c["dominant_launches"]:
+            avg_ms = c["dominant_ms_total"] / c["dominant_launches"]
+            achieved = c["dominant_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                               "kernel": "k_ensarray", "avg_launch_us": round(avg_ms * 1e3, 2),
+                               "algorithmic_bytes_per_launch": c["dominant_bytes_per_launch"],
+                               "bytes_per_neuron_step": c["dominant_bytes_per_launch"] / c["dominant_units_per_launch"],
+                               "launches_timed": c["dominant_launches"],
+                               "launches_per_timestep": c["launches_per_step"]}
+        sim._collect()
+        gpu_probe = sim.data[pm.probe]
+        # ---- cpu_baseline + parity leg ----------------------------------------------------------------
+        if args.cpu_steps > 0:
+            from oracle import OracleSimulator
+            try:
+                from threadpoolctl import threadpool_info
+                cores = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+            except Exception:
+                cores = 1
+            ref = OracleSimulator(model)
+            t0 = time.perf_counter()
+            ref.run_steps(args.cpu_steps)
+            cpu_wall = time.perf_counter() - t0
+            cpu_value = args.cpu_steps * dt / cpu_wall
+            want = ref.probe_data(0)
+            k = args.cpu_steps
+            lo = min(20, k // 2)
+            ce = H.cosine_error(gpu_probe[lo:k], want[lo:k])
+            out["cpu_baseline"] = {"value": round(cpu_value, 6), "unit": "sim-sec/wall-sec", "cores": int(cores),
+                                   "kind": "port",
+                                   "sample": f"first {k} timesteps of the same built model, NumPy float64 oracle "
+                                             f"(nengo-equivalent merged-operator stepping), {os.cpu_count()} host cpus visible"}
+            out["parity"] = {"window_timesteps": k, "max_cosine_error": float(ce.max()),
+                             "max_abs_diff": float(np.abs(gpu_probe[:k] - want[:k]).max()), "bar": 1e-3}
+            out["gpu_over_cpu"] = round(value / cpu_value, 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

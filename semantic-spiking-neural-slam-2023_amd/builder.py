@@ -145,12 +145,14 @@ def _lowpass_coeff(tau, dt):
 # --------------------------------------------------------------------------------------------
 class Builder:
     def __init__(self, network, dt=0.001, seed=None, n_eval_points=None, solver_backend="auto",
-                 vco_shard=None, progress=None):
+                 vco_shard=None, progress=None, probes=None, prune=False):
         self.net, self.dt = network, float(dt)
         self.n_eval_points = n_eval_points
         self.solver_backend = solver_backend
         self.vco_shard = vco_shard           # (rank, world): build only this rank's slice of every EnsembleArray
         self.progress = progress
+        self.probes_override = probes        # build with these probes instead of the network's own
+        self.prune = prune                   # drop operators that no probe (transitively) depends on
         self.model = BuiltModel(dt)
         self.arena_size = {a: 0 for a in "RWSCT"}
         self.inits = []                      # (Ref, values)
@@ -184,7 +186,10 @@ class Builder:
         conns = list(net.all_connections)
         probes = list(net.all_probes)
         rng = np.random.RandomState(self.root_seed)
-        for obj in ensembles + nodes + conns + probes:
+        all_probes = probes
+        if self.probes_override is not None:
+            probes = list(self.probes_override)
+        for obj in ensembles + nodes + conns + all_probes + [p for p in probes if p not in all_probes]:
             s = getattr(obj, "seed", None)
             self.seed_of[id(obj)] = int(s) if s is not None else int(rng.randint(2 ** 31 - 1))
 
@@ -718,6 +723,8 @@ class Builder:
             for key, r in table.items():
                 m.sig[(name, key)] = (A(r), r.len)
         ops = merge_ops(ops, m)
+        if self.prune:
+            ops = prune_ops(ops, m)
         m.ops = schedule_ops(ops, m)
         m.stats.update(n_raw_ops=len(self.raw_ops), n_ops=len(m.ops), sig_size=m.sig_size,
                        n_buffers=len(m.buffers))
@@ -814,6 +821,36 @@ def op_access(o, model):
     raise fe.BuildError(f"unknown op kind {k}")
 
 
+def prune_ops(ops, model):
+    """Dead-operator elimination: keep only operators whose writes can reach a probe, directly or
+    through synapse states / neuron state over later timesteps (fixed point).  Used for the per-rank
+    shard of a VCO-sharded model, where the read-out chain runs elsewhere."""
+    acc = [op_access(o, model) for o in ops]
+    live = []
+    for p in model.probes:
+        if "src" in p:
+            live.append(("s", p["src"], p["src"] + p["width"]))
+        else:
+            b = p["buf"]
+            live.append(("b", b if not isinstance(b, tuple) else -1))
+    keep = [False] * len(ops)
+    changed = True
+    while changed:
+        changed = False
+        for i, a in enumerate(acc):
+            if keep[i]:
+                continue
+            writes = a[0] + a[1] + a[3]
+            if any(_overlap(w, l) for w in writes for l in live):
+                keep[i] = True
+                live.extend(a[2])
+                # an update reads its own previous state; an inc reads the accumulator it adds to
+                live.extend(a[1])
+                live.extend(a[3])
+                changed = True
+    return [o for o, k in zip(ops, keep) if k]
+
+
 def _overlap(a, b):
     if a[0] != b[0]:
         return False
@@ -878,7 +915,8 @@ def schedule_ops(ops, model):
     return out
 
 
-def build(network, dt=0.001, seed=None, n_eval_points=None, solver_backend="auto", vco_shard=None):
+def build(network, dt=0.001, seed=None, n_eval_points=None, solver_backend="auto", vco_shard=None,
+          probes=None, prune=False):
     """Build ``network`` into a :class:`BuiltModel`."""
-    return Builder(network, dt=dt, seed=seed, n_eval_points=n_eval_points,
-                   solver_backend=solver_backend, vco_shard=vco_shard).build()
+    return Builder(network, dt=dt, seed=seed, n_eval_points=n_eval_points, solver_backend=solver_backend,
+                   vco_shard=vco_shard, probes=probes, prune=prune).build()

@@ -1,0 +1,139 @@
+"""Multi-GPU execution of the path integrator: VCO ensembles sharded over ranks.
+
+The VCO ensembles of ``PathIntegration`` are mutually independent (each one's recurrence touches only
+itself, reference ``networks/pathintegration.py:173-185``); the only cross-VCO coupling is the linear
+read-out ``to_SSP @ oscillators.output`` (``:191``).  So, one process per GPU:
+
+* rank r builds and steps only VCOs ``[r*ceil(K/W), (r+1)*ceil(K/W))`` - same seeds as the unsharded
+  model, so the union of the shards IS that model; everything the shard does not need (the read-out
+  chain) is pruned from its operator list;
+* every ``block`` timesteps the ranks all-gather their decoded oscillator outputs
+  (``block x 3*K/W`` values per rank; RCCL over xGMI under torch.distributed's "nccl" backend, gloo
+  on CPU) - exact, because nothing downstream feeds back into the oscillators within a
+  PathIntegration-only model - and rank 0 replays the gathered block through the read-out
+  (``to_SSP`` -> Lowpass(5 ms) -> output node -> probe filter), a second small simulator whose input
+  node is tabulated from the gathered data.
+
+The simulator factory is injectable so the orchestration is exercised on CPU (gloo, world_size 2)
+against the oracle in tests; by default it is the HIP ``Simulator``.
+"""
+import numpy as np
+
+from . import frontend as nengo
+from .builder import build
+
+
+def shard_range(K, rank, world):
+    per = -(-K // world)
+    return min(K, rank * per), min(K, (rank + 1) * per), per
+
+
+class _BlockFeed:
+    """Node function of the read-out's input: serves rows of the last gathered block."""
+
+    def __init__(self, width, dt):
+        self.width, self.dt = width, dt
+        self.rows = np.zeros((0, width))
+        self.first = 0          # 0-based step number of rows[0]
+
+    def __call__(self, t):
+        j = int(round(t / self.dt)) - 1 - self.first
+        return self.rows[j] if 0 <= j < self.rows.shape[0] else np.zeros(self.width)
+
+    def table(self, steps):
+        j = np.asarray(steps) - 1 - self.first
+        ok = (j >= 0) & (j < self.rows.shape[0])
+        return self.rows, np.where(ok, j, -1).astype(np.int32)
+
+
+class ShardedPathIntegration:
+    def __init__(self, pm, rank, world, dt=0.001, dtype="f32", device=0, n_eval_points=None, block=1000,
+                 sim_factory=None, dist=None, gather_device=None):
+        """``pm``: object from ``harness.make_pathint_model`` (model, pathintegrator, probe)."""
+        if dist is None:
+            import torch.distributed as dist
+        self.dist, self.rank, self.world, self.dt, self.block = dist, rank, world, dt, int(block)
+        pi = pm.pathintegrator
+        K = pi.n_oscs
+        self.K = K
+        self.lo, self.hi, self.per = shard_range(K, rank, world)
+        if sim_factory is None:
+            from .simulator import Simulator
+
+            def sim_factory(model):
+                return Simulator(None, model=model, dtype=dtype, device=device)
+        self.gather_device = gather_device
+        # --- this rank's VCO shard: probe = local slice of the oscillator output node ----------------
+        with pm.model:
+            width = 3 * (self.hi - self.lo)
+            self.osc_probe = nengo.Probe(pi.oscillators.output[3 * self.lo:3 * self.hi], synapse=None) \
+                if width else None
+        if self.osc_probe is not None:
+            pm.model.probes.remove(self.osc_probe)
+        probes = [self.osc_probe] if self.osc_probe is not None else []
+        self.model = build(pm.model, dt=dt, n_eval_points=n_eval_points, vco_shard=(rank, world),
+                           probes=probes, prune=True)
+        self.sim = sim_factory(self.model)
+        # --- rank 0: the read-out replayed from gathered blocks ---------------------------------------
+        self.readout = None
+        if rank == 0:
+            d = pi.to_SSP.shape[0]
+            self.feed = _BlockFeed(3 * K, dt)
+            psyn = pm.probe.synapse.tau if pm.probe.synapse is not None else None
+            with nengo.Network(seed=0) as ro:
+                src = nengo.Node(self.feed, size_out=3 * K, label="gathered_osc_output")
+                out = nengo.Node(size_in=d, label="pathint_output")
+                nengo.Connection(src, out, transform=pi.to_SSP)       # default synapse, as pathintegration.py:191
+                self.ro_probe = nengo.Probe(out, synapse=psyn)
+            self.readout_model = build(ro, dt=dt)
+            self.readout = sim_factory(self.readout_model)
+        self.n_steps = 0
+
+    def prepare(self, n_steps):
+        self.sim.prepare(n_steps)
+
+    def _gather(self, local):
+        """local (B, 3*(hi-lo)) float64 -> (B, 3K) on every rank."""
+        import torch
+        B = local.shape[0]
+        send = np.zeros((B, 3 * self.per))
+        send[:, :local.shape[1]] = local
+        dev = self.gather_device
+        if dev is None:
+            dev = torch.device("cuda", torch.cuda.current_device()) if self.dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.from_numpy(send).to(dev)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        full = torch.cat(outs, dim=1).cpu().numpy()
+        return full[:, :3 * self.K]
+
+    def run_block(self, n=None):
+        n = self.block if n is None else int(n)
+        self.sim.run_steps(n, collect=True)
+        if self.osc_probe is not None:
+            local = self.sim.probe_tail(self.osc_probe, n)
+            self.sim.clear_probe_data()
+        else:
+            local = np.zeros((n, 0))
+        full = self._gather(local) if self.world > 1 else local
+        if self.readout is not None:
+            self.feed.rows, self.feed.first = np.ascontiguousarray(full), self.n_steps
+            self.readout.prepare(n)
+            self.readout.run_steps(n)
+        self.n_steps += n
+
+    def run_steps(self, n):
+        done = 0
+        while done < n:
+            c = min(self.block, n - done)
+            self.run_block(c)
+            done += c
+
+    def probe_data(self):
+        """Rank 0: the filtered PathIntegration output, as ``sim.data[probe]`` of the unsharded model."""
+        return self.readout.data[self.ro_probe] if self.readout is not None else None
+
+    def close(self):
+        for s in (self.sim, self.readout):
+            if s is not None and hasattr(s, "close"):
+                s.close()

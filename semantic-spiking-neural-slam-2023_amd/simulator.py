@@ -129,6 +129,9 @@ def pack_model(model, dtype, device=0, steps_per_graph=0):
 def tabulate(fn, width, steps, dt):
     """Evaluate a t-only node function for 1-based step numbers ``steps`` with nengo's time
     ``t = step*dt`` (float64) and run-length-encode equal consecutive rows."""
+    if hasattr(fn, "table"):          # vectorised provider: (rows, idx) for all steps at once
+        rows, idx = fn.table(np.asarray(steps))
+        return np.asarray(rows, dtype=np.float64).reshape(-1, width), np.asarray(idx, dtype=np.int32)
     rows, idx = [], np.empty(len(steps), dtype=np.int32)
     prev = None
     for j, s in enumerate(steps):
@@ -290,6 +293,22 @@ class Simulator:
             width = p.get("width")
             return np.zeros((0, width)) if width else np.zeros((0,) + tuple(p["shape"]))
         return np.concatenate(chunks, axis=0)
+
+    def probe_tail(self, key, n):
+        """The last ``n`` samples of a probe without concatenating the whole history."""
+        out, need = [], int(n)
+        for c in reversed(self._chunks[key]):
+            a = c[1] if isinstance(c, tuple) else c
+            out.append(a[-need:] if need < a.shape[0] else a)
+            need -= out[-1].shape[0]
+            if need <= 0:
+                break
+        return np.concatenate(out[::-1], axis=0) if out else np.zeros((0, self._probe_index[key][2]["width"]))
+
+    def clear_probe_data(self):
+        """Forget samples already handed out (long sharded runs stream blocks through)."""
+        for k in self._chunks:
+            self._chunks[k] = []
 
     # -- state access ----------------------------------------------------------------------------
     def read_signal(self, off, count):

