@@ -214,6 +214,8 @@ class Simulator:
         """Tabulate every t-only node for the next ``n_steps`` steps, upload the tables and reserve
         probe storage, so that ``run_steps(n_steps)`` starts with all inputs resident in HBM."""
         n_steps = int(n_steps)
+        if getattr(self, "_uncollected", False):
+            self._collect()              # a new reservation drops device-side samples: fetch them first
         first = self.n_steps
         steps = np.arange(first + 1, first + n_steps + 1)
         for tid, tb in enumerate(self.model.tables):
@@ -257,6 +259,7 @@ class Simulator:
             for key, p in buf_probes:
                 if self.n_steps % p["every"] == 0:
                     self._chunks[key].append(self.read_buffer(self._probe_buffer_id(p))[None])
+        self._uncollected = True
         if collect:
             self._collect()
         self._prepared_until = max(self._prepared_until, self.n_steps)
@@ -268,6 +271,7 @@ class Simulator:
         return b
 
     def _collect(self):
+        self._uncollected = False
         # samples of the current reservation are re-read in full and replace its previous chunk
         for key, (kind, j, p) in self._probe_index.items():
             if kind != "sig":
