@@ -163,9 +163,16 @@ class OracleSimulator:
                     E[nz] += o["lr_dt"] * learning * (
                         (scale[nz] * a[nz])[:, None] * key[None, :] - a[nz, None] * E[nz])
             elif k == "cleanup":
+                # S[argmax(S @ x)] (slam.py:212-215).  The products are summed column by column so the
+                # result does not depend on a BLAS's blocking: while the path integrator's output holds only
+                # its DC term every grid point has the same similarity up to rounding, and the pick is
+                # decided by summation order.
                 T = buf[o["w"]]
                 x = sig[o["src"]:o["src"] + o["cols"]]
-                sig[o["dst"]:o["dst"] + o["cols"]] = T[int(np.argmax(T @ x))]
+                sims = np.zeros(T.shape[0], dtype=T.dtype)
+                for j in range(T.shape[1]):
+                    sims += T[:, j] * x[j]
+                sig[o["dst"]:o["dst"] + o["cols"]] = T[int(np.argmax(sims))]
             elif k == "gate":
                 d = o["d"]
                 x = sig[o["src"]:o["src"] + 2 * d + 1]

@@ -240,6 +240,7 @@ class Builder:
         # parameters of every ensemble (cheap, vectorised); decoders are solved on demand
         for e in ensembles:
             self._build_ensemble_params(e)
+        conns = self._drop_dead_ends(conns, nodes, probes)
         for c in conns:
             self._lower_connection(c)
         for p in probes:
@@ -255,6 +256,21 @@ class Builder:
         self.model.stats["build_seconds"] = time.time() - t0
         self.model.stats["n_neurons"] = int(sum(e.n_neurons for e in ensembles))
         return self.model
+
+    def _drop_dead_ends(self, conns, nodes, probes):
+        """Connections into passthrough Nodes that nothing reads (no outgoing connection, no probe) -
+        e.g. the unused default ``output`` of the squaring EnsembleArrays (binding.py:297-317) - cannot
+        influence any result; skipping them saves their decoder solves and per-step decoding."""
+        probed = {id(_contig(p.target)[0]) for p in probes}
+        conns = list(conns)
+        while True:
+            has_out = {id(_contig(c.pre)[0]) for c in conns}
+            dead = {id(n) for n in nodes if getattr(n, "output", None) is None and n.size_in > 0
+                    and id(n) not in has_out and id(n) not in probed}
+            kept = [c for c in conns if id(_contig(c.post)[0]) not in dead]
+            if len(kept) == len(conns):
+                return kept
+            conns = kept
 
     # -- nodes -----------------------------------------------------------------------------
     def _alloc_node(self, n):

@@ -59,7 +59,7 @@ struct Buf {
   std::vector<double> host;               // initial contents if keep
 };
 
-enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA };
+enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED };
 
 }  // namespace
 
@@ -106,6 +106,7 @@ struct Sim final : ssn_sim {
   std::vector<double> sig_init;
   std::vector<Buf> bufs;
   std::vector<Item> items;                   // one timestep, unfused
+  std::vector<void*> scratch_bufs;
   std::vector<MOp> mops;                     // [head][middle programs...][tail][head copy]
   MOp* d_mops = nullptr;
   int head_begin = 0, head_count = 0, tail_begin = 0, tail_count = 0;
@@ -145,6 +146,7 @@ struct Sim final : ssn_sim {
     for (auto p : table_idx) if (p) hipFree(p);
     for (auto& s : pslots) if (s.data) hipFree(s.data);
     for (auto& it : items) if (it.type == IT_ENS && it.ens.partials) hipFree(it.ens.partials);
+    for (auto p : scratch_bufs) if (p) hipFree(p);
     for (auto e : ev_pool) hipEventDestroy(e);
     if (ev_run0) hipEventDestroy(ev_run0);
     if (ev_run1) hipEventDestroy(ev_run1);
@@ -455,8 +457,28 @@ struct Sim final : ssn_sim {
           break;
         }
         case SSN_OP_CLEANUP: {
-          // similarities into a scratch region appended to the signal vector, then argmax + row gather
-          return fail(SSN_EUNSUPPORTED, "cleanup operator: use ssn built with the SLAM operator set");
+          // similarities S @ x into a scratch vector (k_matvec), then argmax + row gather in the next program
+          flush();
+          const Buf& w = bufs[o.i[4]];
+          T* scratch = nullptr;
+          CHK(dmalloc(&scratch, o.i[2] * (int64_t)sizeof(T)));
+          scratch_bufs.push_back(scratch);
+          Item it; it.type = IT_MATVEC; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.dst = scratch;
+          it.rows = (int)o.i[2]; it.cols = (int)o.i[3]; it.ld = (int)w.ld; it.set = 1;
+          if (sizeof(T) == 8) {
+            // parity mode: ordered accumulation over a transposed copy (ties are decided by rounding)
+            const int ldt = ((int)o.i[2] + VW - 1) / VW * VW;
+            T* wt = nullptr;
+            CHK(dmalloc(&wt, (int64_t)o.i[3] * ldt * (int64_t)sizeof(T)));
+            scratch_bufs.push_back(wt);
+            HIPCHK(ssn::launch_transpose<T>(stream, (const T*)w.d, wt, (int)o.i[2], (int)o.i[3], (int)w.ld, ldt));
+            it.type = IT_MATVEC_ORDERED; it.Wm = wt; it.ld = ldt;
+          }
+          items.push_back(it);
+          MOp g{};
+          g.kind = ssn::M_ARGMAX_GATHER; g.dst = o.i[0]; g.len = o.i[3]; g.i0 = o.i[2]; g.i1 = w.ld; g.p0 = w.d; g.p1 = scratch;
+          push_micro(g, o.level, true);
+          break;
         }
         default: return fail(SSN_EINVAL, "unknown operator kind %d", o.kind);
       }
@@ -515,6 +537,7 @@ struct Sim final : ssn_sim {
         return hipSuccess;
       }
       case IT_MATVEC: return ssn::launch_matvec<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set);
+      case IT_MATVEC_ORDERED: return ssn::launch_matvec_ordered<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld);
       case IT_NEURONS: return ssn::launch_neurons<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar);
       case IT_PES: return ssn::launch_pes<T>(stream, it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar);
       case IT_VOJA: return ssn::launch_voja<T>(stream, it.Wm, it.src, it.aux0, it.aux1, it.aux2, it.rows, it.cols, it.ld, it.scalar);

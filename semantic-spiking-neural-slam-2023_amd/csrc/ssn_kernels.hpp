@@ -233,11 +233,12 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
         __syncthreads();
         break;
       }
-      case M_ARGMAX_GATHER: {   // src = sims (i0 rows), p0 = table (i0 x ld=i1), len = cols: dst = table[argmax]
+      case M_ARGMAX_GATHER: {   // p1 = sims (i0 rows, scratch), p0 = table (i0 x ld=i1), len = cols: dst = table[argmax]
         T best = T(-INFINITY);
         int bi = 0x7fffffff;
+        const T* sims = (const T*)op.p1;
         for (int i = tid; i < (int)op.i0; i += 1024) {
-          const T v = sig[op.src + i];
+          const T v = sims[i];
           if (v > best) { best = v; bi = i; }     // first maximum within a thread (ascending i)
         }
 #pragma unroll
@@ -324,6 +325,42 @@ __global__ __launch_bounds__(256) void k_matvec(const T* __restrict__ Wm, const 
 template <typename T>
 hipError_t launch_matvec(hipStream_t s, const T* Wm, const T* src, T* dst, int rows, int cols, int ld, int set) {
   hipLaunchKernelGGL((k_matvec<T>), dim3((rows + 3) / 4), dim3(256), 0, s, Wm, src, dst, rows, cols, ld, set);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_matvec_ordered: y[r] = sum_j Wt[j][r] * x[j] accumulated strictly in j order (one thread per row,
+// transposed matrix so that consecutive threads read consecutive addresses).  Used by the clean-up in
+// the f64 parity mode, where argmax ties are decided by rounding and the order must match the oracle.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_matvec_ordered(const T* __restrict__ Wt, const T* __restrict__ x,
+                                                        T* __restrict__ y, int rows, int cols, int ldt) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  T s = T(0);
+  for (int j = 0; j < cols; ++j) s = s + Wt[(size_t)j * ldt + r] * x[j];
+  y[r] = s;
+}
+
+template <typename T>
+__global__ void k_transpose(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols, int ld, int ldt) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+  dst[(size_t)c * ldt + r] = src[(size_t)r * ld + c];
+}
+
+template <typename T>
+hipError_t launch_matvec_ordered(hipStream_t s, const T* Wt, const T* x, T* y, int rows, int cols, int ldt) {
+  hipLaunchKernelGGL((k_matvec_ordered<T>), dim3((rows + 255) / 256), dim3(256), 0, s, Wt, x, y, rows, cols, ldt);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_transpose(hipStream_t s, const T* src, T* dst, int rows, int cols, int ld, int ldt) {
+  const int64_t n = (int64_t)rows * cols;
+  hipLaunchKernelGGL((k_transpose<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, cols, ld, ldt);
   return hipGetLastError();
 }
 
@@ -431,6 +468,8 @@ hipError_t launch_convert_out(hipStream_t s, const T* src, double* dst, int64_t 
   template hipError_t launch_ensarray<T>(hipStream_t, const EnsArgs<T>&);                                    \
   template hipError_t launch_program<T>(hipStream_t, const MicroOp<T>*, int, T*, StepCtx*);                  \
   template hipError_t launch_matvec<T>(hipStream_t, const T*, const T*, T*, int, int, int, int);            \
+  template hipError_t launch_matvec_ordered<T>(hipStream_t, const T*, const T*, T*, int, int, int);         \
+  template hipError_t launch_transpose<T>(hipStream_t, const T*, T*, int, int, int, int);                   \
   template hipError_t launch_neurons<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T); \
   template hipError_t launch_pes<T>(hipStream_t, T*, const T*, const T*, int, int, int, T);                 \
   template hipError_t launch_voja<T>(hipStream_t, T*, const T*, const T*, const T*, const T*, int, int, int, T); \

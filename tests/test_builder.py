@@ -95,13 +95,13 @@ def test_vco_shards_union_is_the_model():
     got = []
     for r in range(3):
         pm = small_pathint(ssp_dim=55, n=30, T=10.0, limit=0.2)
-        m = build(pm.model, vco_shard=(r, 3), probes=[], prune=False)
+        m = build(pm.model, vco_shard=(r, 3))
         e = next(o for o in m.ops if o["kind"] == "ensarray")
         assert e["k_total"] == 28 and e["K"] == (10 if r < 2 else 8) and e["k_lo"] == 10 * r
         np.testing.assert_array_equal(m.buffers[e["enc"]], full.buffers[ens_f["enc"]][e["k_lo"]:e["k_lo"] + e["K"]])
         np.testing.assert_array_equal(m.buffers[e["dec"]], full.buffers[ens_f["dec"]][e["k_lo"]:e["k_lo"] + e["K"]])
         got.append(e["K"])
-        assert m.sig_size == full.sig_size - 55          # same layout minus the (absent) probe filter state
+        assert m.sig_size == full.sig_size               # identical signal layout on every rank
     assert sum(got) == 28
 
 

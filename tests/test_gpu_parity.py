@@ -168,3 +168,50 @@ def test_config2_size_properties(Simulator):
         a2 = sim.data[probe]
     changed = np.any(a2 != a, axis=0).reshape(K, 5).any(1)
     assert changed[100] and changed.sum() == 1 and np.all(a2[:, 500:505] == 0)
+
+
+def _small_slam(weights_every=0.1):
+    s = H.make_ssp_space(2, 55)
+    path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
+    return H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=100, mem_n_neurons=300,
+                             circonv_n_neurons=50, view_rad=0.6, weights_sample_every=weights_every)
+
+
+def test_slam_f64_matches_oracle(Simulator):
+    """SLAMNetwork end to end: clean-up, gate, circular convolutions (product
+    ensemble arrays), dense ensembles, PES and Voja - trajectory, learned decoders and learned encoders."""
+    sm = _small_slam()
+    model = build(sm.model)
+    kinds = {o["kind"] for o in model.ops}
+    assert {"cleanup", "gate", "pes", "voja", "neurons", "ensarray", "matvec"} <= kinds
+    ref = OracleSimulator(model)
+    ref.run_steps(500)
+    mem = sm.slam.assomemory.memory
+    eb = model.params[mem].encoder_buffer
+    with Simulator(None, model=model, dtype="f64") as sim:
+        sim.run_steps(500)
+        np.testing.assert_allclose(sim.data[sm.probe], ref.probe_data(0), atol=1e-9, rtol=0)
+        W_gpu = sim.data[sm.weights_probe]
+        W_ref = ref.probe_data(1)
+        assert W_gpu.shape == W_ref.shape == (5, 55, 300) and np.abs(W_ref[-1]).max() > 1e-5   # PES learned something
+        np.testing.assert_allclose(W_gpu, W_ref, atol=1e-12, rtol=1e-9)
+        E_gpu = sim.read_buffer(eb)
+        assert np.abs(ref.buf[eb] - model.buffers[eb]).max() > 0.05                            # Voja moved encoders
+        np.testing.assert_allclose(E_gpu, ref.buf[eb], atol=1e-10, rtol=1e-9)
+        # map recall (run_slam.py:263-268) from GPU-learned decoders vs oracle-learned decoders
+        import sspslam_amd.frontend as fe
+        rec_g, pos_g = H.map_recall(sm.ssp_space, sm.lm_space, model.params[mem], fe.LIF(), W_gpu[-1])
+        rec_r, pos_r = H.map_recall(sm.ssp_space, sm.lm_space, model.params[mem], fe.LIF(), W_ref[-1])
+        np.testing.assert_allclose(rec_g, rec_r, atol=1e-9)
+        np.testing.assert_array_equal(pos_g, pos_r)
+
+
+def test_slam_f32_within_cosine_bar(Simulator):
+    sm = _small_slam(weights_every=None)
+    model = build(sm.model)
+    ref = OracleSimulator(model)
+    ref.run_steps(300)
+    with Simulator(None, model=model, dtype="f32") as sim:
+        sim.run_steps(300)
+        ce = H.cosine_error(sim.data[sm.probe][20:], ref.probe_data(0)[20:])
+    assert ce.max() < 1e-3, ce.max()

@@ -1,0 +1,60 @@
+"""Step the oracle and the HIP backend side by side and report the first signal ranges that diverge,
+with the operator that writes them.  usage: gpu_debug_compare.py [steps]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from sspslam_amd import harness as H
+from sspslam_amd.builder import build, op_access
+from sspslam_amd.simulator import Simulator
+from oracle import OracleSimulator
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+s = H.make_ssp_space(2, 55)
+path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
+sm = H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=100, mem_n_neurons=300, circonv_n_neurons=50, view_rad=0.6)
+model = build(sm.model)
+ref = OracleSimulator(model)
+sim = Simulator(None, model=model, dtype="f64", steps_per_graph=1)
+acc = [op_access(o, model) for o in model.ops]
+for t in range(steps):
+    ref.run_steps(1)
+    sim.run_steps(1)
+    g = sim.read_signal(0, model.sig_size)
+    d = np.abs(g - ref.sig)
+    bad = np.nonzero(d > 1e-9)[0]
+    bufbad = []
+    for i, meta in enumerate(model.buffer_meta):
+        if meta["role"] in ("state", "learned"):
+            gb = sim.read_buffer(i)
+            db = np.abs(gb - ref.buf[i]).max()
+            if db > 1e-9:
+                bufbad.append((i, meta["name"], float(db)))
+    if bad.size or bufbad:
+        print("step", t + 1, "first bad signals", bad[:10], "count", bad.size, "max", d.max())
+        for j, (o, a) in enumerate(zip(model.ops, acc)):
+            writes = a[0] + a[1] + a[3]
+            for w in writes:
+                if w[0] == "s":
+                    hit = bad[(bad >= w[1]) & (bad < w[2])]
+                    if hit.size:
+                        print("   op", j, o["kind"], {k: v for k, v in o.items() if k in ("dst", "src", "len", "rows", "cols", "mode", "level", "K", "n")},
+                              "bad", hit.size, "of", w[2] - w[1], "maxdiff", d[hit].max())
+        print("   buffers:", bufbad)
+        break
+else:
+    print("no divergence in", steps, "steps")
+
+cl = [o for o in model.ops if o["kind"] == "cleanup"]
+if cl:
+    o = cl[0]
+    T = model.buffers[o["w"]]
+    xg = g[o["src"]:o["src"] + o["cols"]]
+    xr = ref.sig[o["src"]:o["src"] + o["cols"]]
+    print("cleanup input diff", np.abs(xg - xr).max(), "norm", np.linalg.norm(xr))
+    sims = T @ xr
+    order = np.argsort(-sims)[:5]
+    print("oracle top5 idx", order, "sims", sims[order])
+    outg = g[o["dst"]:o["dst"] + o["cols"]]
+    outr = ref.sig[o["dst"]:o["dst"] + o["cols"]]
+    ig = np.argmin(np.abs(T - outg).sum(1)); ir = np.argmin(np.abs(T - outr).sum(1))
+    print("gpu picked", ig, "resid", np.abs(T[ig] - outg).max(), "sims there", sims[ig], "| oracle picked", ir, sims[ir])
