@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSN_ABI_VERSION 1
+#define SSN_ABI_VERSION 2
 
 enum ssn_status {
   SSN_OK = 0,
@@ -73,6 +73,10 @@ typedef struct ssn_buffer_desc {
 typedef struct ssn_op_desc {
   int32_t kind;
   int32_t level;
+  int32_t stage;        /* 0 pre, 1 core (stepped one timestep at a time), 2 post; pre/post run time-batched  */
+  int32_t border;       /* position in the time-batched order of its stage (pre/post), else -1              */
+  int32_t src_prev;     /* batched: source operand is a synapse state read before its update (previous row) */
+  int32_t reserved;
   int64_t i[12];
   double f[4];
 } ssn_op_desc;
@@ -81,7 +85,10 @@ typedef struct ssn_probe_desc {
   int64_t src;          /* signal offset  */
   int64_t width;
   int64_t every;        /* sample when (step % every) == 0, steps counted from 1 */
+  int64_t stage;        /* 1: sampled by the core every step; 0/2: sampled by a time-batched stage */
 } ssn_probe_desc;
+
+typedef struct ssn_range { int64_t lo, hi; } ssn_range;   /* signal range [lo, hi) */
 
 typedef struct ssn_model_desc {
   int32_t abi_version;  /* SSN_ABI_VERSION */
@@ -98,6 +105,14 @@ typedef struct ssn_model_desc {
   const ssn_buffer_desc* buffers;
   const ssn_op_desc* ops;
   const ssn_probe_desc* probes;
+  /* stage boundaries (host builder, stages.py): signals the pre stage hands to the core at the start of
+   * each timestep, and signals the core hands to the post stage at the end of each timestep */
+  int32_t n_pre_to_core;
+  int32_t n_core_to_post;
+  const ssn_range* pre_to_core;
+  const ssn_range* core_to_post;
+  int32_t block_steps;                /* timesteps per time-batched block; 0 = library default (256) */
+  int32_t reserved2;
 } ssn_model_desc;
 
 typedef struct ssn_counters {

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libssn_hip.so")
 
-SSN_ABI_VERSION = 1
+SSN_ABI_VERSION = 2
 SSN_F32, SSN_F64 = 0, 1
 SSN_BUF_REAL, SSN_BUF_I32 = 0, 1
 NEURON_CODE = {"lif": 0, "lifrate": 1, "relu": 2}
@@ -23,11 +23,16 @@ class BufferDesc(C.Structure):
 
 
 class OpDesc(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("level", C.c_int32), ("i", C.c_int64 * 12), ("f", C.c_double * 4)]
+    _fields_ = [("kind", C.c_int32), ("level", C.c_int32), ("stage", C.c_int32), ("border", C.c_int32),
+                ("src_prev", C.c_int32), ("reserved", C.c_int32), ("i", C.c_int64 * 12), ("f", C.c_double * 4)]
 
 
 class ProbeDesc(C.Structure):
-    _fields_ = [("src", C.c_int64), ("width", C.c_int64), ("every", C.c_int64)]
+    _fields_ = [("src", C.c_int64), ("width", C.c_int64), ("every", C.c_int64), ("stage", C.c_int64)]
+
+
+class Range(C.Structure):
+    _fields_ = [("lo", C.c_int64), ("hi", C.c_int64)]
 
 
 class ModelDesc(C.Structure):
@@ -35,7 +40,9 @@ class ModelDesc(C.Structure):
                 ("dt", C.c_double), ("n_signals", C.c_int64), ("signal_init", C.POINTER(C.c_double)),
                 ("n_buffers", C.c_int32), ("n_ops", C.c_int32), ("n_probes", C.c_int32),
                 ("steps_per_graph", C.c_int32), ("buffers", C.POINTER(BufferDesc)), ("ops", C.POINTER(OpDesc)),
-                ("probes", C.POINTER(ProbeDesc))]
+                ("probes", C.POINTER(ProbeDesc)), ("n_pre_to_core", C.c_int32), ("n_core_to_post", C.c_int32),
+                ("pre_to_core", C.POINTER(Range)), ("core_to_post", C.POINTER(Range)), ("block_steps", C.c_int32),
+                ("reserved2", C.c_int32)]
 
 
 class Counters(C.Structure):

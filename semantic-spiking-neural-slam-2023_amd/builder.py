@@ -29,6 +29,7 @@ import numpy as np
 
 from . import frontend as fe
 from .solvers import solve_decoders
+from .stages import stage_ops
 
 MICRO_KINDS = ("fill", "table", "axpy", "lowpass", "matvec_small", "gate")
 
@@ -145,12 +146,14 @@ def _lowpass_coeff(tau, dt):
 # --------------------------------------------------------------------------------------------
 class Builder:
     def __init__(self, network, dt=0.001, seed=None, n_eval_points=None, solver_backend="auto",
-                 vco_shard=None, progress=None, probes=None, prune=False):
+                 vco_shard=None, progress=None, probes=None, prune=False, staged=True):
         self.net, self.dt = network, float(dt)
         self.n_eval_points = n_eval_points
         self.solver_backend = solver_backend
         self.vco_shard = vco_shard           # (rank, world): build only this rank's slice of every EnsembleArray
         self.progress = progress
+        self.r_allocs = []
+        self.staged = staged
         self.probes_override = probes        # build with these probes instead of the network's own
         self.prune = prune                   # drop operators that no probe (transitively) depends on
         self.model = BuiltModel(dt)
@@ -166,6 +169,8 @@ class Builder:
     # -- allocation ------------------------------------------------------------------------
     def alloc(self, arena, size, init=None):
         r = Ref(arena, self.arena_size[arena], size)
+        if arena == "R" and size:
+            self.r_allocs.append((r.off, int(size)))
         self.arena_size[arena] += int(size)
         if init is not None:
             self.inits.append((r, np.asarray(init, dtype=float).reshape(-1)))
@@ -719,8 +724,6 @@ class Builder:
         for table in m.tables:
             table["dst"] = A(table.pop("ref"))
         ops = []
-        if self.arena_size["R"]:
-            ops.append({"kind": "fill", "dst": base["R"], "len": self.arena_size["R"], "value": 0.0, "seq": -1})
         for o in self.raw_ops:
             o = dict(o)
             for key in ("dst", "src", "x", "j", "out", "err", "act", "spk", "key", "learn"):
@@ -741,7 +744,8 @@ class Builder:
         ops = merge_ops(ops, m)
         if self.prune:
             ops = prune_ops(ops, m)
-        m.ops = schedule_ops(ops, m)
+        r_allocs = [(base["R"] + off, ln) for off, ln in self.r_allocs]
+        m.ops = stage_ops(ops, m, r_allocs, schedule_ops, op_access, _overlap, enable=self.staged)
         m.stats.update(n_raw_ops=len(self.raw_ops), n_ops=len(m.ops), sig_size=m.sig_size,
                        n_buffers=len(m.buffers))
 
@@ -932,7 +936,8 @@ def schedule_ops(ops, model):
 
 
 def build(network, dt=0.001, seed=None, n_eval_points=None, solver_backend="auto", vco_shard=None,
-          probes=None, prune=False):
-    """Build ``network`` into a :class:`BuiltModel`."""
+          probes=None, prune=False, staged=True):
+    """Build ``network`` into a :class:`BuiltModel`.  ``staged=False`` keeps every operator in the
+    per-timestep core (no time-batched pre/post stages)."""
     return Builder(network, dt=dt, seed=seed, n_eval_points=n_eval_points, solver_backend=solver_backend,
-                   vco_shard=vco_shard, probes=probes, prune=prune).build()
+                   vco_shard=vco_shard, probes=probes, prune=prune, staged=staged).build()

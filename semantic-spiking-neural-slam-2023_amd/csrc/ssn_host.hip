@@ -23,6 +23,8 @@
 
 namespace {
 
+__global__ void k_set_block(ssn::StepCtx* ctx, long long block_start) { ctx->block_start = block_start; }
+
 thread_local std::string g_err;
 
 int fail(int code, const char* fmt, ...) {
@@ -105,8 +107,14 @@ struct Sim final : ssn_sim {
   T* sig = nullptr;
   std::vector<double> sig_init;
   std::vector<Buf> bufs;
-  std::vector<Item> items;                   // one timestep, unfused
+  std::vector<Item> items;                   // one timestep of the core stage, unfused
   std::vector<void*> scratch_bufs;
+  // time-batched pre / post stages
+  T* bsig = nullptr;                          // [block+1][n_sig]
+  int block = 0;                              // timesteps per block (0: staging off)
+  std::vector<ssn::BatchOp<T>> pre_ops, post_ops;
+  std::vector<ssn_range> pre_to_core, core_to_post;
+  std::vector<unsigned char> batched_mask;    // signals owned by a batched stage (for ssn_read_signal)
   std::vector<MOp> mops;                     // [head][middle programs...][tail][head copy]
   MOp* d_mops = nullptr;
   int head_begin = 0, head_count = 0, tail_begin = 0, tail_count = 0;
@@ -151,6 +159,7 @@ struct Sim final : ssn_sim {
     if (ev_run0) hipEventDestroy(ev_run0);
     if (ev_run1) hipEventDestroy(ev_run1);
     if (sig) hipFree(sig);
+    if (bsig) hipFree(bsig);
     if (d_mops) hipFree(d_mops);
     if (d_ctx) hipFree(d_ctx);
     if (d_tables) hipFree(d_tables);
@@ -332,6 +341,20 @@ struct Sim final : ssn_sim {
     for (int i = 0; i < m->n_probes; ++i) pslots[i].every = probes[i].every;
     CHK(dmalloc(&d_pslots, std::max<int64_t>(1, m->n_probes) * (int64_t)sizeof(ssn::ProbeSlot)));
     if (m->n_probes) HIPCHK(hipMemcpy(d_pslots, pslots.data(), pslots.size() * sizeof(ssn::ProbeSlot), hipMemcpyHostToDevice));
+    // time-batched stages
+    bool staged = false;
+    for (int i = 0; i < m->n_ops; ++i) staged = staged || m->ops[i].stage != 1;
+    for (auto& p : probes) staged = staged || p.stage != 1;
+    batched_mask.assign((size_t)n_sig, 0);
+    if (staged) {
+      block = m->block_steps > 0 ? m->block_steps : 256;
+      CHK(dmalloc(&bsig, (int64_t)(block + 1) * n_sig * (int64_t)sizeof(T)));
+      CHK(init_bsig());
+      pre_to_core.assign(m->pre_to_core, m->pre_to_core + m->n_pre_to_core);
+      core_to_post.assign(m->core_to_post, m->core_to_post + m->n_core_to_post);
+      for (auto& r : pre_to_core) CHK(check_range(r.lo, r.hi - r.lo, "pre->core boundary"));
+      for (auto& r : core_to_post) CHK(check_range(r.lo, r.hi - r.lo, "core->post boundary"));
+    }
     CHK(plan(m));
     steps_per_graph = m->steps_per_graph > 0 ? m->steps_per_graph : 16;
     CHK(capture());
@@ -370,9 +393,35 @@ struct Sim final : ssn_sim {
     };
     int64_t best_units = -1;
     int best_item = -1;
+    for (auto& r : pre_to_core) {        // the pre stage's results for this timestep
+      MOp op{};
+      op.kind = ssn::M_ROW_IN; op.dst = r.lo; op.len = r.hi - r.lo; op.p0 = bsig; op.i0 = n_sig;
+      push_micro(op, -10, false);
+    }
+    std::vector<std::pair<int, ssn::BatchOp<T>>> pre_sorted, post_sorted;
     for (int i = 0; i < m->n_ops; ++i) {
       const ssn_op_desc& o = m->ops[i];
       MOp op{};
+      if (o.stage != 1) {
+        ssn::BatchOp<T> b{};
+        b.bsig = bsig; b.n_sig = n_sig; b.src_prev = o.src_prev ? 1 : 0;
+        int64_t wlo = 0, wlen = 0;
+        switch (o.kind) {
+          case SSN_OP_FILL: b.kind = ssn::M_FILL; b.dst = o.i[0]; b.len = o.i[1]; b.a = (T)o.f[0]; wlo = o.i[0]; wlen = o.i[1]; break;
+          case SSN_OP_TABLE: b.kind = ssn::M_TABLE; b.dst = o.i[0]; b.len = o.i[1]; b.p0 = d_tables + o.i[2];
+            tables[o.i[2]].width = o.i[1]; wlo = o.i[0]; wlen = o.i[1]; break;
+          case SSN_OP_AXPY: b.kind = o.i[3] ? ssn::M_AXPY_SET : ssn::M_AXPY_INC; b.dst = o.i[0]; b.src = o.i[1]; b.len = o.i[2];
+            b.a = (T)o.f[0]; wlo = o.i[0]; wlen = o.i[2]; break;
+          case SSN_OP_LOWPASS: b.kind = ssn::M_LOWPASS; b.dst = o.i[0]; b.src = o.i[1]; b.len = o.i[2];
+            b.a = (T)o.f[0]; b.b = (T)((1.0 - o.f[0]) * o.f[1]); wlo = o.i[0]; wlen = o.i[2]; break;
+          case SSN_OP_MATVEC: b.kind = o.i[5] ? ssn::M_MATVEC_SET : ssn::M_MATVEC_INC; b.dst = o.i[0]; b.src = o.i[1];
+            b.len = o.i[2]; b.cols = (int)o.i[3]; b.ld = (int)bufs[o.i[4]].ld; b.p0 = bufs[o.i[4]].d; wlo = o.i[0]; wlen = o.i[2]; break;
+          default: return fail(SSN_EUNSUPPORTED, "operator kind %d cannot run in a time-batched stage", o.kind);
+        }
+        for (int64_t j = wlo; j < wlo + wlen; ++j) batched_mask[(size_t)j] = 1;
+        (o.stage == 0 ? pre_sorted : post_sorted).push_back({o.border, b});
+        continue;
+      }
       switch (o.kind) {
         case SSN_OP_FILL:
           op.kind = ssn::M_FILL; op.dst = o.i[0]; op.len = o.i[1]; op.a = (T)o.f[0];
@@ -483,10 +532,30 @@ struct Sim final : ssn_sim {
         default: return fail(SSN_EINVAL, "unknown operator kind %d", o.kind);
       }
     }
+    auto by_order = [](const std::pair<int, ssn::BatchOp<T>>& a, const std::pair<int, ssn::BatchOp<T>>& b) { return a.first < b.first; };
+    std::stable_sort(pre_sorted.begin(), pre_sorted.end(), by_order);
+    std::stable_sort(post_sorted.begin(), post_sorted.end(), by_order);
+    for (auto& x : pre_sorted) pre_ops.push_back(x.second);
+    for (auto& x : post_sorted) post_ops.push_back(x.second);
+    bool first_out = true;
+    for (auto& r : core_to_post) {       // hand this timestep's results to the post stage
+      MOp op{};
+      op.kind = ssn::M_ROW_OUT; op.src = r.lo; op.len = r.hi - r.lo; op.p0 = bsig; op.i0 = n_sig;
+      push_micro(op, -11, first_out);
+      first_out = false;
+    }
+    bool first_probe = true;
     for (size_t p = 0; p < probes.size(); ++p) {
+      if (probes[p].stage != 1) {         // sampled by the batched stages, after all their operators
+        ssn::BatchOp<T> b{};
+        b.bsig = bsig; b.n_sig = n_sig; b.kind = ssn::M_PROBE; b.src = probes[p].src; b.len = probes[p].width; b.p0 = d_pslots + p;
+        post_ops.push_back(b);
+        continue;
+      }
       MOp op{};
       op.kind = ssn::M_PROBE; op.src = probes[p].src; op.len = probes[p].width; op.p0 = d_pslots + p;
-      push_micro(op, -2, p == 0);
+      push_micro(op, -2, first_probe);
+      first_probe = false;
     }
     MOp end{};
     end.kind = ssn::M_STEP_END;
@@ -523,6 +592,24 @@ struct Sim final : ssn_sim {
     HIPCHK(hipMemcpy(d_mops, mops.data(), mops.size() * sizeof(MOp), hipMemcpyHostToDevice));
     launches_per_step = (int)items.size() - (can_fuse ? 1 : 0);
     return SSN_OK;
+  }
+
+  int init_bsig() {
+    if (!bsig) return SSN_OK;
+    CHK(upload(sig_init.data(), bsig, 1, n_sig, n_sig));
+    for (int r = 1; r <= block; ++r)
+      HIPCHK(hipMemcpyAsync(bsig + (size_t)r * n_sig, bsig, (size_t)n_sig * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return SSN_OK;
+  }
+
+  hipError_t run_batch(std::vector<ssn::BatchOp<T>>& ops, int B, int64_t step0) {
+    for (auto& o : ops) {
+      o.B = B; o.step0 = step0;
+      hipError_t e = ssn::launch_batch_op<T>(stream, o);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
   }
 
   // ---- launching --------------------------------------------------------------------------
@@ -578,10 +665,10 @@ struct Sim final : ssn_sim {
     HIPCHK(hipSetDevice(device));
     if (n < 0) return fail(SSN_EINVAL, "negative step count");
     if (n == 0) return SSN_OK;
-    HIPCHK(hipEventRecord(ev_run0, stream));
+    int n_dom = 0;
+    for (auto& it : items) n_dom += it.dominant ? 1 : 0;
+    size_t ev_used = 0;
     if (profile) {
-      int n_dom = 0;
-      for (auto& it : items) n_dom += it.dominant ? 1 : 0;
       const size_t need = (size_t)(2 * n * std::max(1, n_dom));
       if (need > 400000) return fail(SSN_EINVAL, "profile run too long (%lld steps): at most 200000 timed launches", (long long)n);
       while (ev_pool.size() < need) {
@@ -589,27 +676,43 @@ struct Sim final : ssn_sim {
         HIPCHK(hipEventCreate(&ev));
         ev_pool.push_back(ev);
       }
-      size_t k = 0;
-      for (int64_t s = 0; s < n; ++s)
-        for (auto& it : items) {
-          if (it.dominant) { HIPCHK(launch_item(it, ev_pool[k], ev_pool[k + 1])); k += 2; }
-          else HIPCHK(launch_item(it, nullptr, nullptr));
-        }
-      HIPCHK(hipEventRecord(ev_run1, stream));
-      HIPCHK(hipStreamSynchronize(stream));
-      for (size_t j = 0; j < k; j += 2) {
-        float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, ev_pool[j], ev_pool[j + 1]));
-        dom_ms += ms;
-        dom_launches += 1;
+    }
+    HIPCHK(hipEventRecord(ev_run0, stream));
+    int64_t done = 0;
+    while (done < n) {
+      // one block: [pre stage, batched] -> core, one timestep at a time -> [post stage, batched]
+      const int64_t B = bsig ? std::min<int64_t>(block, n - done) : (n - done);
+      const int64_t step0 = steps_done + done;
+      if (bsig) {
+        hipLaunchKernelGGL(k_set_block, dim3(1), dim3(1), 0, stream, d_ctx, (long long)step0);
+        HIPCHK(hipGetLastError());
+        HIPCHK(run_batch(pre_ops, (int)B, step0));
       }
-    } else {
-      int64_t left = n;
-      if (graph_exec)
-        for (; left >= steps_per_graph; left -= steps_per_graph) HIPCHK(hipGraphLaunch(graph_exec, stream));
-      if (left > 0) HIPCHK(launch_steps((int)left, true));
-      HIPCHK(hipEventRecord(ev_run1, stream));
-      HIPCHK(hipStreamSynchronize(stream));
+      if (profile) {
+        for (int64_t s = 0; s < B; ++s)
+          for (auto& it : items) {
+            if (it.dominant) { HIPCHK(launch_item(it, ev_pool[ev_used], ev_pool[ev_used + 1])); ev_used += 2; }
+            else HIPCHK(launch_item(it, nullptr, nullptr));
+          }
+      } else {
+        int64_t left = B;
+        if (graph_exec)
+          for (; left >= steps_per_graph; left -= steps_per_graph) HIPCHK(hipGraphLaunch(graph_exec, stream));
+        if (left > 0) HIPCHK(launch_steps((int)left, true));
+      }
+      if (bsig) {
+        HIPCHK(run_batch(post_ops, (int)B, step0));
+        HIPCHK(hipMemcpyAsync(bsig, bsig + (size_t)B * n_sig, (size_t)n_sig * sizeof(T), hipMemcpyDeviceToDevice, stream));
+      }
+      done += B;
+    }
+    HIPCHK(hipEventRecord(ev_run1, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    for (size_t j = 0; j < ev_used; j += 2) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, ev_pool[j], ev_pool[j + 1]));
+      dom_ms += ms;
+      dom_launches += 1;
     }
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, ev_run0, ev_run1));
@@ -629,6 +732,7 @@ struct Sim final : ssn_sim {
     for (auto& b : bufs)
       if (b.keep) CHK(upload(b.host.data(), (T*)b.d, b.rows, b.cols, b.ld));
     HIPCHK(hipMemset(d_ctx, 0, sizeof(ssn::StepCtx)));
+    CHK(init_bsig());
     steps_done = 0;
     reserve_first = reserve_n = 0;
     for (auto& s : pslots) { s.base_slot = 0; s.capacity = 0; }
@@ -714,7 +818,17 @@ struct Sim final : ssn_sim {
   int rw_signal(int64_t off, int64_t count, double* dst, const double* src) override {
     HIPCHK(hipSetDevice(device));
     CHK(check_range(off, count, "signal access"));
-    return dst ? download(sig + off, dst, 1, count, count) : upload(src, sig + off, 1, count, count);
+    if (!dst) {
+      CHK(upload(src, sig + off, 1, count, count));
+      return bsig ? upload(src, bsig + off, 1, count, count) : SSN_OK;
+    }
+    CHK(download(sig + off, dst, 1, count, count));
+    if (bsig) {                       // signals of the batched stages live in the block buffer (row 0 = latest)
+      std::vector<double> tmp((size_t)count);
+      CHK(download(bsig + off, tmp.data(), 1, count, count));
+      for (int64_t i = 0; i < count; ++i) if (batched_mask[(size_t)(off + i)]) dst[i] = tmp[(size_t)i];
+    }
+    return SSN_OK;
   }
 
   int rw_buffer(int id, double* dst, const double* src, int64_t count) override {
@@ -816,6 +930,6 @@ int ssn_device_count(void) {
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 const char* ssn_last_error(void) { return g_err.c_str(); }
-const char* ssn_version(void) { return "libssn_hip 0.1 (gfx950, ABI 1)"; }
+const char* ssn_version(void) { return "libssn_hip 0.2 (gfx950, ABI 2)"; }
 
 }  // extern "C"

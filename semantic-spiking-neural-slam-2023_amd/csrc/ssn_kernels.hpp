@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "ssn_launch.hpp"
 
 namespace ssn {
@@ -272,6 +273,16 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
         }
         break;
       }
+      case M_ROW_IN: {    // p0 = bsig, i0 = n_sig: sig[dst..] = bsig[row][dst..], row = step - block_start + 1
+        const T* row = (const T*)op.p0 + (size_t)(step - ctx->block_start + 1) * op.i0;
+        for (long long i = tid; i < op.len; i += 1024) sig[op.dst + i] = row[op.dst + i];
+        break;
+      }
+      case M_ROW_OUT: {   // bsig[row][src..] = sig[src..]
+        T* row = (T*)op.p0 + (size_t)(step - ctx->block_start + 1) * op.i0;
+        for (long long i = tid; i < op.len; i += 1024) row[op.src + i] = sig[op.src + i];
+        break;
+      }
       case M_STEP_END:
         step += 1;
         if (tid == 0) ctx->step = step;
@@ -434,6 +445,120 @@ hipError_t launch_voja(hipStream_t s, T* E, const T* spk, const T* key, const T*
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Time-batched operators (feed-forward pre / post stages, stages.py): one launch runs an operator for
+// all B timesteps of a block on the block buffer bsig[B+1][n_sig] (row r = signals after step
+// block_start + r).  A per-step GEMV becomes one GEMM (the matrix is read once per block), a Lowpass
+// becomes a scan along time.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void kb_elementwise(BatchOp<T> o) {
+  const long long total = (long long)o.B * o.len;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long t = e / o.len, i = e - t * o.len;
+    T* drow = o.bsig + (size_t)(t + 1) * o.n_sig;
+    const T* srow = o.bsig + (size_t)(t + 1 - o.src_prev) * o.n_sig;
+    switch (o.kind) {
+      case M_FILL: drow[o.dst + i] = o.a; break;
+      case M_AXPY_INC: drow[o.dst + i] += o.a * srow[o.src + i]; break;
+      case M_AXPY_SET: drow[o.dst + i] = o.a * srow[o.src + i]; break;
+      case M_TABLE: {
+        const TableSlot* tb = (const TableSlot*)o.p0;
+        const long long rel = o.step0 + t - tb->first_step;
+        int row = -1;
+        if (rel >= 0 && rel < tb->n_idx) row = tb->idx[rel];
+        drow[o.dst + i] = (row >= 0 && row < tb->n_rows) ? ((const T*)tb->rows)[(size_t)row * tb->width + i] : T(0);
+        break;
+      }
+      case M_PROBE: {
+        const ProbeSlot* ps = (const ProbeSlot*)o.p0;
+        const long long s1 = o.step0 + t + 1;
+        if (s1 % ps->every == 0) {
+          const long long slot = s1 / ps->every - 1 - ps->base_slot;
+          if (slot >= 0 && slot < ps->capacity) ((T*)ps->data)[(size_t)slot * o.len + i] = drow[o.src + i];
+        }
+        break;
+      }
+      default: break;
+    }
+  }
+}
+
+// scan along time: y[t+1] = a*y[t] + b*u[t], one thread per signal element, rows read ahead in groups
+template <typename T>
+__global__ __launch_bounds__(64) void kb_lowpass(BatchOp<T> o) {
+  const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= o.len) return;
+  T y = o.bsig[o.dst + i];                                  // carry-in (row 0)
+  const T* u = o.bsig + (size_t)(1 - o.src_prev) * o.n_sig + o.src + i;
+  T* out = o.bsig + (size_t)o.n_sig + o.dst + i;
+  int t = 0;
+  for (; t + 8 <= o.B; t += 8) {
+    T v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = u[(size_t)(t + j) * o.n_sig];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { y = o.a * y + o.b * v[j]; out[(size_t)(t + j) * o.n_sig] = y; }
+  }
+  for (; t < o.B; ++t) { y = o.a * y + o.b * u[(size_t)t * o.n_sig]; out[(size_t)t * o.n_sig] = y; }
+}
+
+// C[t][r] (+)= sum_c A[t][c] * W[r][c]   (A = block rows of the source signal, W row-major [rows][ld])
+// 32 x 32 output tile per 256-thread workgroup, K staged through LDS in slabs of 32.
+template <typename T>
+__global__ __launch_bounds__(256) void kb_gemm(BatchOp<T> o) {
+  __shared__ T As[32][33];
+  __shared__ T Ws[32][33];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // 16 x 16 threads, 2 x 2 outputs each
+  const int t0 = blockIdx.y * 32, r0 = blockIdx.x * 32;
+  const T* A = o.bsig + (size_t)(1 - o.src_prev) * o.n_sig + o.src;
+  const T* Wm = (const T*)o.p0;
+  T acc[2][2] = {{T(0), T(0)}, {T(0), T(0)}};
+  const int rows = (int)o.len;
+  for (int k0 = 0; k0 < o.cols; k0 += 32) {
+    for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+      const int rr = e >> 5, cc = e & 31;
+      const int t = t0 + rr, r = r0 + rr, c = k0 + cc;
+      As[rr][cc] = (t < o.B && c < o.cols) ? A[(size_t)t * o.n_sig + c] : T(0);
+      Ws[rr][cc] = (r < rows && c < o.cols) ? Wm[(size_t)r * o.ld + c] : T(0);
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      const T a0 = As[ty][kk], a1 = As[ty + 16][kk];
+      const T w0 = Ws[tx][kk], w1 = Ws[tx + 16][kk];
+      acc[0][0] += a0 * w0; acc[0][1] += a0 * w1;
+      acc[1][0] += a1 * w0; acc[1][1] += a1 * w1;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int t = t0 + ty + 16 * a, r = r0 + tx + 16 * b;
+      if (t < o.B && r < rows) {
+        T* d = o.bsig + (size_t)(t + 1) * o.n_sig + o.dst + r;
+        if (o.kind == M_MATVEC_SET) *d = acc[a][b]; else *d += acc[a][b];
+      }
+    }
+}
+
+template <typename T>
+hipError_t launch_batch_op(hipStream_t s, const BatchOp<T>& o) {
+  if (o.B <= 0 || o.len <= 0) return hipSuccess;
+  if (o.kind == M_LOWPASS) {
+    hipLaunchKernelGGL((kb_lowpass<T>), dim3((unsigned)((o.len + 63) / 64)), dim3(64), 0, s, o);
+  } else if (o.kind == M_MATVEC_INC || o.kind == M_MATVEC_SET) {
+    hipLaunchKernelGGL((kb_gemm<T>), dim3((unsigned)((o.len + 31) / 32), (unsigned)((o.B + 31) / 32)), dim3(256), 0, s, o);
+  } else {
+    const long long total = (long long)o.B * o.len;
+    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL((kb_elementwise<T>), dim3(grid), dim3(256), 0, s, o);
+  }
+  return hipGetLastError();
+}
+
 // conversion helpers for uploads / downloads (host double <-> device T), row-padded
 template <typename T>
 __global__ void k_convert_in(const double* __restrict__ src, T* __restrict__ dst, int64_t rows, int64_t cols, int64_t ld) {
@@ -473,6 +598,7 @@ hipError_t launch_convert_out(hipStream_t s, const T* src, double* dst, int64_t 
   template hipError_t launch_neurons<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T); \
   template hipError_t launch_pes<T>(hipStream_t, T*, const T*, const T*, int, int, int, T);                 \
   template hipError_t launch_voja<T>(hipStream_t, T*, const T*, const T*, const T*, const T*, int, int, int, T); \
+  template hipError_t launch_batch_op<T>(hipStream_t, const BatchOp<T>&);                                   \
   template hipError_t launch_convert_in<T>(hipStream_t, const double*, T*, int64_t, int64_t, int64_t);      \
   template hipError_t launch_convert_out<T>(hipStream_t, const T*, double*, int64_t, int64_t, int64_t);
 

@@ -30,7 +30,7 @@ struct EnsArgs {
 
 enum MicroKind {
   M_FILL = 1, M_AXPY_INC, M_AXPY_SET, M_LOWPASS, M_TABLE, M_MATVEC_INC, M_MATVEC_SET, M_ENS_FINISH,
-  M_GATE, M_ARGMAX_GATHER, M_PROBE, M_STEP_END
+  M_GATE, M_ARGMAX_GATHER, M_PROBE, M_STEP_END, M_ROW_IN, M_ROW_OUT
 };
 
 template <typename T>
@@ -56,9 +56,26 @@ struct ProbeSlot {
 };
 
 struct StepCtx {
-  long long step;      // steps completed
+  long long step;        // steps completed
   int probe_overflow;
   int pad;
+  long long block_start; // step number at which the current time-batched block began
+};
+
+// One operator of a time-batched stage, executed for rows t = 0..B-1 of the block.  Row r of the block
+// buffer `bsig` ([B+1][n_sig]) holds the signals after step (block_start + r); row 0 is the carry-in.
+template <typename T>
+struct BatchOp {
+  T* bsig;
+  long long n_sig;       // row stride
+  int B;
+  int kind;              // MicroKind (M_FILL, M_AXPY_*, M_LOWPASS, M_TABLE, M_MATVEC_*, M_PROBE)
+  long long dst, src, len;   // len = rows for matvec
+  int cols, ld;
+  int src_prev;          // 1: read row t (value before this step's update) instead of row t+1
+  T a, b;
+  const void* p0;        // W | TableSlot* | ProbeSlot*
+  long long step0;       // = block_start
 };
 
 template <typename T> hipError_t launch_ensarray(hipStream_t, const EnsArgs<T>&);
@@ -70,6 +87,7 @@ template <typename T> hipError_t launch_neurons(hipStream_t, const NeuronParams<
 template <typename T> hipError_t launch_pes(hipStream_t, T* W, const T* err, const T* act, int rows, int cols, int ld, T kappa);
 template <typename T> hipError_t launch_voja(hipStream_t, T* E, const T* spk, const T* key, const T* learn, const T* scale,
                                             int rows, int cols, int ld, T lr_dt);
+template <typename T> hipError_t launch_batch_op(hipStream_t, const BatchOp<T>&);
 template <typename T> hipError_t launch_convert_in(hipStream_t, const double* src, T* dst, int64_t rows, int64_t cols, int64_t ld);
 template <typename T> hipError_t launch_convert_out(hipStream_t, const T* src, double* dst, int64_t rows, int64_t cols, int64_t ld);
 

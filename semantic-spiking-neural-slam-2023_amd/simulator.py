@@ -44,7 +44,7 @@ class SimulationData(dict):
         return key in self._sim._probe_index or key in self._sim.model.params
 
 
-def pack_model(model, dtype, device=0, steps_per_graph=0):
+def pack_model(model, dtype, device=0, steps_per_graph=0, block_steps=0):
     """BuiltModel -> (ssn_model_desc, keep-alive list) for ``ssn_create``."""
     keep = []
     sig_init = np.ascontiguousarray(model.sig_init, dtype=np.float64)
@@ -67,6 +67,9 @@ def pack_model(model, dtype, device=0, steps_per_graph=0):
         d = ops[j]
         d.kind = _lib.OP_CODE[k]
         d.level = int(o.get("level", 0))
+        d.stage = int(o.get("stage", 1))
+        d.border = int(o.get("border", -1))
+        d.src_prev = int(o.get("src_prev", 0))
         ii, ff = [0] * 12, [0.0] * 4
         if k == "fill":
             ii[:2] = [o["dst"], o["len"]]
@@ -109,8 +112,19 @@ def pack_model(model, dtype, device=0, steps_per_graph=0):
             d.f[a] = float(ff[a])
     sig_probes = [p for p in model.probes if "src" in p]
     probes = (_lib.ProbeDesc * max(1, len(sig_probes)))()
+    info = getattr(model, "stage_info", None) or {}
+    pstage = info.get("probe_stage")
+    all_idx = [i for i, p in enumerate(model.probes) if "src" in p]
     for j, p in enumerate(sig_probes):
         probes[j].src, probes[j].width, probes[j].every = int(p["src"]), int(p["width"]), int(p["every"])
+        probes[j].stage = int(pstage[all_idx[j]]) if pstage is not None else 1
+    p2c, c2p = info.get("pre_to_core", []), info.get("core_to_post", [])
+    r_p2c = (_lib.Range * max(1, len(p2c)))()
+    r_c2p = (_lib.Range * max(1, len(c2p)))()
+    for j, (lo, hi) in enumerate(p2c):
+        r_p2c[j].lo, r_p2c[j].hi = int(lo), int(hi)
+    for j, (lo, hi) in enumerate(c2p):
+        r_c2p[j].lo, r_c2p[j].hi = int(lo), int(hi)
     desc = _lib.ModelDesc()
     desc.abi_version = _lib.SSN_ABI_VERSION
     desc.dtype = _lib.SSN_F64 if dtype in ("f64", "float64", np.float64) else _lib.SSN_F32
@@ -122,7 +136,10 @@ def pack_model(model, dtype, device=0, steps_per_graph=0):
     desc.n_buffers, desc.n_ops, desc.n_probes = len(model.buffers), len(model.ops), len(sig_probes)
     desc.steps_per_graph = int(steps_per_graph)
     desc.buffers, desc.ops, desc.probes = bufs, ops, probes
-    keep += [bufs, ops, probes]
+    desc.n_pre_to_core, desc.n_core_to_post = len(p2c), len(c2p)
+    desc.pre_to_core, desc.core_to_post = r_p2c, r_c2p
+    desc.block_steps = int(block_steps)
+    keep += [bufs, ops, probes, r_p2c, r_c2p]
     return desc, keep, sig_probes
 
 
@@ -147,7 +164,7 @@ def tabulate(fn, width, steps, dt):
 
 class Simulator:
     def __init__(self, network, dt=0.001, seed=None, progress_bar=None, dtype="f32", device=0,
-                 n_eval_points=None, steps_per_graph=0, model=None, vco_shard=None):
+                 n_eval_points=None, steps_per_graph=0, model=None, vco_shard=None, block_steps=0):
         self.dt = float(dt)
         self.closed = True
         self._lib = _lib.load()          # fails loudly when the HIP library is not built
@@ -158,7 +175,7 @@ class Simulator:
                 model = build(network, dt=dt, seed=seed, n_eval_points=n_eval_points, vco_shard=vco_shard)
         self.model = model
         self.dtype = "f64" if dtype in ("f64", "float64", np.float64) else "f32"
-        desc, keep, self._sig_probes = pack_model(model, self.dtype, device, steps_per_graph)
+        desc, keep, self._sig_probes = pack_model(model, self.dtype, device, steps_per_graph, block_steps)
         self._h = C.c_void_p()
         t0 = time.time()
         self._check(self._lib.ssn_create(C.byref(desc), C.byref(self._h)), build=True)

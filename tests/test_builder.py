@@ -20,7 +20,7 @@ def test_pi_lowers_to_a_handful_of_merged_ops(pi_model):
     pm, m = pi_model
     kinds = [o["kind"] for o in m.ops]
     assert kinds.count("ensarray") == 1 and kinds.count("matvec") == 3       # to_Fourier, velocity (stacked), to_SSP
-    assert len(m.ops) <= 20 and m.stats["n_raw_ops"] > 100                    # 27 VCOs' worth of ops merged
+    assert len(m.ops) <= 24 and m.stats["n_raw_ops"] > 100                    # 27 VCOs' worth of ops merged
     ens = next(o for o in m.ops if o["kind"] == "ensarray")
     assert (ens["K"], ens["n"], ens["din"], ens["dout"]) == (28, 40, 3, 5)
     vel = [o for o in m.ops if o["kind"] == "matvec" and o["cols"] == 2]
@@ -49,6 +49,35 @@ def test_schedule_respects_set_inc_read_update(pi_model):
                 wj = acc[j][0] + acc[j][1] + acc[j][3]
                 assert not any(_overlap(a, b) for a in wi for b in wj + acc[j][2])
                 assert not any(_overlap(a, b) for a in wj for b in acc[i][2])
+
+
+def test_stage_partition_of_pathintegration(pi_model):
+    """Only the VCO array and its feedback filter are stepped per timestep; the to_Fourier input chain
+    (pre) and the to_SSP read-out chain (post) are feed-forward in time and run time-batched."""
+    _, m = pi_model
+    info = m.stage_info
+    assert info["enabled"] and info["n_core"] == 3
+    core = [o["kind"] for o in m.ops if o["stage"] == 1]
+    assert sorted(core) == ["axpy", "ensarray", "lowpass"]
+    pre = [o for o in m.ops if o["stage"] == 0]
+    post = [o for o in m.ops if o["stage"] == 2]
+    assert sum(o["kind"] == "matvec" for o in pre) == 2 and sum(o["kind"] == "matvec" for o in post) == 1
+    assert [o["stage"] for o in m.ops] == sorted(o["stage"] for o in m.ops)          # stage-major order
+    ens = next(o for o in m.ops if o["kind"] == "ensarray")
+    assert info["pre_to_core"] == [(ens["x"], ens["x"] + 84)]                           # the VCO inputs
+    assert len(info["core_to_post"]) == 1 and info["core_to_post"][0][1] - info["core_to_post"][0][0] == 84
+    assert info["probe_stage"] == [2]
+    # batched order is a permutation; pre-update state reads are flagged
+    for st in (pre, post):
+        assert sorted(o["border"] for o in st) == list(range(len(st)))
+    flagged = [o for o in m.ops if o["src_prev"]]
+    assert len(flagged) == 2 and all(o["kind"] == "axpy" for o in flagged)
+    # staged and unstaged orders give the same oracle trajectory
+    pm2 = small_pathint(ssp_dim=55, n=40, T=10.0, limit=0.2)
+    a, b = OracleSimulator(m), OracleSimulator(build(pm2.model, staged=False))
+    a.run_steps(120)
+    b.run_steps(120)
+    np.testing.assert_allclose(a.probe_data(0), b.probe_data(0), atol=1e-13)
 
 
 def test_cycle_without_synapse_is_rejected():
