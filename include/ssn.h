@@ -101,7 +101,8 @@ typedef struct ssn_model_desc {
   int32_t n_buffers;
   int32_t n_ops;
   int32_t n_probes;
-  int32_t steps_per_graph;            /* timesteps captured per hipGraph; 0 = library default */
+  int32_t steps_per_graph;            /* timesteps captured per hipGraph; 0 = library default (16);
+                                         negative = default without the fused recurrent-array core (debug) */
   const ssn_buffer_desc* buffers;
   const ssn_op_desc* ops;
   const ssn_probe_desc* probes;

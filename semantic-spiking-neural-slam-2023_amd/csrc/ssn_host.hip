@@ -24,6 +24,7 @@
 namespace {
 
 __global__ void k_set_block(ssn::StepCtx* ctx, long long block_start) { ctx->block_start = block_start; }
+__global__ void k_advance(ssn::StepCtx* ctx, long long n) { ctx->step += n; }
 
 thread_local std::string g_err;
 
@@ -61,7 +62,7 @@ struct Buf {
   std::vector<double> host;               // initial contents if keep
 };
 
-enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED };
+enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH };
 
 }  // namespace
 
@@ -91,6 +92,7 @@ struct Sim final : ssn_sim {
     int type = IT_PROGRAM;
     int op_begin = 0, op_count = 0;          // program: range in d_mops
     ssn::EnsArgs<T> ens;
+    ssn::FinishArgs<T> fin;
     bool dominant = false;
     // matvec / pes / voja / neurons
     T* Wm = nullptr; const T* src = nullptr; T* dst = nullptr; const T* aux0 = nullptr; const T* aux1 = nullptr;
@@ -112,6 +114,9 @@ struct Sim final : ssn_sim {
   // time-batched pre / post stages
   T* bsig = nullptr;                          // [block+1][n_sig]
   int block = 0;                              // timesteps per block (0: staging off)
+  bool core_empty = false;                    // no per-timestep work at all
+  bool fused_core = false;                    // core == one recurrent ensemble array: [k_ensarray, k_ens_finish]
+  std::vector<void*> fused_bufs;
   std::vector<ssn::BatchOp<T>> pre_ops, post_ops;
   std::vector<ssn_range> pre_to_core, core_to_post;
   std::vector<unsigned char> batched_mask;    // signals owned by a batched stage (for ssn_read_signal)
@@ -155,6 +160,7 @@ struct Sim final : ssn_sim {
     for (auto& s : pslots) if (s.data) hipFree(s.data);
     for (auto& it : items) if (it.type == IT_ENS && it.ens.partials) hipFree(it.ens.partials);
     for (auto p : scratch_bufs) if (p) hipFree(p);
+    for (auto p : fused_bufs) if (p) hipFree(p);
     for (auto e : ev_pool) hipEventDestroy(e);
     if (ev_run0) hipEventDestroy(ev_run0);
     if (ev_run1) hipEventDestroy(ev_run1);
@@ -369,7 +375,129 @@ struct Sim final : ssn_sim {
     return np;
   }
 
+  void ens_chunking(ssn::EnsArgs<T>& a) {
+    // whole 256-thread sweeps per workgroup; keep >= ~4096 workgroups chip-wide while sweeps can grow
+    const int n_vec = a.n_pad / VW;
+    int sweeps = 1;
+    const int max_sweeps = (n_vec + 255) / 256;
+    while (sweeps < max_sweeps && (int64_t)a.K * ((n_vec + 256 * (sweeps + 1) - 1) / (256 * (sweeps + 1))) >= 4096) ++sweeps;
+    a.chunk_vec = 256 * sweeps;
+    a.P = (n_vec + a.chunk_vec - 1) / a.chunk_vec;
+  }
+
+  void fill_ens_args(const ssn_op_desc& o, ssn::EnsArgs<T>& a) {
+    a = ssn::EnsArgs<T>{};
+    a.K = (int)o.i[1]; a.n = (int)o.i[2]; a.din = (int)o.i[3]; a.dout = (int)o.i[4];
+    a.n_pad = (int)bufs[o.i[5]].ld;
+    a.enc = (const T*)bufs[o.i[5]].d; a.bias = (const T*)bufs[o.i[6]].d; a.dec = (const T*)bufs[o.i[7]].d;
+    a.V = (T*)bufs[o.i[9]].d; a.R = (T*)bufs[o.i[10]].d;
+    a.sig = sig; a.x_off = o.i[0];
+    a.np = neuron_params(o.i[11], o.f);
+    a.xrows = nullptr; a.n_sig = n_sig; a.ctx = d_ctx; a.n_rec = 0;
+    ens_chunking(a);
+  }
+
+  // Core stage == one recurrent ensemble array (the path integrator's VCO array): x assembled in the
+  // kernel prologue, decoded rows / synapse update / hand-off / step counter in one barrier-free finish
+  // kernel.  Returns false (and plans nothing) when the core does not have that shape.
+  bool try_fused_core(const ssn_model_desc* m, int* rc) {
+    *rc = SSN_OK;
+    if (!bsig) return false;
+    for (auto& p : probes) if (p.stage == 1) return false;
+    int ens_i = -1;
+    std::vector<int> axpys, lows;
+    for (int i = 0; i < m->n_ops; ++i) {
+      const ssn_op_desc& o = m->ops[i];
+      if (o.stage != 1) continue;
+      if (o.kind == SSN_OP_ENSARRAY) { if (ens_i >= 0) return false; ens_i = i; }
+      else if (o.kind == SSN_OP_AXPY && o.i[3] == 0) axpys.push_back(i);
+      else if (o.kind == SSN_OP_LOWPASS) lows.push_back(i);
+      else return false;
+    }
+    if (ens_i < 0 || axpys.size() > 4) return false;
+    const ssn_op_desc& eo = m->ops[ens_i];
+    const int64_t K = eo.i[1], din = eo.i[3], dout = eo.i[4];
+    const int64_t x0 = eo.i[0], x1 = eo.i[0] + K * din;
+    auto inside = [](int64_t lo, int64_t hi, const std::vector<ssn_range>& rs) {
+      for (auto& r : rs) if (lo >= r.lo && hi <= r.hi) return true;
+      return false;
+    };
+    if (!inside(x0, x1, pre_to_core)) return false;
+    for (int i : axpys) {                       // recurrent terms must land inside pre-stage-provided inputs
+      const ssn_op_desc& o = m->ops[i];
+      if (!inside(o.i[0], o.i[0] + o.i[2], pre_to_core)) return false;
+    }
+    const int32_t* didx = (const int32_t*)m->buffers[eo.i[8]].data;
+    std::vector<int> row_of((size_t)n_sig, -1);
+    for (int64_t j = 0; j < K * dout; ++j) row_of[(size_t)didx[j]] = (int)j;   // padded rows share a trash slot: harmless
+    std::vector<int> lp_state((size_t)(K * dout), -1);
+    std::vector<double> lp_a((size_t)(K * dout), 0.0), lp_b((size_t)(K * dout), 0.0);
+    std::vector<unsigned char> rowout((size_t)(K * dout), 0);
+    for (int i : lows) {
+      const ssn_op_desc& o = m->ops[i];
+      for (int64_t e = 0; e < o.i[2]; ++e) {
+        const int row = row_of[(size_t)(o.i[1] + e)];
+        if (row < 0) {
+          // no local row feeds this filter input (VCO owned by another rank): input and state stay 0,
+          // provided nothing else writes that signal
+          if (inside(o.i[1] + e, o.i[1] + e + 1, pre_to_core) || sig_init[(size_t)(o.i[1] + e)] != 0.0) return false;
+          continue;
+        }
+        if (lp_state[(size_t)row] >= 0) return false;
+        lp_state[(size_t)row] = (int)(o.i[0] + e);
+        lp_a[(size_t)row] = o.f[0];
+        lp_b[(size_t)row] = (1.0 - o.f[0]) * o.f[1];
+      }
+    }
+    for (auto& r : core_to_post)
+      for (int64_t e = r.lo; e < r.hi; ++e) {
+        const int row = row_of[(size_t)e];
+        if (row >= 0) rowout[(size_t)row] = 1;      // (elements no local row writes stay at their initial value)
+      }
+    // ---- plan: [k_ensarray (fused prologue), k_ens_finish] -------------------------------------------
+    Item it; it.type = IT_ENS;
+    fill_ens_args(eo, it.ens);
+    ssn::EnsArgs<T>& a = it.ens;
+    a.xrows = bsig;
+    for (int i : axpys) {
+      const ssn_op_desc& o = m->ops[i];
+      a.rec_dst[a.n_rec] = o.i[0]; a.rec_src[a.n_rec] = o.i[1]; a.rec_len[a.n_rec] = o.i[2]; a.rec_alpha[a.n_rec] = (T)o.f[0];
+      ++a.n_rec;
+    }
+    if ((*rc = dmalloc(&a.partials, (int64_t)a.K * a.P * a.dout * (int64_t)sizeof(T))) != SSN_OK) return true;
+    it.dominant = true;
+    dom_units = (int64_t)a.K * a.n;
+    dom_bytes = (double)dom_units * (a.din + a.dout + 5) * sizeof(T);
+    Item fi; fi.type = IT_FINISH;
+    ssn::FinishArgs<T>& f = fi.fin;
+    f = ssn::FinishArgs<T>{};
+    const int64_t nr = K * dout;
+    int* d_lp = nullptr; T* d_a = nullptr; T* d_b = nullptr; unsigned char* d_ro = nullptr; unsigned int* d_ticket = nullptr;
+    if ((*rc = dmalloc(&d_lp, nr * 4)) != SSN_OK) return true;
+    if ((*rc = dmalloc(&d_a, nr * (int64_t)sizeof(T))) != SSN_OK) return true;
+    if ((*rc = dmalloc(&d_b, nr * (int64_t)sizeof(T))) != SSN_OK) return true;
+    if ((*rc = dmalloc(&d_ro, nr)) != SSN_OK) return true;
+    if ((*rc = dmalloc(&d_ticket, 64)) != SSN_OK) return true;
+    fused_bufs.insert(fused_bufs.end(), {(void*)d_lp, (void*)d_a, (void*)d_b, (void*)d_ro, (void*)d_ticket});
+    hipMemcpy(d_lp, lp_state.data(), (size_t)nr * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_ro, rowout.data(), (size_t)nr, hipMemcpyHostToDevice);
+    hipMemset(d_ticket, 0, 64);
+    if ((*rc = upload(lp_a.data(), d_a, 1, nr, nr)) != SSN_OK) return true;
+    if ((*rc = upload(lp_b.data(), d_b, 1, nr, nr)) != SSN_OK) return true;
+    f.partials = a.partials; f.didx = (const int*)bufs[eo.i[8]].d; f.lp_state = d_lp; f.lp_a = d_a; f.lp_b = d_b;
+    f.rowout = d_ro; f.sig = sig; f.bsig = bsig; f.n_sig = n_sig; f.ctx = d_ctx; f.ticket = d_ticket;
+    f.K = a.K; f.P = a.P; f.dout = a.dout; f.n_blocks = (int)((nr + 255) / 256);
+    items.push_back(it);
+    items.push_back(fi);
+    fused_core = true;
+    // the batched stages are planned by plan(); nothing else runs per timestep
+    return true;
+  }
+
   int plan(const ssn_model_desc* m) {
+    int frc = SSN_OK;
+    const bool fused = m->steps_per_graph >= 0 && try_fused_core(m, &frc);
+    CHK(frc);
     std::vector<std::vector<MOp>> programs;   // programs in step order
     std::vector<int> item_prog;               // for IT_PROGRAM items: index into programs
     std::vector<MOp> cur;
@@ -394,6 +522,7 @@ struct Sim final : ssn_sim {
     int64_t best_units = -1;
     int best_item = -1;
     for (auto& r : pre_to_core) {        // the pre stage's results for this timestep
+      if (fused) break;
       MOp op{};
       op.kind = ssn::M_ROW_IN; op.dst = r.lo; op.len = r.hi - r.lo; op.p0 = bsig; op.i0 = n_sig;
       push_micro(op, -10, false);
@@ -422,6 +551,7 @@ struct Sim final : ssn_sim {
         (o.stage == 0 ? pre_sorted : post_sorted).push_back({o.border, b});
         continue;
       }
+      if (fused) continue;               // the core is [k_ensarray, k_ens_finish], planned above
       switch (o.kind) {
         case SSN_OP_FILL:
           op.kind = ssn::M_FILL; op.dst = o.i[0]; op.len = o.i[1]; op.a = (T)o.f[0];
@@ -458,19 +588,7 @@ struct Sim final : ssn_sim {
           flush();
           Item it; it.type = IT_ENS;
           ssn::EnsArgs<T>& a = it.ens;
-          a.K = (int)o.i[1]; a.n = (int)o.i[2]; a.din = (int)o.i[3]; a.dout = (int)o.i[4];
-          a.n_pad = (int)bufs[o.i[5]].ld;
-          a.enc = (const T*)bufs[o.i[5]].d; a.bias = (const T*)bufs[o.i[6]].d; a.dec = (const T*)bufs[o.i[7]].d;
-          a.V = (T*)bufs[o.i[9]].d; a.R = (T*)bufs[o.i[10]].d;
-          a.sig = sig; a.x_off = o.i[0];
-          a.np = neuron_params(o.i[11], o.f);
-          // chunking: whole 256-thread sweeps per workgroup; aim for >= ~8 workgroups per CU chip-wide
-          const int n_vec = a.n_pad / VW;
-          int sweeps = 1;
-          const int max_sweeps = (n_vec + 255) / 256;
-          while (sweeps < max_sweeps && (int64_t)a.K * ((n_vec + 256 * (sweeps + 1) - 1) / (256 * (sweeps + 1))) >= 4096) ++sweeps;
-          a.chunk_vec = 256 * sweeps;
-          a.P = (n_vec + a.chunk_vec - 1) / a.chunk_vec;
+          fill_ens_args(o, a);
           CHK(dmalloc(&a.partials, (int64_t)a.K * a.P * a.dout * (int64_t)sizeof(T)));
           const int64_t units = (int64_t)a.K * a.n;
           if (units > best_units) { best_units = units; best_item = (int)items.size(); }
@@ -539,6 +657,7 @@ struct Sim final : ssn_sim {
     for (auto& x : post_sorted) post_ops.push_back(x.second);
     bool first_out = true;
     for (auto& r : core_to_post) {       // hand this timestep's results to the post stage
+      if (fused) break;
       MOp op{};
       op.kind = ssn::M_ROW_OUT; op.src = r.lo; op.len = r.hi - r.lo; op.p0 = bsig; op.i0 = n_sig;
       push_micro(op, -11, first_out);
@@ -557,9 +676,11 @@ struct Sim final : ssn_sim {
       push_micro(op, -2, first_probe);
       first_probe = false;
     }
-    MOp end{};
-    end.kind = ssn::M_STEP_END;
-    push_micro(end, -3, false);
+    if (!fused) {
+      MOp end{};
+      end.kind = ssn::M_STEP_END;
+      push_micro(end, -3, false);
+    }
     force_barrier = true;
     flush();
     if (best_item >= 0) {
@@ -579,7 +700,7 @@ struct Sim final : ssn_sim {
     int pi = 0;
     for (auto& it : items)
       if (it.type == IT_PROGRAM) { it.op_begin = begin[pi]; it.op_count = (int)programs[pi].size(); ++pi; }
-    can_fuse = items.size() >= 2 && items.front().type == IT_PROGRAM && items.back().type == IT_PROGRAM;
+    can_fuse = !fused && items.size() >= 2 && items.front().type == IT_PROGRAM && items.back().type == IT_PROGRAM;
     if (can_fuse) {
       head_begin = items.front().op_begin; head_count = items.front().op_count;
       tail_begin = items.back().op_begin; tail_count = items.back().op_count;
@@ -591,6 +712,12 @@ struct Sim final : ssn_sim {
     CHK(dmalloc(&d_mops, (int64_t)mops.size() * (int64_t)sizeof(MOp)));
     HIPCHK(hipMemcpy(d_mops, mops.data(), mops.size() * sizeof(MOp), hipMemcpyHostToDevice));
     launches_per_step = (int)items.size() - (can_fuse ? 1 : 0);
+    int n_core_ops = 0;
+    for (int i = 0; i < m->n_ops; ++i) n_core_ops += m->ops[i].stage == 1;
+    bool core_probe = false;
+    for (auto& p : probes) core_probe = core_probe || p.stage == 1;
+    core_empty = bsig && n_core_ops == 0 && !core_probe;
+    if (core_empty) launches_per_step = 0;
     return SSN_OK;
   }
 
@@ -625,6 +752,7 @@ struct Sim final : ssn_sim {
       }
       case IT_MATVEC: return ssn::launch_matvec<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set);
       case IT_MATVEC_ORDERED: return ssn::launch_matvec_ordered<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld);
+      case IT_FINISH: return ssn::launch_ens_finish<T>(stream, it.fin);
       case IT_NEURONS: return ssn::launch_neurons<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar);
       case IT_PES: return ssn::launch_pes<T>(stream, it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar);
       case IT_VOJA: return ssn::launch_voja<T>(stream, it.Wm, it.src, it.aux0, it.aux1, it.aux2, it.rows, it.cols, it.ld, it.scalar);
@@ -688,7 +816,11 @@ struct Sim final : ssn_sim {
         HIPCHK(hipGetLastError());
         HIPCHK(run_batch(pre_ops, (int)B, step0));
       }
-      if (profile) {
+      if (core_empty) {
+        // nothing is stepped one timestep at a time (purely feed-forward model): just advance the clock
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, (long long)B);
+        HIPCHK(hipGetLastError());
+      } else if (profile) {
         for (int64_t s = 0; s < B; ++s)
           for (auto& it : items) {
             if (it.dominant) { HIPCHK(launch_item(it, ev_pool[ev_used], ev_pool[ev_used + 1])); ev_used += 2; }

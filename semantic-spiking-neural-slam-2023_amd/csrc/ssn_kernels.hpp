@@ -86,8 +86,18 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
   T* __restrict__ Rp = a.R + (size_t)k * row;
 
   T x[DIN];
+  {
+    const T* xsrc = a.sig;
+    if (a.xrows) xsrc = a.xrows + (size_t)(a.ctx->step - a.ctx->block_start + 1) * a.n_sig;
 #pragma unroll
-  for (int d = 0; d < DIN; ++d) x[d] = a.sig[a.x_off + (int64_t)k * DIN + d];
+    for (int d = 0; d < DIN; ++d) {
+      const long long xi = a.x_off + (long long)k * DIN + d;
+      T v = xsrc[xi];
+      for (int j = 0; j < a.n_rec; ++j)
+        if (xi >= a.rec_dst[j] && xi < a.rec_dst[j] + a.rec_len[j]) v += a.rec_alpha[j] * a.sig[a.rec_src[j] + (xi - a.rec_dst[j])];
+      x[d] = v;
+    }
+  }
 
   T acc[DOUT];
 #pragma unroll
@@ -133,6 +143,33 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
     const int r = threadIdx.x;
     a.partials[((size_t)k * a.P + p) * DOUT + r] = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_ens_finish(FinishArgs<T> f) {
+  const long long step = f.ctx->step;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < f.K * f.dout) {
+    const int k = i / f.dout, r = i - k * f.dout;
+    T s = T(0);
+    for (int p = 0; p < f.P; ++p) s += f.partials[((size_t)k * f.P + p) * f.dout + r];
+    const int dst = f.didx[i];
+    f.sig[dst] = s;
+    const int st = f.lp_state[i];
+    if (st >= 0) f.sig[st] = f.lp_a[i] * f.sig[st] + f.lp_b[i] * s;
+    if (f.rowout[i]) f.bsig[(size_t)(step - f.ctx->block_start + 1) * f.n_sig + dst] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int old = atomicAdd(f.ticket, 1u);
+    if (old % (unsigned)f.n_blocks == (unsigned)f.n_blocks - 1u) f.ctx->step = step + 1;   // every block has read `step`
+  }
+}
+
+template <typename T>
+hipError_t launch_ens_finish(hipStream_t s, const FinishArgs<T>& f) {
+  hipLaunchKernelGGL((k_ens_finish<T>), dim3(f.n_blocks), dim3(256), 0, s, f);
+  return hipGetLastError();
 }
 
 template <typename T, int DIN>
@@ -592,6 +629,7 @@ hipError_t launch_convert_out(hipStream_t s, const T* src, double* dst, int64_t 
 #define SSN_INSTANTIATE(T)                                                                                   \
   template hipError_t launch_ensarray<T>(hipStream_t, const EnsArgs<T>&);                                    \
   template hipError_t launch_program<T>(hipStream_t, const MicroOp<T>*, int, T*, StepCtx*);                  \
+  template hipError_t launch_ens_finish<T>(hipStream_t, const FinishArgs<T>&);                               \
   template hipError_t launch_matvec<T>(hipStream_t, const T*, const T*, T*, int, int, int, int);            \
   template hipError_t launch_matvec_ordered<T>(hipStream_t, const T*, const T*, T*, int, int, int);         \
   template hipError_t launch_transpose<T>(hipStream_t, const T*, T*, int, int, int, int);                   \

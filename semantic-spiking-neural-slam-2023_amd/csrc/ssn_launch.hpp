@@ -12,6 +12,8 @@ struct NeuronParams {
   T dt, tau_rc, tau_ref, min_voltage;
 };
 
+struct StepCtx;
+
 template <typename T>
 struct EnsArgs {
   const T* enc;        // [K][din][n_pad]
@@ -26,6 +28,33 @@ struct EnsArgs {
   int P;               // chunks (workgroups) per ensemble
   int chunk_vec;       // 16-byte vectors per chunk
   NeuronParams<T> np;
+  // fused input assembly (recurrent ensemble array): x = block-buffer row of this step (pre stage
+  // output) + sum_j alpha_j * sig[rec_src_j + (xi - rec_dst_j)] for absolute x index xi inside term j
+  const T* xrows;      // block buffer base or nullptr (then x comes from sig)
+  long long n_sig;
+  const StepCtx* ctx;
+  int n_rec;
+  long long rec_dst[4], rec_src[4], rec_len[4];
+  T rec_alpha[4];
+};
+
+// Finish of a fused recurrent ensemble array: one thread per decoded row (k, r):
+//   v = sum_p partials[k][p][r];  sig[dst] = v;  optional lowpass state update;  optional hand-off to
+//   the post stage (block-buffer row of this step).  The last workgroup to finish advances the step.
+template <typename T>
+struct FinishArgs {
+  const T* partials;
+  const int* didx;         // [K*dout] destination signal per row
+  const int* lp_state;     // [K*dout] state signal updated from this row, or -1
+  const T* lp_a;           // [K*dout]
+  const T* lp_b;           // [K*dout]
+  const unsigned char* rowout;   // [K*dout] 1: also written to the block buffer
+  T* sig;
+  T* bsig;
+  long long n_sig;
+  StepCtx* ctx;
+  unsigned int* ticket;
+  int K, P, dout, n_blocks;
 };
 
 enum MicroKind {
@@ -79,6 +108,7 @@ struct BatchOp {
 };
 
 template <typename T> hipError_t launch_ensarray(hipStream_t, const EnsArgs<T>&);
+template <typename T> hipError_t launch_ens_finish(hipStream_t, const FinishArgs<T>&);
 template <typename T> hipError_t launch_program(hipStream_t, const MicroOp<T>*, int, T*, StepCtx*);
 template <typename T> hipError_t launch_matvec(hipStream_t, const T* W, const T* src, T* dst, int rows, int cols, int ld, int set);
 template <typename T> hipError_t launch_matvec_ordered(hipStream_t, const T* Wt, const T* x, T* y, int rows, int cols, int ldt);

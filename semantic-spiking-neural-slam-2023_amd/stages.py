@@ -54,6 +54,57 @@ def _intersect(a, b):
     return out
 
 
+def _split_elementwise(ops, stage):
+    """Split fill / axpy / lowpass operators of the batched stages at every range endpoint of the other
+    operators of those stages (iterated to closure).  The merge pass may have glued together element
+    ranges that sit at different depths of the time-series data flow (e.g. ``a.in += s1`` and
+    ``b.in += s2`` where s2 filters a); operator-level dependencies would then show a false cycle."""
+    def ranges(o):
+        k = o["kind"]
+        if k == "fill":
+            return [(o["dst"], o["dst"] + o["len"])]
+        if k in ("axpy", "lowpass"):
+            return [(o["dst"], o["dst"] + o["len"]), (o["src"], o["src"] + o["len"])]
+        if k == "matvec":
+            return [(o["dst"], o["dst"] + o["rows"]), (o["src"], o["src"] + o["cols"])]
+        if k == "table":
+            return [(o["dst"], o["dst"] + o["width"])]
+        return []
+    for _ in range(64):
+        pts = set()
+        for o, st in zip(ops, stage):
+            if st != CORE:
+                for lo, hi in ranges(o):
+                    pts.add(lo)
+                    pts.add(hi)
+        new_ops, new_stage, changed = [], [], False
+        for o, st in zip(ops, stage):
+            if st == CORE or o["kind"] not in ("fill", "axpy", "lowpass"):
+                new_ops.append(o)
+                new_stage.append(st)
+                continue
+            L = o["len"]
+            bases = [o["dst"]] + ([o["src"]] if "src" in o else [])
+            cuts = sorted({p - b for b in bases for p in pts if b < p < b + L})
+            if not cuts:
+                new_ops.append(o)
+                new_stage.append(st)
+                continue
+            changed = True
+            edges = [0] + cuts + [L]
+            for lo, hi in zip(edges, edges[1:]):
+                piece = dict(o)
+                piece["dst"], piece["len"] = o["dst"] + lo, hi - lo
+                if "src" in o:
+                    piece["src"] = o["src"] + lo
+                new_ops.append(piece)
+                new_stage.append(st)
+        ops, stage = new_ops, new_stage
+        if not changed:
+            break
+    return ops, stage
+
+
 def stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=True):
     n = len(ops)
     acc = [op_access(o, model) for o in ops]
@@ -81,6 +132,8 @@ def stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=Tru
 
     seeds = [i for i, o in enumerate(ops) if o["kind"] in CORE_KINDS]
     stage = [CORE] * n
+    if enable and not seeds:
+        stage = [POST] * n          # no neurons at all (e.g. a linear read-out): everything is feed-forward
     if enable and seeds:
         # along every edge i -> j: j an ancestor of a seed => i is too; i a descendant => j is too.
         # Hence stage[i] <= stage[j] on all data-flow edges without further fixing.
@@ -107,6 +160,12 @@ def stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=Tru
                             return stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=False)
                         stage[j] = stage[i]
                         changed = True
+
+    if enable and any(st != CORE for st in stage):
+        ops, stage = _split_elementwise(list(ops), list(stage))
+        n = len(ops)
+        acc = [op_access(o, model) for o in ops]
+        sig_writes = [[r for cls in (0, 1, 3) for r in a[cls]] for a in acc]
 
     # ---- per-stage reset of the accumulators (R arena) ---------------------------------------------
     fills = []
@@ -218,7 +277,7 @@ def stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=Tru
     probe_need = _merge_ranges([(p["src"], p["src"] + p["width"]) for p, s in zip(model.probes, probe_stage)
                                 if "src" in p and s == POST])
     model.stage_info = {
-        "enabled": bool(enable and seeds and any(o["stage"] != CORE for o in out)),
+        "enabled": bool(enable and any(o["stage"] != CORE for o in out)),
         "pre_to_core": _intersect(pre_w, core_need),
         "core_to_post": _intersect(core_w, _merge_ranges(post_need + probe_need)),
         "probe_stage": probe_stage,

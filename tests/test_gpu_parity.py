@@ -215,3 +215,62 @@ def test_slam_f32_within_cosine_bar(Simulator):
         sim.run_steps(300)
         ce = H.cosine_error(sim.data[sm.probe][20:], ref.probe_data(0)[20:])
     assert ce.max() < 1e-3, ce.max()
+
+
+def test_feedforward_model_runs_fully_batched(Simulator):
+    """No neurons at all (the multi-GPU read-out is such a model): every operator runs time-batched -
+    GEMM over the block, lowpass scans with carry across block boundaries (block = 64 here)."""
+    rng = np.random.RandomState(0)
+    Tm = rng.randn(7, 5)
+    with nengo.Network(seed=0) as m:
+        u = nengo.Node(lambda t: np.sin(np.arange(1, 6) * 9 * t))
+        a = nengo.Node(size_in=7)
+        b = nengo.Node(size_in=7)
+        nengo.Connection(u, a, transform=Tm, synapse=0.01)
+        nengo.Connection(a, b, synapse=0.005)
+        nengo.Connection(u[:2], b[3:5], transform=-2.0, synapse=None)
+        p1, p2, p3 = nengo.Probe(b, synapse=0.02), nengo.Probe(a), nengo.Probe(u, sample_every=0.003)
+    model = build(m)
+    assert all(o["stage"] == 2 for o in model.ops) and model.stage_info["enabled"]
+    ref = OracleSimulator(model)
+    ref.run_steps(300)
+    with Simulator(None, model=model, dtype="f64", block_steps=64) as sim:
+        sim.run_steps(100)
+        sim.run_steps(200)
+        assert sim.counters()["launches_per_step"] == 0
+        for i, p in enumerate((p1, p2, p3)):
+            np.testing.assert_allclose(sim.data[p], ref.probe_data(i), atol=1e-12, rtol=0)
+        assert sim.data[p3].shape == (100, 5)
+
+
+def test_sharded_runner_on_hip_matches_unsharded(Simulator):
+    from sspslam_amd.sharding import ShardedPathIntegration
+    pm = small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2)
+    model = build(pm.model)
+    ref = OracleSimulator(model)
+    ref.run_steps(300)
+    pm2 = small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2)
+    r = ShardedPathIntegration(pm2, 0, 1, dtype="f64", block=128)
+    r.prepare(300)
+    r.run_steps(300)
+    np.testing.assert_allclose(r.probe_data(), ref.probe_data(0), atol=1e-9, rtol=0)
+    assert r.readout.counters()["launches_per_step"] == 0        # read-out replays fully batched
+    r.close()
+
+
+def test_fused_recurrent_core_equals_generic_path(Simulator):
+    """The fused [k_ensarray prologue + k_ens_finish] core and the generic program path are two plans of
+    the same operators: identical trajectories (f64), incl. multi-chunk ensembles (n > 1024)."""
+    pm = small_pathint(ssp_dim=55, n=2500, T=10.0, limit=0.2)
+    model = build(pm.model, n_eval_points=600)
+    outs = []
+    for spg in (16, -1):
+        with Simulator(None, model=model, dtype="f64", steps_per_graph=spg, block_steps=96) as sim:
+            sim.run_steps(300)
+            outs.append(sim.data[pm.probe])
+            outs.append(sim.counters()["launches_per_step"])
+    assert outs[1] == 2 and outs[3] == 2
+    np.testing.assert_array_equal(outs[0], outs[2])
+    ref = OracleSimulator(model)
+    ref.run_steps(300)
+    np.testing.assert_allclose(outs[0], ref.probe_data(0), atol=1e-9, rtol=0)
