@@ -101,8 +101,7 @@ typedef struct ssn_model_desc {
   int32_t n_buffers;
   int32_t n_ops;
   int32_t n_probes;
-  int32_t steps_per_graph;            /* timesteps captured per hipGraph; 0 = library default (16);
-                                         negative = default without the fused recurrent-array core (debug) */
+  int32_t steps_per_graph;            /* timesteps captured per hipGraph; 0 = library default (16), 1 = no graph */
   const ssn_buffer_desc* buffers;
   const ssn_op_desc* ops;
   const ssn_probe_desc* probes;
@@ -113,7 +112,8 @@ typedef struct ssn_model_desc {
   const ssn_range* pre_to_core;
   const ssn_range* core_to_post;
   int32_t block_steps;                /* timesteps per time-batched block; 0 = library default (256) */
-  int32_t reserved2;
+  int32_t flags;                      /* debug / A-B switches: 1 = no fused recurrent-array core (generic programs),
+                                         2 = no LIF fast path (unpacked state, dense row-major decoders)           */
 } ssn_model_desc;
 
 typedef struct ssn_counters {

@@ -42,7 +42,7 @@ class ModelDesc(C.Structure):
                 ("steps_per_graph", C.c_int32), ("buffers", C.POINTER(BufferDesc)), ("ops", C.POINTER(OpDesc)),
                 ("probes", C.POINTER(ProbeDesc)), ("n_pre_to_core", C.c_int32), ("n_core_to_post", C.c_int32),
                 ("pre_to_core", C.POINTER(Range)), ("core_to_post", C.POINTER(Range)), ("block_steps", C.c_int32),
-                ("reserved2", C.c_int32)]
+                ("flags", C.c_int32)]
 
 
 class Counters(C.Structure):

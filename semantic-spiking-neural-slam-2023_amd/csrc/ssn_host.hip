@@ -60,6 +60,10 @@ struct Buf {
   bool shaped = false;
   bool keep = false;                      // keep host copy for reset (state / learned)
   std::vector<double> host;               // initial contents if keep
+  // ensemble-array fast path (k_ensarray FAST): decoders neuron-major, (V, R) packed into the V buffer
+  int dec_K = 0, dec_dout = 0, dec_n = 0, dec_DP = 0;   // dec_DP > 0: stored [K][ld][DP] instead of [K*dout][ld]
+  int packed = 0;                         // 1: holds packed LIF state words; 2: refractory view of buffer `partner`
+  int partner = -1;
 };
 
 enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH };
@@ -115,6 +119,7 @@ struct Sim final : ssn_sim {
   T* bsig = nullptr;                          // [block+1][n_sig]
   int block = 0;                              // timesteps per block (0: staging off)
   bool core_empty = false;                    // no per-timestep work at all
+  int flags = 0;                              // ssn_model_desc.flags
   bool fused_core = false;                    // core == one recurrent ensemble array: [k_ensarray, k_ens_finish]
   std::vector<void*> fused_bufs;
   std::vector<ssn::BatchOp<T>> pre_ops, post_ops;
@@ -208,6 +213,44 @@ struct Sim final : ssn_sim {
     return SSN_OK;
   }
 
+  bool ens_fast(const ssn_op_desc& o) const {
+    // spiking LIF with min_voltage == 0: packed state word + (dout >= 3) spike-sparse neuron-major decoders
+    return !(flags & 2) && o.i[11] == SSN_LIF && o.f[2] == 0.0;
+  }
+
+  // host [rows][cols] double -> device layout of buffer b
+  int upload_buf(Buf& b, const double* src) {
+    if (!b.dec_DP) return upload(src, (T*)b.d, b.rows, b.cols, b.ld);
+    T* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, (size_t)(b.rows * b.ld) * sizeof(T)));
+    int rc = upload(src, tmp, b.rows, b.cols, b.ld);
+    hipError_t e = hipSuccess;
+    if (rc == SSN_OK) e = ssn::launch_dec_pack<T>(stream, tmp, (T*)b.d, b.dec_K, b.dec_dout, b.dec_n, (int)b.ld, b.dec_DP, 0);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    hipFree(tmp);
+    CHK(rc);
+    HIPCHK(e);
+    return SSN_OK;
+  }
+
+  int download_buf(Buf& b, double* dst) {
+    if (!b.dec_DP && !b.packed) return download((const T*)b.d, dst, b.rows, b.cols, b.ld);
+    T* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, (size_t)(b.rows * b.ld) * sizeof(T)));
+    hipError_t e = hipSuccess;
+    if (b.dec_DP) {
+      e = hipMemsetAsync(tmp, 0, (size_t)(b.rows * b.ld) * sizeof(T), stream);
+      if (e == hipSuccess) e = ssn::launch_dec_pack<T>(stream, (const T*)b.d, tmp, b.dec_K, b.dec_dout, b.dec_n, (int)b.ld, b.dec_DP, 1);
+    } else {
+      const T* words = (const T*)(b.packed == 2 ? bufs[b.partner].d : b.d);
+      e = ssn::launch_state_unpack<T>(stream, words, tmp, b.rows * b.ld, b.packed == 2);
+    }
+    int rc = e == hipSuccess ? download(tmp, dst, b.rows, b.cols, b.ld) : SSN_OK;
+    hipFree(tmp);
+    HIPCHK(e);
+    return rc;
+  }
+
   int shape(int id, int64_t rows, int64_t cols, bool pad, bool keep) {
     if (id < 0 || id >= (int)bufs.size()) return fail(SSN_EINVAL, "buffer id %d out of range", id);
     Buf& b = bufs[id];
@@ -239,6 +282,7 @@ struct Sim final : ssn_sim {
   int create(const ssn_model_desc* m) {
     device = m->device;
     dt = m->dt;
+    flags = m->flags;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&ev_run0));
@@ -267,6 +311,12 @@ struct Sim final : ssn_sim {
           CHK(shape((int)o.i[7], K * dout, n, true, false));
           CHK(shape((int)o.i[9], K, n, true, true));
           CHK(shape((int)o.i[10], K, n, true, true));
+          if (ens_fast(o)) {
+            Buf& vb = bufs[o.i[9]]; Buf& rb = bufs[o.i[10]]; Buf& db = bufs[o.i[7]];
+            if (vb.packed == 2 || rb.packed == 1 || o.i[9] == o.i[10]) return fail(SSN_EINVAL, "ensemble array state buffers shared inconsistently");
+            vb.packed = 1; rb.packed = 2; rb.partner = (int)o.i[9];
+            if (dout >= 3) { db.dec_K = (int)K; db.dec_dout = (int)dout; db.dec_n = (int)n; db.dec_DP = dout <= 4 ? 4 : 8; }
+          }
           if (o.i[8] < 0 || o.i[8] >= m->n_buffers || bufs[o.i[8]].kind != SSN_BUF_I32 || bufs[o.i[8]].count != K * dout)
             return fail(SSN_EINVAL, "ensemble array dst_idx buffer must be int32 [K*dout]");
           const int32_t* di = (const int32_t*)m->buffers[o.i[8]].data;
@@ -321,8 +371,9 @@ struct Sim final : ssn_sim {
         CHK(dmalloc((int32_t**)&b.d, b.count * 4));
         HIPCHK(hipMemcpy(b.d, m->buffers[i].data, (size_t)b.count * 4, hipMemcpyHostToDevice));
       } else {
-        CHK(dmalloc((T**)&b.d, b.rows * b.ld * (int64_t)sizeof(T)));
-        CHK(upload((const double*)m->buffers[i].data, (T*)b.d, b.rows, b.cols, b.ld));
+        const int64_t elems = b.dec_DP ? (int64_t)b.dec_K * b.ld * b.dec_DP : b.rows * b.ld;
+        CHK(dmalloc((T**)&b.d, elems * (int64_t)sizeof(T)));
+        CHK(upload_buf(b, (const double*)m->buffers[i].data));
         if (b.keep) b.host.assign((const double*)m->buffers[i].data, (const double*)m->buffers[i].data + b.count);
       }
     }
@@ -362,7 +413,7 @@ struct Sim final : ssn_sim {
       for (auto& r : core_to_post) CHK(check_range(r.lo, r.hi - r.lo, "core->post boundary"));
     }
     CHK(plan(m));
-    steps_per_graph = m->steps_per_graph > 0 ? m->steps_per_graph : 16;
+    steps_per_graph = m->steps_per_graph != 0 ? m->steps_per_graph : 16;
     CHK(capture());
     HIPCHK(hipStreamSynchronize(stream));
     return SSN_OK;
@@ -394,6 +445,7 @@ struct Sim final : ssn_sim {
     a.sig = sig; a.x_off = o.i[0];
     a.np = neuron_params(o.i[11], o.f);
     a.xrows = nullptr; a.n_sig = n_sig; a.ctx = d_ctx; a.n_rec = 0;
+    a.fast = ens_fast(o) ? 1 : 0;
     ens_chunking(a);
   }
 
@@ -496,7 +548,7 @@ struct Sim final : ssn_sim {
 
   int plan(const ssn_model_desc* m) {
     int frc = SSN_OK;
-    const bool fused = m->steps_per_graph >= 0 && try_fused_core(m, &frc);
+    const bool fused = !(flags & 1) && try_fused_core(m, &frc);
     CHK(frc);
     std::vector<std::vector<MOp>> programs;   // programs in step order
     std::vector<int> item_prog;               // for IT_PROGRAM items: index into programs
@@ -862,7 +914,7 @@ struct Sim final : ssn_sim {
     HIPCHK(hipStreamSynchronize(stream));
     CHK(upload(sig_init.data(), sig, 1, n_sig, n_sig));
     for (auto& b : bufs)
-      if (b.keep) CHK(upload(b.host.data(), (T*)b.d, b.rows, b.cols, b.ld));
+      if (b.keep) CHK(upload_buf(b, b.host.data()));
     HIPCHK(hipMemset(d_ctx, 0, sizeof(ssn::StepCtx)));
     CHK(init_bsig());
     steps_done = 0;
@@ -968,7 +1020,9 @@ struct Sim final : ssn_sim {
     if (id < 0 || id >= (int)bufs.size()) return fail(SSN_EINVAL, "buffer id %d out of range", id);
     Buf& b = bufs[id];
     if (b.kind != SSN_BUF_REAL || count != b.count) return fail(SSN_EINVAL, "buffer %d: real buffer of %lld elements expected", id, (long long)b.count);
-    return dst ? download((const T*)b.d, dst, b.rows, b.cols, b.ld) : upload(src, (T*)b.d, b.rows, b.cols, b.ld);
+    if (dst) return download_buf(b, dst);
+    if (b.packed == 2) return fail(SSN_EUNSUPPORTED, "buffer %d: the refractory times of a LIF ensemble array are packed with its voltages; write the voltage buffer", id);
+    return upload_buf(b, src);
   }
 
   int counters(ssn_counters* out) override {
@@ -1062,6 +1116,6 @@ int ssn_device_count(void) {
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 const char* ssn_last_error(void) { return g_err.c_str(); }
-const char* ssn_version(void) { return "libssn_hip 0.2 (gfx950, ABI 2)"; }
+const char* ssn_version(void) { return "libssn_hip 0.3 (gfx950, ABI 2)"; }
 
 }  // extern "C"

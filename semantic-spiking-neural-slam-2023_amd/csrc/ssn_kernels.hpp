@@ -65,23 +65,38 @@ __device__ inline T wave_sum(T v) {
 // ---------------------------------------------------------------------------------------------
 // k_ensarray: K equal ensembles of n neurons, din-dimensional, dout decoded rows each.
 //   grid = K * P workgroups of 256 threads; workgroup (k, p) streams a contiguous chunk of
-//   ensemble k's neurons once: enc[din] + bias + V + R in, V + R out, dec[dout] in -
-//   (din + dout + 5) words per neuron-step, every access a 16-byte-per-lane coalesced vector.
-//   Spikes never leave registers.  Each workgroup leaves dout partial sums; the P partials of an
-//   ensemble are added in fixed order by the ENS_FINISH micro-op of the following program
-//   (deterministic, no atomics).
-// Layout: enc [K][DIN][n_pad], bias/V/R [K][n_pad], dec [K][DOUT][n_pad], n_pad % W == 0.
+//   ensemble k's neurons once.  Every streamed access is a 16-byte-per-lane coalesced vector; spikes
+//   never leave registers.  Each workgroup leaves dout partial sums; the P partials of an ensemble are
+//   added in fixed order afterwards (deterministic, no atomics).
+//
+//   Two variants (template FAST):
+//   * generic (any neuron type): enc[din] + bias + V + R in, V + R out, dec[dout] in:
+//     (din + dout + 5) words per neuron-step (the 52 B of SURVEY 8d at din 3, dout 5, f32).
+//   * FAST (spiking LIF with min_voltage = 0) moves fewer bytes for the same result, bit for bit:
+//       - voltage and refractory time share ONE state word s: s >= 0 is the voltage of a
+//         non-refractory neuron, s < 0 is minus the remaining refractory time (voltage is exactly 0
+//         then).  A refractory time <= dt is not stored: the next step integrates for the full dt
+//         whatever its value.  (-2 words)
+//       - decoders are stored neuron-major ([n][DP], DP = 4 or 8 words) and fetched only for the
+//         neurons that spiked this step (~10 % at SLAM rates): ~64 B per spike instead of dout words
+//         per neuron.
+// Layout: enc [K][DIN][n_pad], bias/V/R [K][n_pad], dec [K][DOUT][n_pad] (generic) or [K][n_pad][DP]
+// (FAST with DOUT >= 3), n_pad % W == 0.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DIN, int DOUT>
+template <int DOUT> struct DecPitch { static constexpr int value = DOUT <= 4 ? 4 : 8; };
+
+template <typename T, int DIN, int DOUT, bool FAST>
 __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
   using vec = typename VecT<T>::type;
   constexpr int W = VecT<T>::W;
+  constexpr bool SPARSE = FAST && DOUT >= 3;
+  constexpr int DP = DecPitch<DOUT>::value;
   const int k = blockIdx.x / a.P;
   const int p = blockIdx.x - k * a.P;
   const size_t row = (size_t)a.n_pad;
   const T* __restrict__ enc = a.enc + (size_t)k * DIN * row;
   const T* __restrict__ bias = a.bias + (size_t)k * row;
-  const T* __restrict__ dec = a.dec + (size_t)k * DOUT * row;
+  const T* __restrict__ dec = a.dec + (size_t)k * (SPARSE ? DP : DOUT) * row;
   T* __restrict__ Vp = a.V + (size_t)k * row;
   T* __restrict__ Rp = a.R + (size_t)k * row;
 
@@ -106,29 +121,84 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
   const int n_vec = a.n_pad / W;
   const int v_begin = p * a.chunk_vec;
   const int v_end = min(n_vec, v_begin + a.chunk_vec);
+  const NeuronParams<T> np = a.np;
   for (int v = v_begin + (int)threadIdx.x; v < v_end; v += 256) {
     const size_t o = (size_t)v * W;
-    T e[DIN][W], b[W], Vv[W], Rv[W], dd[DOUT][W];
+    T e[DIN][W], b[W], Vv[W];
 #pragma unroll
     for (int d = 0; d < DIN; ++d) *(vec*)e[d] = *(const vec*)(enc + d * row + o);
     *(vec*)b = *(const vec*)(bias + o);
     *(vec*)Vv = *(const vec*)(Vp + o);
-    *(vec*)Rv = *(const vec*)(Rp + o);
+    if constexpr (!FAST) {
+      T Rv[W], dd[DOUT][W];
+      *(vec*)Rv = *(const vec*)(Rp + o);
 #pragma unroll
-    for (int r = 0; r < DOUT; ++r) *(vec*)dd[r] = *(const vec*)(dec + r * row + o);
+      for (int r = 0; r < DOUT; ++r) *(vec*)dd[r] = *(const vec*)(dec + r * row + o);
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
-      if ((int)o + j < a.n) {
-        T J = b[j];
+      for (int j = 0; j < W; ++j) {
+        if ((int)o + j < a.n) {
+          T J = b[j];
 #pragma unroll
-        for (int d = 0; d < DIN; ++d) J += e[d][j] * x[d];
-        const T act = neuron_step(a.np, J, Vv[j], Rv[j]);
+          for (int d = 0; d < DIN; ++d) J += e[d][j] * x[d];
+          const T act = neuron_step(np, J, Vv[j], Rv[j]);
 #pragma unroll
-        for (int r = 0; r < DOUT; ++r) acc[r] += act * dd[r][j];
+          for (int r = 0; r < DOUT; ++r) acc[r] += act * dd[r][j];
+        }
+      }
+      *(vec*)(Vp + o) = *(vec*)Vv;
+      *(vec*)(Rp + o) = *(vec*)Rv;
+    } else {
+      bool spiked[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        spiked[j] = false;
+        if ((int)o + j < a.n) {
+          T J = b[j];
+#pragma unroll
+          for (int d = 0; d < DIN; ++d) J += e[d][j] * x[d];
+          // unpack the state word, then nengo's LIF step operation for operation
+          const T s = Vv[j];
+          T V = s < T(0) ? T(0) : s;
+          T R = (s < T(0) ? -s : T(0)) - np.dt;
+          T delta = np.dt - R;
+          delta = delta < T(0) ? T(0) : (delta > np.dt ? np.dt : delta);
+          V = V - (J - V) * expm1_(-delta / np.tau_rc);
+          if (V > T(1)) {
+            const T t_spike = np.dt + np.tau_rc * log1p_(-(V - T(1)) / (J - T(1)));
+            R = np.tau_ref + t_spike;
+            V = T(0);
+            spiked[j] = true;
+          } else if (V < T(0)) {
+            V = T(0);
+          }
+          Vv[j] = R > np.dt ? -R : V;       // voltage is exactly 0 whenever R > dt
+        }
+      }
+      *(vec*)(Vp + o) = *(vec*)Vv;
+      if constexpr (SPARSE) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          if (spiked[j]) {
+            T dd[DP];
+            const T* dp = dec + (o + j) * DP;
+#pragma unroll
+            for (int q = 0; q < DP; q += W) *(vec*)(dd + q) = *(const vec*)(dp + q);
+#pragma unroll
+            for (int r = 0; r < DOUT; ++r) acc[r] += dd[r];
+          }
+        }
+      } else {
+        T dd[DOUT][W];
+#pragma unroll
+        for (int r = 0; r < DOUT; ++r) *(vec*)dd[r] = *(const vec*)(dec + r * row + o);
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+          if (spiked[j]) {
+#pragma unroll
+            for (int r = 0; r < DOUT; ++r) acc[r] += dd[r][j];
+          }
       }
     }
-    *(vec*)(Vp + o) = *(vec*)Vv;
-    *(vec*)(Rp + o) = *(vec*)Rv;
   }
 
   __shared__ T red[4][DOUT];
@@ -143,6 +213,39 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
     const int r = threadIdx.x;
     a.partials[((size_t)k * a.P + p) * DOUT + r] = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
   }
+}
+
+// decoder re-layout [K][dout][n] (row-major, host order, ld = n_pad) <-> [K][n_pad][DP] (neuron-major)
+template <typename T>
+__global__ void k_dec_pack(const T* __restrict__ src, T* __restrict__ dst, int K, int dout, int n, int n_pad, int DP, int unpack) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)K * n_pad * DP) return;
+  const int q = (int)(i % DP);
+  const int64_t t = i / DP;
+  const int nn = (int)(t % n_pad), k = (int)(t / n_pad);
+  if (!unpack) dst[i] = (q < dout && nn < n) ? src[((size_t)k * dout + q) * n_pad + nn] : T(0);
+  else if (q < dout && nn < n) dst[((size_t)k * dout + q) * n_pad + nn] = src[i];
+}
+template <typename T>
+hipError_t launch_dec_pack(hipStream_t s, const T* src, T* dst, int K, int dout, int n, int n_pad, int DP, int unpack) {
+  const int64_t total = (int64_t)K * n_pad * DP;
+  hipLaunchKernelGGL((k_dec_pack<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, K, dout, n, n_pad, DP, unpack);
+  return hipGetLastError();
+}
+
+// packed LIF state word -> (voltage, refractory time) for ssn_read_buffer
+template <typename T>
+__global__ void k_state_unpack(const T* __restrict__ s, T* __restrict__ out, int64_t n, int want_refractory) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const T v = s[i];
+  out[i] = want_refractory ? (v < T(0) ? -v : T(0)) : (v < T(0) ? T(0) : v);
+}
+template <typename T>
+hipError_t launch_state_unpack(hipStream_t s, const T* src, T* out, int64_t n, int want_refractory) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((k_state_unpack<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, out, n, want_refractory);
+  return hipGetLastError();
 }
 
 template <typename T>
@@ -172,11 +275,11 @@ hipError_t launch_ens_finish(hipStream_t s, const FinishArgs<T>& f) {
   return hipGetLastError();
 }
 
-template <typename T, int DIN>
+template <typename T, int DIN, bool FAST>
 static hipError_t launch_ens_dout(hipStream_t s, const EnsArgs<T>& a) {
   const dim3 grid((unsigned)(a.K * a.P)), block(256);
   switch (a.dout) {
-#define SSN_CASE(D) case D: hipLaunchKernelGGL((k_ensarray<T, DIN, D>), grid, block, 0, s, a); break;
+#define SSN_CASE(D) case D: hipLaunchKernelGGL((k_ensarray<T, DIN, D, FAST>), grid, block, 0, s, a); break;
     SSN_CASE(1) SSN_CASE(2) SSN_CASE(3) SSN_CASE(4) SSN_CASE(5) SSN_CASE(6) SSN_CASE(7) SSN_CASE(8)
 #undef SSN_CASE
     default: return hipErrorInvalidValue;
@@ -186,11 +289,20 @@ static hipError_t launch_ens_dout(hipStream_t s, const EnsArgs<T>& a) {
 
 template <typename T>
 hipError_t launch_ensarray(hipStream_t s, const EnsArgs<T>& a) {
+  if (a.fast) {
+    switch (a.din) {
+      case 1: return launch_ens_dout<T, 1, true>(s, a);
+      case 2: return launch_ens_dout<T, 2, true>(s, a);
+      case 3: return launch_ens_dout<T, 3, true>(s, a);
+      case 4: return launch_ens_dout<T, 4, true>(s, a);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (a.din) {
-    case 1: return launch_ens_dout<T, 1>(s, a);
-    case 2: return launch_ens_dout<T, 2>(s, a);
-    case 3: return launch_ens_dout<T, 3>(s, a);
-    case 4: return launch_ens_dout<T, 4>(s, a);
+    case 1: return launch_ens_dout<T, 1, false>(s, a);
+    case 2: return launch_ens_dout<T, 2, false>(s, a);
+    case 3: return launch_ens_dout<T, 3, false>(s, a);
+    case 4: return launch_ens_dout<T, 4, false>(s, a);
     default: return hipErrorInvalidValue;
   }
 }
@@ -628,6 +740,8 @@ hipError_t launch_convert_out(hipStream_t s, const T* src, double* dst, int64_t 
 
 #define SSN_INSTANTIATE(T)                                                                                   \
   template hipError_t launch_ensarray<T>(hipStream_t, const EnsArgs<T>&);                                    \
+  template hipError_t launch_dec_pack<T>(hipStream_t, const T*, T*, int, int, int, int, int, int);           \
+  template hipError_t launch_state_unpack<T>(hipStream_t, const T*, T*, int64_t, int);                       \
   template hipError_t launch_program<T>(hipStream_t, const MicroOp<T>*, int, T*, StepCtx*);                  \
   template hipError_t launch_ens_finish<T>(hipStream_t, const FinishArgs<T>&);                               \
   template hipError_t launch_matvec<T>(hipStream_t, const T*, const T*, T*, int, int, int, int);            \

@@ -36,6 +36,7 @@ struct EnsArgs {
   int n_rec;
   long long rec_dst[4], rec_src[4], rec_len[4];
   T rec_alpha[4];
+  int fast;            // LIF fast variant: packed state word (+ neuron-major spike-sparse decoders if dout >= 3)
 };
 
 // Finish of a fused recurrent ensemble array: one thread per decoded row (k, r):
@@ -108,6 +109,8 @@ struct BatchOp {
 };
 
 template <typename T> hipError_t launch_ensarray(hipStream_t, const EnsArgs<T>&);
+template <typename T> hipError_t launch_dec_pack(hipStream_t, const T* src, T* dst, int K, int dout, int n, int n_pad, int DP, int unpack);
+template <typename T> hipError_t launch_state_unpack(hipStream_t, const T* src, T* out, int64_t n, int want_refractory);
 template <typename T> hipError_t launch_ens_finish(hipStream_t, const FinishArgs<T>&);
 template <typename T> hipError_t launch_program(hipStream_t, const MicroOp<T>*, int, T*, StepCtx*);
 template <typename T> hipError_t launch_matvec(hipStream_t, const T* W, const T* src, T* dst, int rows, int cols, int ld, int set);

@@ -44,7 +44,7 @@ class SimulationData(dict):
         return key in self._sim._probe_index or key in self._sim.model.params
 
 
-def pack_model(model, dtype, device=0, steps_per_graph=0, block_steps=0):
+def pack_model(model, dtype, device=0, steps_per_graph=0, block_steps=0, flags=0):
     """BuiltModel -> (ssn_model_desc, keep-alive list) for ``ssn_create``."""
     keep = []
     sig_init = np.ascontiguousarray(model.sig_init, dtype=np.float64)
@@ -139,6 +139,7 @@ def pack_model(model, dtype, device=0, steps_per_graph=0, block_steps=0):
     desc.n_pre_to_core, desc.n_core_to_post = len(p2c), len(c2p)
     desc.pre_to_core, desc.core_to_post = r_p2c, r_c2p
     desc.block_steps = int(block_steps)
+    desc.flags = int(flags)
     keep += [bufs, ops, probes, r_p2c, r_c2p]
     return desc, keep, sig_probes
 
@@ -164,7 +165,7 @@ def tabulate(fn, width, steps, dt):
 
 class Simulator:
     def __init__(self, network, dt=0.001, seed=None, progress_bar=None, dtype="f32", device=0,
-                 n_eval_points=None, steps_per_graph=0, model=None, vco_shard=None, block_steps=0):
+                 n_eval_points=None, steps_per_graph=0, model=None, vco_shard=None, block_steps=0, flags=0):
         self.dt = float(dt)
         self.closed = True
         self._lib = _lib.load()          # fails loudly when the HIP library is not built
@@ -175,7 +176,7 @@ class Simulator:
                 model = build(network, dt=dt, seed=seed, n_eval_points=n_eval_points, vco_shard=vco_shard)
         self.model = model
         self.dtype = "f64" if dtype in ("f64", "float64", np.float64) else "f32"
-        desc, keep, self._sig_probes = pack_model(model, self.dtype, device, steps_per_graph, block_steps)
+        desc, keep, self._sig_probes = pack_model(model, self.dtype, device, steps_per_graph, block_steps, flags)
         self._h = C.c_void_p()
         t0 = time.time()
         self._check(self._lib.ssn_create(C.byref(desc), C.byref(self._h)), build=True)

@@ -264,13 +264,17 @@ def test_fused_recurrent_core_equals_generic_path(Simulator):
     pm = small_pathint(ssp_dim=55, n=2500, T=10.0, limit=0.2)
     model = build(pm.model, n_eval_points=600)
     outs = []
-    for spg in (16, -1):
-        with Simulator(None, model=model, dtype="f64", steps_per_graph=spg, block_steps=96) as sim:
+    for flags in (0, 1):
+        with Simulator(None, model=model, dtype="f64", flags=flags, block_steps=96) as sim:
             sim.run_steps(300)
             outs.append(sim.data[pm.probe])
             outs.append(sim.counters()["launches_per_step"])
     assert outs[1] == 2 and outs[3] == 2
     np.testing.assert_array_equal(outs[0], outs[2])
+    # LIF fast path (packed state word, spike-sparse neuron-major decoders) vs the generic kernel: same bits
+    with Simulator(None, model=model, dtype="f64", flags=2, block_steps=96) as sim:
+        sim.run_steps(300)
+        np.testing.assert_array_equal(sim.data[pm.probe], outs[0])
     ref = OracleSimulator(model)
     ref.run_steps(300)
     np.testing.assert_allclose(outs[0], ref.probe_data(0), atol=1e-9, rtol=0)
