@@ -144,8 +144,19 @@ def main():
         if c["dominant_launches"]:
             avg_ms = c["dominant_ms_total"] / c["dominant_launches"]
             achieved = c["dominant_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_note = None, None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):          # HBM bytes per launch from separate rocprofv3 --pmc passes of this command
+                with open(pmc) as f:
+                    t = json.load(f)
+                if t.get("units_per_launch") == c["dominant_units_per_launch"] and t.get("dtype") == args.dtype:
+                    traffic = t["hbm_bytes_per_launch"]
+                    traffic_note = ("measured HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json); "
+                                    "below the algorithmic count because the LIF fast path packs (V, refractory) into one word and "
+                                    "fetches decoders only for neurons that spiked")
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                               "hbm_gbs_measured": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
                                "kernel": "k_ensarray", "avg_launch_us": round(avg_ms * 1e3, 2),
                                "algorithmic_bytes_per_launch": c["dominant_bytes_per_launch"],
                                "bytes_per_neuron_step": c["dominant_bytes_per_launch"] / c["dominant_units_per_launch"],

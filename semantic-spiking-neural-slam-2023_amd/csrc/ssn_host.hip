@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -218,6 +219,8 @@ struct Sim final : ssn_sim {
     return !(flags & 2) && o.i[11] == SSN_LIF && o.f[2] == 0.0;
   }
 
+  bool ens_sparse(const ssn_op_desc& o) const { return ens_fast(o) && !(flags & 4) && o.i[4] >= 3; }
+
   // host [rows][cols] double -> device layout of buffer b
   int upload_buf(Buf& b, const double* src) {
     if (!b.dec_DP) return upload(src, (T*)b.d, b.rows, b.cols, b.ld);
@@ -315,7 +318,7 @@ struct Sim final : ssn_sim {
             Buf& vb = bufs[o.i[9]]; Buf& rb = bufs[o.i[10]]; Buf& db = bufs[o.i[7]];
             if (vb.packed == 2 || rb.packed == 1 || o.i[9] == o.i[10]) return fail(SSN_EINVAL, "ensemble array state buffers shared inconsistently");
             vb.packed = 1; rb.packed = 2; rb.partner = (int)o.i[9];
-            if (dout >= 3) { db.dec_K = (int)K; db.dec_dout = (int)dout; db.dec_n = (int)n; db.dec_DP = dout <= 4 ? 4 : 8; }
+            if (ens_sparse(o)) { db.dec_K = (int)K; db.dec_dout = (int)dout; db.dec_n = (int)n; db.dec_DP = dout <= 4 ? 4 : 8; }
           }
           if (o.i[8] < 0 || o.i[8] >= m->n_buffers || bufs[o.i[8]].kind != SSN_BUF_I32 || bufs[o.i[8]].count != K * dout)
             return fail(SSN_EINVAL, "ensemble array dst_idx buffer must be int32 [K*dout]");
@@ -432,6 +435,7 @@ struct Sim final : ssn_sim {
     int sweeps = 1;
     const int max_sweeps = (n_vec + 255) / 256;
     while (sweeps < max_sweeps && (int64_t)a.K * ((n_vec + 256 * (sweeps + 1) - 1) / (256 * (sweeps + 1))) >= 4096) ++sweeps;
+    if (const char* env = getenv("SSN_ENS_SWEEPS")) sweeps = std::max(1, std::min(max_sweeps, atoi(env)));   // tuning knob
     a.chunk_vec = 256 * sweeps;
     a.P = (n_vec + a.chunk_vec - 1) / a.chunk_vec;
   }
@@ -445,7 +449,7 @@ struct Sim final : ssn_sim {
     a.sig = sig; a.x_off = o.i[0];
     a.np = neuron_params(o.i[11], o.f);
     a.xrows = nullptr; a.n_sig = n_sig; a.ctx = d_ctx; a.n_rec = 0;
-    a.fast = ens_fast(o) ? 1 : 0;
+    a.fast = ens_fast(o) ? (ens_sparse(o) ? 1 : 2) : 0;
     ens_chunking(a);
   }
 

@@ -28,6 +28,38 @@ __device__ inline double expm1_(double x) { return expm1(x); }
 __device__ inline float  log1p_(float x)  { return log1pf(x); }
 __device__ inline double log1p_(double x) { return log1p(x); }
 
+// LIF arithmetic of the FAST kernel variant.  double: the libm calls, operation for operation like the
+// oracle.  float: the same formulas with cheap evaluations that are exact to f32 rounding on the
+// argument ranges that occur - expm1(x) for x in [-dt/tau_rc, 0] by its Taylor polynomial (|x| <= ~0.05:
+// the first neglected term is < 2e-13 relative), log1p(-u) for u in (0, 1) via the hardware log, and
+// reciprocal-multiply divisions.  This cuts the per-neuron VALU work ~4x (the kernel was co-limited by it).
+template <typename T> struct LifMath;
+template <> struct LifMath<double> {
+  const double tau_rc;
+  __device__ explicit LifMath(const NeuronParams<double>& p) : tau_rc(p.tau_rc) {}
+  __device__ double decay(double delta) const { return expm1(-delta / tau_rc); }
+  __device__ double spike_time_term(double V, double J) const { return log1p(-(V - 1.0) / (J - 1.0)); }
+};
+template <> struct LifMath<float> {
+  const float neg_inv_tau;
+  __device__ explicit LifMath(const NeuronParams<float>& p) : neg_inv_tau(-1.0f / p.tau_rc) {}
+  __device__ float decay(float delta) const {
+    const float x = delta * neg_inv_tau;
+    if (x < -0.125f) return expm1f(x);          // dt/tau_rc larger than the polynomial's range: library call
+    float q = 1.0f / 720.0f;
+    q = fmaf(q, x, 1.0f / 120.0f);
+    q = fmaf(q, x, 1.0f / 24.0f);
+    q = fmaf(q, x, 1.0f / 6.0f);
+    q = fmaf(q, x, 0.5f);
+    q = fmaf(q, x, 1.0f);
+    return q * x;
+  }
+  __device__ float spike_time_term(float V, float J) const {
+    const float u = (V - 1.0f) * __frcp_rn(J - 1.0f);
+    return __logf(1.0f - u);
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // neuron models.  Returns the unit-amplitude activity: spike 0/1 or rate.
 // Operation order follows the oracle (oracle/stepper.py lif_step) so that the f64 build, compiled
@@ -85,11 +117,12 @@ __device__ inline T wave_sum(T v) {
 // ---------------------------------------------------------------------------------------------
 template <int DOUT> struct DecPitch { static constexpr int value = DOUT <= 4 ? 4 : 8; };
 
-template <typename T, int DIN, int DOUT, bool FAST>
+template <typename T, int DIN, int DOUT, int MODE>   // MODE 0 generic | 1 fast, spike-sparse decoders | 2 fast, dense decoders
 __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
   using vec = typename VecT<T>::type;
   constexpr int W = VecT<T>::W;
-  constexpr bool SPARSE = FAST && DOUT >= 3;
+  constexpr bool FAST = MODE != 0;
+  constexpr bool SPARSE = MODE == 1;
   constexpr int DP = DecPitch<DOUT>::value;
   const int k = blockIdx.x / a.P;
   const int p = blockIdx.x - k * a.P;
@@ -100,6 +133,26 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
   T* __restrict__ Vp = a.V + (size_t)k * row;
   T* __restrict__ Rp = a.R + (size_t)k * row;
 
+  const int n_vec = a.n_pad / W;
+  const int v_begin = p * a.chunk_vec;
+  const int v_end = min(n_vec, v_begin + a.chunk_vec);
+  const NeuronParams<T> np = a.np;
+  const LifMath<T> lm(np);
+
+  // The streaming loads of the first sweep are issued before the (dependent, scalar) input assembly so
+  // that its latency chain - step counter -> row address -> x - hides under them.
+  T e[DIN][W], b[W], Vv[W], Rv[W];
+  int v = v_begin + (int)threadIdx.x;
+  auto load_sweep = [&](int vv) {
+    const size_t o = (size_t)vv * W;
+#pragma unroll
+    for (int d = 0; d < DIN; ++d) *(vec*)e[d] = *(const vec*)(enc + d * row + o);
+    *(vec*)b = *(const vec*)(bias + o);
+    *(vec*)Vv = *(const vec*)(Vp + o);
+    if constexpr (!FAST) *(vec*)Rv = *(const vec*)(Rp + o);
+  };
+  if (v < v_end) load_sweep(v);
+
   T x[DIN];
   {
     const T* xsrc = a.sig;
@@ -107,10 +160,10 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
 #pragma unroll
     for (int d = 0; d < DIN; ++d) {
       const long long xi = a.x_off + (long long)k * DIN + d;
-      T v = xsrc[xi];
+      T xv = xsrc[xi];
       for (int j = 0; j < a.n_rec; ++j)
-        if (xi >= a.rec_dst[j] && xi < a.rec_dst[j] + a.rec_len[j]) v += a.rec_alpha[j] * a.sig[a.rec_src[j] + (xi - a.rec_dst[j])];
-      x[d] = v;
+        if (xi >= a.rec_dst[j] && xi < a.rec_dst[j] + a.rec_len[j]) xv += a.rec_alpha[j] * a.sig[a.rec_src[j] + (xi - a.rec_dst[j])];
+      x[d] = xv;
     }
   }
 
@@ -118,20 +171,10 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
 #pragma unroll
   for (int r = 0; r < DOUT; ++r) acc[r] = T(0);
 
-  const int n_vec = a.n_pad / W;
-  const int v_begin = p * a.chunk_vec;
-  const int v_end = min(n_vec, v_begin + a.chunk_vec);
-  const NeuronParams<T> np = a.np;
-  for (int v = v_begin + (int)threadIdx.x; v < v_end; v += 256) {
+  for (; v < v_end; v += 256) {
     const size_t o = (size_t)v * W;
-    T e[DIN][W], b[W], Vv[W];
-#pragma unroll
-    for (int d = 0; d < DIN; ++d) *(vec*)e[d] = *(const vec*)(enc + d * row + o);
-    *(vec*)b = *(const vec*)(bias + o);
-    *(vec*)Vv = *(const vec*)(Vp + o);
     if constexpr (!FAST) {
-      T Rv[W], dd[DOUT][W];
-      *(vec*)Rv = *(const vec*)(Rp + o);
+      T dd[DOUT][W];
 #pragma unroll
       for (int r = 0; r < DOUT; ++r) *(vec*)dd[r] = *(const vec*)(dec + r * row + o);
 #pragma unroll
@@ -162,9 +205,9 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
           T R = (s < T(0) ? -s : T(0)) - np.dt;
           T delta = np.dt - R;
           delta = delta < T(0) ? T(0) : (delta > np.dt ? np.dt : delta);
-          V = V - (J - V) * expm1_(-delta / np.tau_rc);
+          V = V - (J - V) * lm.decay(delta);
           if (V > T(1)) {
-            const T t_spike = np.dt + np.tau_rc * log1p_(-(V - T(1)) / (J - T(1)));
+            const T t_spike = np.dt + np.tau_rc * lm.spike_time_term(V, J);
             R = np.tau_ref + t_spike;
             V = T(0);
             spiked[j] = true;
@@ -175,6 +218,7 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
         }
       }
       *(vec*)(Vp + o) = *(vec*)Vv;
+      if (v + 256 < v_end) load_sweep(v + 256);     // next sweep streams in under the decoder gather
       if constexpr (SPARSE) {
 #pragma unroll
         for (int j = 0; j < W; ++j) {
@@ -199,6 +243,7 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
           }
       }
     }
+    if constexpr (!FAST) { if (v + 256 < v_end) load_sweep(v + 256); }
   }
 
   __shared__ T red[4][DOUT];
@@ -275,11 +320,11 @@ hipError_t launch_ens_finish(hipStream_t s, const FinishArgs<T>& f) {
   return hipGetLastError();
 }
 
-template <typename T, int DIN, bool FAST>
+template <typename T, int DIN, int MODE>
 static hipError_t launch_ens_dout(hipStream_t s, const EnsArgs<T>& a) {
   const dim3 grid((unsigned)(a.K * a.P)), block(256);
   switch (a.dout) {
-#define SSN_CASE(D) case D: hipLaunchKernelGGL((k_ensarray<T, DIN, D, FAST>), grid, block, 0, s, a); break;
+#define SSN_CASE(D) case D: hipLaunchKernelGGL((k_ensarray<T, DIN, D, MODE>), grid, block, 0, s, a); break;
     SSN_CASE(1) SSN_CASE(2) SSN_CASE(3) SSN_CASE(4) SSN_CASE(5) SSN_CASE(6) SSN_CASE(7) SSN_CASE(8)
 #undef SSN_CASE
     default: return hipErrorInvalidValue;
@@ -287,24 +332,22 @@ static hipError_t launch_ens_dout(hipStream_t s, const EnsArgs<T>& a) {
   return hipGetLastError();
 }
 
-template <typename T>
-hipError_t launch_ensarray(hipStream_t s, const EnsArgs<T>& a) {
-  if (a.fast) {
-    switch (a.din) {
-      case 1: return launch_ens_dout<T, 1, true>(s, a);
-      case 2: return launch_ens_dout<T, 2, true>(s, a);
-      case 3: return launch_ens_dout<T, 3, true>(s, a);
-      case 4: return launch_ens_dout<T, 4, true>(s, a);
-      default: return hipErrorInvalidValue;
-    }
-  }
+template <typename T, int MODE>
+static hipError_t launch_ens_din(hipStream_t s, const EnsArgs<T>& a) {
   switch (a.din) {
-    case 1: return launch_ens_dout<T, 1, false>(s, a);
-    case 2: return launch_ens_dout<T, 2, false>(s, a);
-    case 3: return launch_ens_dout<T, 3, false>(s, a);
-    case 4: return launch_ens_dout<T, 4, false>(s, a);
+    case 1: return launch_ens_dout<T, 1, MODE>(s, a);
+    case 2: return launch_ens_dout<T, 2, MODE>(s, a);
+    case 3: return launch_ens_dout<T, 3, MODE>(s, a);
+    case 4: return launch_ens_dout<T, 4, MODE>(s, a);
     default: return hipErrorInvalidValue;
   }
+}
+
+template <typename T>
+hipError_t launch_ensarray(hipStream_t s, const EnsArgs<T>& a) {
+  if (a.fast == 1) return launch_ens_din<T, 1>(s, a);
+  if (a.fast == 2) return launch_ens_din<T, 2>(s, a);
+  return launch_ens_din<T, 0>(s, a);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -16,11 +16,12 @@ for r in csv.DictReader(open(sys.argv[3])):
     if "ssn::" in r["Name"] or "k_set_block" in r["Name"]:
         stats[r["Name"].split("(")[0].replace("void ", "")] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                                              "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
-out = {"kernel": "ssn::k_ensarray<float,3,5>", "launches_sampled": {"fetch": nf, "write": nw},
+out = {"kernel": "ssn::k_ensarray<float,3,5,1>", "dtype": "f32", "units_per_launch": int(sys.argv[5]) if len(sys.argv) > 5 else 5080000,
+       "launches_sampled": {"fetch": nf, "write": nw},
        "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB_raw": write_kb,
        "read_bytes_per_launch": 2 * fetch_kb * 1024, "write_bytes_per_launch": write_kb * 1024,
        "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
-       "corrections": "FETCH_SIZE x2 on gfx950 for 16-B/lane coalesced streaming reads; WRITE_SIZE exact; separate --pmc passes",
+       "corrections": "FETCH_SIZE x2 on gfx950 (calibrated for 16-B/lane coalesced streaming reads; applied to the whole count, so the sparse 32-B decoder gathers may be over-counted); WRITE_SIZE exact; separate --pmc passes",
        "kernel_stats": stats}
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("read_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch")}))
