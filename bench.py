@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=60, help="oracle timesteps for the cpu_baseline / parity leg (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=500)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the multi-rank path with several ranks sharing one GPU (RCCL needs one GPU per rank)")
     return ap.parse_args()
 
 
@@ -66,9 +68,13 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from sspslam_amd import harness as H
     from sspslam_amd.builder import build
@@ -95,8 +101,16 @@ def main():
         sim = Simulator(None, model=model, dtype=args.dtype, device=local_rank)
         runner = None
     else:
-        runner = ShardedPathIntegration(pm, rank, world, dt=dt, dtype=args.dtype, device=local_rank,
-                                        n_eval_points=args.eval_points, block=args.block)
+        # ranks that share a GPU (rehearsal only) build one after the other: concurrent rocSOLVER use from
+        # several processes on one device was seen to fail; with one GPU per rank all ranks build at once
+        shared = world > torch.cuda.device_count()
+        runner = None
+        for turn in range(world if shared else 1):
+            if not shared or turn == rank:
+                runner = ShardedPathIntegration(pm, rank, world, dt=dt, dtype=args.dtype, device=local_rank,
+                                                n_eval_points=args.eval_points, block=args.block)
+            if shared:
+                dist.barrier()
         sim, model = runner.sim, runner.model
     build_s = time.time() - t0
 
@@ -112,14 +126,18 @@ def main():
         runner.prepare(n_total)
     for _ in range(args.warmup):
         run_block()
+    if runner is not None:
+        runner.flush()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_block()
+    if runner is not None:
+        runner.flush()                       # rank 0: the read-out of the last block is part of the job
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
-        w = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        w = torch.tensor([wall], device="cuda" if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     sim_seconds = args.steps * args.block * dt
@@ -133,7 +151,7 @@ def main():
         "config": {"workload": f"PathIntegration 2-D ssp_dim={space.ssp_dim} pi_n_neurons={args.pi_n_neurons}/VCO "
                                f"({K} VCOs, {N} LIF neurons), configs[1]",
                    "timesteps_per_step": args.block, "dt": dt, "eval_points_per_vco": args.eval_points,
-                   "parallelism": "1 GPU" if world == 1 else f"VCO-sharded x{world}, all-gather per {args.block} steps",
+                   "parallelism": "1 GPU" if world == 1 else f"VCO-sharded x{world}, all-gather per {args.block} steps ({args.dist_backend})",
                    "build_seconds": round(build_s, 1)},
     }
 

@@ -17,6 +17,9 @@ read-out ``to_SSP @ oscillators.output`` (``:191``).  So, one process per GPU:
 The simulator factory is injectable so the orchestration is exercised on CPU (gloo, world_size 2)
 against the oracle in tests; by default it is the HIP ``Simulator``.
 """
+import queue
+import threading
+
 import numpy as np
 
 from . import frontend as nengo
@@ -48,7 +51,7 @@ class _BlockFeed:
 
 class ShardedPathIntegration:
     def __init__(self, pm, rank, world, dt=0.001, dtype="f32", device=0, n_eval_points=None, block=1000,
-                 sim_factory=None, dist=None, gather_device=None):
+                 sim_factory=None, dist=None, gather_device=None, async_readout=True):
         """``pm``: object from ``harness.make_pathint_model`` (model, pathintegrator, probe)."""
         if dist is None:
             import torch.distributed as dist
@@ -88,9 +91,46 @@ class ShardedPathIntegration:
             self.readout_model = build(ro, dt=dt)
             self.readout = sim_factory(self.readout_model)
         self.n_steps = 0
+        # rank 0 replays block b through the read-out on a worker thread while every rank already steps
+        # block b+1 (the library releases the GIL; the two simulators have their own HIP streams)
+        self._jobs = self._worker = self._error = None
+        if self.readout is not None and async_readout:
+            self._jobs = queue.Queue(maxsize=2)
+            self._worker = threading.Thread(target=self._readout_loop, daemon=True)
+            self._worker.start()
+        self._warm = False
 
     def prepare(self, n_steps):
         self.sim.prepare(n_steps)
+        if self.world > 1 and not self._warm and self.dist.is_initialized():
+            self._gather(np.zeros((1, 3 * (self.hi - self.lo))))   # the first collective sets up the communicator: untimed
+            self._warm = True
+
+    def _replay(self, full, first, n):
+        self.feed.rows, self.feed.first = np.ascontiguousarray(full), first
+        self.readout.prepare(n)
+        self.readout.run_steps(n)
+
+    def _readout_loop(self):
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                self._jobs.task_done()
+                return
+            try:
+                self._replay(*job)
+            except BaseException as e:       # surfaced by flush()
+                self._error = e
+            finally:
+                self._jobs.task_done()
+
+    def flush(self):
+        """Wait until the read-out has consumed every block handed to it."""
+        if self._jobs is not None:
+            self._jobs.join()
+            if self._error is not None:
+                err, self._error = self._error, None
+                raise err
 
     def _gather(self, local):
         """local (B, 3*(hi-lo)) float64 -> (B, 3K) on every rank."""
@@ -117,9 +157,12 @@ class ShardedPathIntegration:
             local = np.zeros((n, 0))
         full = self._gather(local) if self.world > 1 else local
         if self.readout is not None:
-            self.feed.rows, self.feed.first = np.ascontiguousarray(full), self.n_steps
-            self.readout.prepare(n)
-            self.readout.run_steps(n)
+            if self._jobs is not None:
+                if self._error is not None:
+                    self.flush()
+                self._jobs.put((full, self.n_steps, n))
+            else:
+                self._replay(full, self.n_steps, n)
         self.n_steps += n
 
     def run_steps(self, n):
@@ -131,9 +174,15 @@ class ShardedPathIntegration:
 
     def probe_data(self):
         """Rank 0: the filtered PathIntegration output, as ``sim.data[probe]`` of the unsharded model."""
+        self.flush()
         return self.readout.data[self.ro_probe] if self.readout is not None else None
 
     def close(self):
+        if self._jobs is not None:
+            self.flush()
+            self._jobs.put(None)
+            self._worker.join()
+            self._jobs = None
         for s in (self.sim, self.readout):
             if s is not None and hasattr(s, "close"):
                 s.close()

@@ -92,16 +92,23 @@ def _solve_torch(eval_points, scaled_encoders, bias, neuron, Y, reg):
     m, n = A.shape
     sigma = reg * float(A.max())
     lam = m * sigma * sigma
-    if m >= n:
-        G = A.T @ A
-        G.diagonal().add_(lam)
-        L = torch.linalg.cholesky(G)
-        D = torch.cholesky_solve(A.T @ Yt, L)
-    else:
-        G = A @ A.T
-        G.diagonal().add_(lam)
-        L = torch.linalg.cholesky(G)
-        D = A.T @ torch.cholesky_solve(Yt, L)
+    G = A.T @ A if m >= n else A @ A.T
+    G.diagonal().add_(lam)
+    L = None
+    for _ in range(2):                       # the Gram matrix is positive definite by construction; a failed
+        L, info = torch.linalg.cholesky_ex(G)    # factorisation has only been seen with several processes sharing a GPU
+        if int(info) == 0 and bool(torch.isfinite(L).all()):
+            break
+        L = None
+        torch.cuda.synchronize() if dev.type == "cuda" else None
+    if L is None:                            # last resort: host factorisation of the same system
+        import scipy.linalg
+        with _blas_threads():
+            c = scipy.linalg.cho_factor(G.cpu().numpy(), check_finite=False)
+            if m >= n:
+                return scipy.linalg.cho_solve(c, (A.T @ Yt).cpu().numpy(), check_finite=False)
+            return (A.T.cpu().numpy()) @ scipy.linalg.cho_solve(c, Yt.cpu().numpy(), check_finite=False)
+    D = torch.cholesky_solve(A.T @ Yt, L) if m >= n else A.T @ torch.cholesky_solve(Yt, L)
     return D.cpu().numpy()
 
 
