@@ -114,7 +114,8 @@ typedef struct ssn_model_desc {
   int32_t block_steps;                /* timesteps per time-batched block; 0 = library default (256) */
   int32_t flags;                      /* debug / A-B switches: 1 = no fused recurrent-array core (generic programs),
                                          2 = no LIF fast path (unpacked state, dense row-major decoders),
-                                         4 = LIF fast path with dense decoders (no spike-sparse gather)           */
+                                         4 = LIF fast path with dense decoders (no spike-sparse gather),
+                                         8 = dense decoder products for dense ensembles (no k_spmv_partial)      */
 } ssn_model_desc;
 
 typedef struct ssn_counters {

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -65,9 +66,12 @@ struct Buf {
   int dec_K = 0, dec_dout = 0, dec_n = 0, dec_DP = 0;   // dec_DP > 0: stored [K][ld][DP] instead of [K*dout][ld]
   int packed = 0;                         // 1: holds packed LIF state words; 2: refractory view of buffer `partner`
   int partner = -1;
+  // spike-sparse decoders (k_spmv_partial): logical [rows][cols] stored neuron-major [cols][ldt]
+  bool transposed = false;
+  int64_t ldt = 0;
 };
 
-enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH };
+enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV };
 
 }  // namespace
 
@@ -123,6 +127,7 @@ struct Sim final : ssn_sim {
   int flags = 0;                              // ssn_model_desc.flags
   bool fused_core = false;                    // core == one recurrent ensemble array: [k_ensarray, k_ens_finish]
   std::vector<void*> fused_bufs;
+  std::set<int> sparse_w;                     // decoder buffers multiplied with a LIF spike vector
   std::vector<ssn::BatchOp<T>> pre_ops, post_ops;
   std::vector<ssn_range> pre_to_core, core_to_post;
   std::vector<unsigned char> batched_mask;    // signals owned by a batched stage (for ssn_read_signal)
@@ -223,6 +228,19 @@ struct Sim final : ssn_sim {
 
   // host [rows][cols] double -> device layout of buffer b
   int upload_buf(Buf& b, const double* src) {
+    if (b.transposed) {
+      T* tmp = nullptr;
+      HIPCHK(hipMalloc((void**)&tmp, (size_t)(b.rows * b.ld) * sizeof(T)));
+      int rc = upload(src, tmp, b.rows, b.cols, b.ld);
+      hipError_t e = hipSuccess;
+      if (rc == SSN_OK) e = hipMemsetAsync(b.d, 0, (size_t)(b.cols * b.ldt) * sizeof(T), stream);
+      if (rc == SSN_OK && e == hipSuccess) e = ssn::launch_transpose<T>(stream, tmp, (T*)b.d, (int)b.rows, (int)b.cols, (int)b.ld, (int)b.ldt);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      hipFree(tmp);
+      CHK(rc);
+      HIPCHK(e);
+      return SSN_OK;
+    }
     if (!b.dec_DP) return upload(src, (T*)b.d, b.rows, b.cols, b.ld);
     T* tmp = nullptr;
     HIPCHK(hipMalloc((void**)&tmp, (size_t)(b.rows * b.ld) * sizeof(T)));
@@ -237,6 +255,15 @@ struct Sim final : ssn_sim {
   }
 
   int download_buf(Buf& b, double* dst) {
+    if (b.transposed) {
+      T* tmp = nullptr;
+      HIPCHK(hipMalloc((void**)&tmp, (size_t)(b.rows * b.ld) * sizeof(T)));
+      hipError_t e = ssn::launch_transpose<T>(stream, (const T*)b.d, tmp, (int)b.cols, (int)b.rows, (int)b.ldt, (int)b.ld);
+      int rc = e == hipSuccess ? download(tmp, dst, b.rows, b.cols, b.ld) : SSN_OK;
+      hipFree(tmp);
+      HIPCHK(e);
+      return rc;
+    }
     if (!b.dec_DP && !b.packed) return download((const T*)b.d, dst, b.rows, b.cols, b.ld);
     T* tmp = nullptr;
     HIPCHK(hipMalloc((void**)&tmp, (size_t)(b.rows * b.ld) * sizeof(T)));
@@ -257,6 +284,7 @@ struct Sim final : ssn_sim {
   int shape(int id, int64_t rows, int64_t cols, bool pad, bool keep) {
     if (id < 0 || id >= (int)bufs.size()) return fail(SSN_EINVAL, "buffer id %d out of range", id);
     Buf& b = bufs[id];
+    if (sparse_w.count(id)) { b.transposed = true; b.ldt = (rows + VW - 1) / VW * VW; pad = true; }
     if (b.kind != SSN_BUF_REAL) return fail(SSN_EINVAL, "buffer %d is not a real buffer", id);
     if (rows * cols != b.count) return fail(SSN_EINVAL, "buffer %d has %lld elements, operator expects %lld x %lld",
                                             id, (long long)b.count, (long long)rows, (long long)cols);
@@ -299,6 +327,28 @@ struct Sim final : ssn_sim {
       bufs[i].kind = m->buffers[i].kind;
       bufs[i].cols = bufs[i].ld = bufs[i].count;
       if (!m->buffers[i].data && bufs[i].count) return fail(SSN_EINVAL, "buffer %d has no data", i);
+    }
+    // decoders applied to the spike vector of a dense LIF ensemble are kept neuron-major and multiplied sparsely
+    if (!(flags & 8))
+      for (int i = 0; i < m->n_ops; ++i) {
+        const ssn_op_desc& o = m->ops[i];
+        if (o.kind != SSN_OP_MATVEC || o.stage != 1 || is_micro(o) || o.i[3] < 128 || o.i[3] > 15000) continue;
+        for (int j = 0; j < m->n_ops; ++j) {
+          const ssn_op_desc& q = m->ops[j];
+          if (q.kind == SSN_OP_NEURONS && q.i[5] == SSN_LIF && q.i[1] == o.i[1] && q.i[2] == o.i[3]) sparse_w.insert((int)o.i[4]);
+        }
+      }
+    for (int i = 0; i < m->n_ops; ++i) {          // a buffer also used as a dense operand elsewhere stays dense
+      const ssn_op_desc& o = m->ops[i];
+      if (o.kind == SSN_OP_MATVEC && sparse_w.count((int)o.i[4])) {
+        bool ok = false;
+        for (int j = 0; j < m->n_ops; ++j) {
+          const ssn_op_desc& q = m->ops[j];
+          if (q.kind == SSN_OP_NEURONS && q.i[5] == SSN_LIF && q.i[1] == o.i[1] && q.i[2] == o.i[3] && o.stage == 1 && !is_micro(o)) ok = true;
+        }
+        if (!ok) sparse_w.erase((int)o.i[4]);
+      }
+      if ((o.kind == SSN_OP_VOJA || o.kind == SSN_OP_CLEANUP) && sparse_w.count((int)o.i[o.kind == SSN_OP_VOJA ? 0 : 4])) sparse_w.erase((int)o.i[o.kind == SSN_OP_VOJA ? 0 : 4]);
     }
     // pass 1: buffer layouts
     for (int i = 0; i < m->n_ops; ++i) {
@@ -374,7 +424,7 @@ struct Sim final : ssn_sim {
         CHK(dmalloc((int32_t**)&b.d, b.count * 4));
         HIPCHK(hipMemcpy(b.d, m->buffers[i].data, (size_t)b.count * 4, hipMemcpyHostToDevice));
       } else {
-        const int64_t elems = b.dec_DP ? (int64_t)b.dec_K * b.ld * b.dec_DP : b.rows * b.ld;
+        const int64_t elems = b.dec_DP ? (int64_t)b.dec_K * b.ld * b.dec_DP : (b.transposed ? b.cols * b.ldt : b.rows * b.ld);
         CHK(dmalloc((T**)&b.d, elems * (int64_t)sizeof(T)));
         CHK(upload_buf(b, (const double*)m->buffers[i].data));
         if (b.keep) b.host.assign((const double*)m->buffers[i].data, (const double*)m->buffers[i].data + b.count);
@@ -632,6 +682,20 @@ struct Sim final : ssn_sim {
             op.kind = o.i[5] ? ssn::M_MATVEC_SET : ssn::M_MATVEC_INC;
             op.dst = o.i[0]; op.src = o.i[1]; op.len = o.i[2]; op.i0 = o.i[3]; op.i1 = w.ld; op.p0 = w.d;
             push_micro(op, o.level, false);
+          } else if (w.transposed) {
+            // spike-sparse decoders: partial sums per spike-list chunk, reduced in the following program
+            flush();
+            const int chunks = 32;
+            const int rows_pad = (int)w.ldt;
+            T* partial = nullptr;
+            CHK(dmalloc(&partial, (int64_t)chunks * rows_pad * (int64_t)sizeof(T)));
+            scratch_bufs.push_back(partial);
+            Item it; it.type = IT_SPMV; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.dst = partial;
+            it.rows = (int)o.i[2]; it.cols = (int)o.i[3]; it.ld = (int)w.ldt; it.n = chunks;
+            items.push_back(it);
+            MOp r{};
+            r.kind = o.i[5] ? ssn::M_REDUCE_SET : ssn::M_REDUCE_INC; r.dst = o.i[0]; r.len = o.i[2]; r.i0 = chunks; r.i1 = rows_pad; r.p0 = partial;
+            push_micro(r, o.level, true);
           } else {
             flush();
             Item it; it.type = IT_MATVEC; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.dst = sig + o.i[0];
@@ -667,6 +731,9 @@ struct Sim final : ssn_sim {
           const Buf& w = bufs[o.i[0]];
           Item it; it.type = IT_PES; it.Wm = (T*)w.d; it.rows = (int)o.i[1]; it.cols = (int)o.i[2]; it.ld = (int)w.ld;
           it.aux0 = sig + o.i[3]; it.aux1 = sig + o.i[4]; it.scalar = (T)o.f[0];
+          if (w.transposed) {   // neuron-major weights: W^T[c][r] += kappa * act[c] * err[r]
+            it.rows = (int)o.i[2]; it.cols = (int)o.i[1]; it.ld = (int)w.ldt; it.aux0 = sig + o.i[4]; it.aux1 = sig + o.i[3];
+          }
           items.push_back(it);
           break;
         }
@@ -809,6 +876,7 @@ struct Sim final : ssn_sim {
       case IT_MATVEC: return ssn::launch_matvec<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set);
       case IT_MATVEC_ORDERED: return ssn::launch_matvec_ordered<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld);
       case IT_FINISH: return ssn::launch_ens_finish<T>(stream, it.fin);
+      case IT_SPMV: return ssn::launch_spmv_partial<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n);
       case IT_NEURONS: return ssn::launch_neurons<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar);
       case IT_PES: return ssn::launch_pes<T>(stream, it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar);
       case IT_VOJA: return ssn::launch_voja<T>(stream, it.Wm, it.src, it.aux0, it.aux1, it.aux2, it.rows, it.cols, it.ld, it.scalar);

@@ -475,6 +475,16 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
         for (long long i = tid; i < op.len; i += 1024) row[op.src + i] = sig[op.src + i];
         break;
       }
+      case M_REDUCE_SET:
+      case M_REDUCE_INC: {   // p0 = partial [i0 chunks][i1 rows_pad]: dst[r] (+)= sum_c partial[c][r], fixed order
+        const T* part = (const T*)op.p0;
+        for (long long r = tid; r < op.len; r += 1024) {
+          T s = T(0);
+          for (int c = 0; c < (int)op.i0; ++c) s += part[(size_t)c * op.i1 + r];
+          if (op.kind == M_REDUCE_INC) sig[op.dst + r] += s; else sig[op.dst + r] = s;
+        }
+        break;
+      }
       case M_STEP_END:
         step += 1;
         if (tid == 0) ctx->step = step;
@@ -528,6 +538,57 @@ __global__ __launch_bounds__(256) void k_matvec(const T* __restrict__ Wm, const 
 template <typename T>
 hipError_t launch_matvec(hipStream_t s, const T* Wm, const T* src, T* dst, int rows, int cols, int ld, int set) {
   hipLaunchKernelGGL((k_matvec<T>), dim3((rows + 3) / 4), dim3(256), 0, s, Wm, src, dst, rows, cols, ld, set);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_spmv_partial: y = W s for a SPARSE s (the spike vector of a LIF ensemble: ~5-10 % non-zero), with W
+// stored neuron-major, Wt[n][ldt] - one spiking neuron = one contiguous row of `rows` decoders.
+//   grid (column tiles of 256, chunks): every workgroup compacts the spike vector into LDS (ascending
+//   index order, blocked scan), takes its 1/chunks share of the spike list and accumulates its 256
+//   outputs; partial[chunk][r] is reduced in fixed order by the following program (deterministic).
+//   Traffic: (#spikes x rows) weights instead of (n x rows).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_spmv_partial(const T* __restrict__ Wt, int ldt, const T* __restrict__ spikes,
+                                                      int n, int rows, T* __restrict__ partial, int rows_pad, int chunks) {
+  extern __shared__ unsigned char smem[];
+  int* list = (int*)smem;                       // [n] compacted indices
+  __shared__ int counts[257];
+  const int tid = threadIdx.x;
+  const int per = (n + 255) / 256;
+  const int lo = min(n, tid * per), hi = min(n, lo + per);
+  int cnt = 0;
+  for (int i = lo; i < hi; ++i) cnt += spikes[i] != T(0);
+  counts[tid + 1] = cnt;
+  if (tid == 0) counts[0] = 0;
+  __syncthreads();
+  if (tid == 0) for (int t = 1; t <= 256; ++t) counts[t] += counts[t - 1];
+  __syncthreads();
+  int w = counts[tid];
+  for (int i = lo; i < hi; ++i) if (spikes[i] != T(0)) list[w++] = i;
+  __syncthreads();
+  const int m = counts[256];
+  const int c = blockIdx.y;
+  const int b = (int)((long long)m * c / chunks), e = (int)((long long)m * (c + 1) / chunks);
+  const int r = blockIdx.x * 256 + tid;
+  T acc = T(0);
+  if (r < rows) {
+    int i = b;
+    for (; i + 4 <= e; i += 4) {
+      const int j0 = list[i], j1 = list[i + 1], j2 = list[i + 2], j3 = list[i + 3];
+      const T w0 = Wt[(size_t)j0 * ldt + r], w1 = Wt[(size_t)j1 * ldt + r], w2 = Wt[(size_t)j2 * ldt + r], w3 = Wt[(size_t)j3 * ldt + r];
+      acc += spikes[j0] * w0; acc += spikes[j1] * w1; acc += spikes[j2] * w2; acc += spikes[j3] * w3;
+    }
+    for (; i < e; ++i) { const int j = list[i]; acc += spikes[j] * Wt[(size_t)j * ldt + r]; }
+    partial[(size_t)c * rows_pad + r] = acc;
+  }
+}
+
+template <typename T>
+hipError_t launch_spmv_partial(hipStream_t s, const T* Wt, int ldt, const T* spikes, int n, int rows, T* partial, int rows_pad, int chunks) {
+  hipLaunchKernelGGL((k_spmv_partial<T>), dim3((rows + 255) / 256, chunks), dim3(256), (size_t)n * sizeof(int), s,
+                     Wt, ldt, spikes, n, rows, partial, rows_pad, chunks);
   return hipGetLastError();
 }
 
@@ -789,6 +850,7 @@ hipError_t launch_convert_out(hipStream_t s, const T* src, double* dst, int64_t 
   template hipError_t launch_ens_finish<T>(hipStream_t, const FinishArgs<T>&);                               \
   template hipError_t launch_matvec<T>(hipStream_t, const T*, const T*, T*, int, int, int, int);            \
   template hipError_t launch_matvec_ordered<T>(hipStream_t, const T*, const T*, T*, int, int, int);         \
+  template hipError_t launch_spmv_partial<T>(hipStream_t, const T*, int, const T*, int, int, T*, int, int);  \
   template hipError_t launch_transpose<T>(hipStream_t, const T*, T*, int, int, int, int);                   \
   template hipError_t launch_neurons<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T); \
   template hipError_t launch_pes<T>(hipStream_t, T*, const T*, const T*, int, int, int, T);                 \

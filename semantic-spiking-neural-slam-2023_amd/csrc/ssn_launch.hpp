@@ -60,7 +60,7 @@ struct FinishArgs {
 
 enum MicroKind {
   M_FILL = 1, M_AXPY_INC, M_AXPY_SET, M_LOWPASS, M_TABLE, M_MATVEC_INC, M_MATVEC_SET, M_ENS_FINISH,
-  M_GATE, M_ARGMAX_GATHER, M_PROBE, M_STEP_END, M_ROW_IN, M_ROW_OUT
+  M_GATE, M_ARGMAX_GATHER, M_PROBE, M_STEP_END, M_ROW_IN, M_ROW_OUT, M_REDUCE_SET, M_REDUCE_INC
 };
 
 template <typename T>
@@ -116,6 +116,8 @@ template <typename T> hipError_t launch_program(hipStream_t, const MicroOp<T>*, 
 template <typename T> hipError_t launch_matvec(hipStream_t, const T* W, const T* src, T* dst, int rows, int cols, int ld, int set);
 template <typename T> hipError_t launch_matvec_ordered(hipStream_t, const T* Wt, const T* x, T* y, int rows, int cols, int ldt);
 template <typename T> hipError_t launch_transpose(hipStream_t, const T* src, T* dst, int rows, int cols, int ld, int ldt);
+template <typename T> hipError_t launch_spmv_partial(hipStream_t, const T* Wt, int ldt, const T* spikes, int n, int rows, T* partial,
+                                                     int rows_pad, int chunks);
 template <typename T> hipError_t launch_neurons(hipStream_t, const NeuronParams<T>&, const T* J, T* out, T* V, T* R, int n, T amp);
 template <typename T> hipError_t launch_pes(hipStream_t, T* W, const T* err, const T* act, int rows, int cols, int ld, T kappa);
 template <typename T> hipError_t launch_voja(hipStream_t, T* E, const T* spk, const T* key, const T* learn, const T* scale,
