@@ -115,7 +115,9 @@ typedef struct ssn_model_desc {
   int32_t flags;                      /* debug / A-B switches: 1 = no fused recurrent-array core (generic programs),
                                          2 = no LIF fast path (unpacked state, dense row-major decoders),
                                          4 = LIF fast path with dense decoders (no spike-sparse gather),
-                                         8 = dense decoder products for dense ensembles (no k_spmv_partial)      */
+                                         8 = dense decoder products for dense ensembles (no k_spmv_partial),
+                                         16 = fused recurrent-array core always with a separate finish kernel,
+                                         (default: finish deferred into the next step's prologue, 1 launch per step) */
 } ssn_model_desc;
 
 typedef struct ssn_counters {

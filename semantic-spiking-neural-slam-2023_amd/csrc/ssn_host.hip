@@ -126,6 +126,8 @@ struct Sim final : ssn_sim {
   bool core_empty = false;                    // no per-timestep work at all
   int flags = 0;                              // ssn_model_desc.flags
   bool fused_core = false;                    // core == one recurrent ensemble array: [k_ensarray, k_ens_finish]
+  bool fused_defer = false;                   // ... with the finish deferred into the next step's prologue: [k_ensarray]
+  ssn::FinishArgs<T> fin_begin, fin_flush;
   std::vector<void*> fused_bufs;
   std::set<int> sparse_w;                     // decoder buffers multiplied with a LIF spike vector
   std::vector<ssn::BatchOp<T>> pre_ops, post_ops;
@@ -500,6 +502,7 @@ struct Sim final : ssn_sim {
     a.np = neuron_params(o.i[11], o.f);
     a.xrows = nullptr; a.n_sig = n_sig; a.ctx = d_ctx; a.n_rec = 0;
     a.fast = ens_fast(o) ? (ens_sparse(o) ? 1 : 2) : 0;
+    a.defer = 0; a.sub = 0; a.partials_stride = 0;
     ens_chunking(a);
   }
 
@@ -560,17 +563,55 @@ struct Sim final : ssn_sim {
         const int row = row_of[(size_t)e];
         if (row >= 0) rowout[(size_t)row] = 1;      // (elements no local row writes stay at their initial value)
       }
+    // ---- can the finish be deferred into the next step's prologue?  every recurrent term must read a
+    //      filter state owned by a row of the SAME ensemble (ens_k -> Lowpass -> ens_k), one term per input
+    bool defer = !(flags & 16);        // decided below: only worth it in the latency-bound regime (few workgroups)
+    std::vector<int> xrow((size_t)(K * din), -1), lp_has((size_t)(K * dout), 0);
+    std::vector<double> xalpha((size_t)(K * din), 0.0);
+    {
+      std::vector<int> owner((size_t)n_sig, -1);
+      for (int64_t j = 0; j < K * dout; ++j)
+        if (lp_state[(size_t)j] >= 0) { owner[(size_t)lp_state[(size_t)j]] = (int)j; lp_has[(size_t)j] = 1; }
+      // filter states whose input no row writes (dropped all-zero decoder rows, other ranks' VCOs) stay 0
+      std::vector<unsigned char> dead_zero((size_t)n_sig, 0);
+      for (int i : lows) {
+        const ssn_op_desc& o = m->ops[i];
+        for (int64_t e = 0; e < o.i[2]; ++e) {
+          const int64_t st = o.i[0] + e, src = o.i[1] + e;
+          if (row_of[(size_t)src] < 0 && sig_init[(size_t)st] == 0.0 && sig_init[(size_t)src] == 0.0 &&
+              !inside(src, src + 1, pre_to_core)) dead_zero[(size_t)st] = 1;
+        }
+      }
+      for (int i : axpys) {
+        const ssn_op_desc& o = m->ops[i];
+        for (int64_t e = 0; e < K * din && defer; ++e) {
+          const int64_t xi = x0 + e;
+          if (xi < o.i[0] || xi >= o.i[0] + o.i[2]) continue;
+          const int64_t st = o.i[1] + (xi - o.i[0]);
+          const int row = owner[(size_t)st];
+          if (row < 0 && dead_zero[(size_t)st]) continue;               // adds exactly 0
+          if (row < 0 || row / dout != e / din || xrow[(size_t)e] >= 0) defer = false;
+          else { xrow[(size_t)e] = (int)(row % dout); xalpha[(size_t)e] = o.f[0]; }
+        }
+      }
+    }
     // ---- plan: [k_ensarray (fused prologue), k_ens_finish] -------------------------------------------
     Item it; it.type = IT_ENS;
     fill_ens_args(eo, it.ens);
     ssn::EnsArgs<T>& a = it.ens;
     a.xrows = bsig;
+    // measured on MI355X (tools/bench_shard.py): 5080 workgroups (config 2 on one GPU) 35.4 us/step with the
+    // separate finish kernel vs 37.4 deferred; 2540 / 1270 / 640 workgroups (2 / 4 / 8-GPU shards) 24.5 / 15.8 /
+    // 13.1 vs 22.0 / 12.5 / 9.4 deferred
+    // (one process, full size: 36.6 us/step deferred vs 37.4 with the finish kernel -> deferred whenever it applies)
     for (int i : axpys) {
       const ssn_op_desc& o = m->ops[i];
       a.rec_dst[a.n_rec] = o.i[0]; a.rec_src[a.n_rec] = o.i[1]; a.rec_len[a.n_rec] = o.i[2]; a.rec_alpha[a.n_rec] = (T)o.f[0];
       ++a.n_rec;
     }
-    if ((*rc = dmalloc(&a.partials, (int64_t)a.K * a.P * a.dout * (int64_t)sizeof(T))) != SSN_OK) return true;
+    a.partials_stride = (int64_t)a.K * a.P * a.dout;
+    if ((*rc = dmalloc(&a.partials, 2 * a.partials_stride * (int64_t)sizeof(T))) != SSN_OK) return true;
+    hipMemset(a.partials, 0, (size_t)(2 * a.partials_stride) * sizeof(T));
     it.dominant = true;
     dom_units = (int64_t)a.K * a.n;
     dom_bytes = (double)dom_units * (a.din + a.dout + 5) * sizeof(T);
@@ -593,6 +634,27 @@ struct Sim final : ssn_sim {
     f.partials = a.partials; f.didx = (const int*)bufs[eo.i[8]].d; f.lp_state = d_lp; f.lp_a = d_a; f.lp_b = d_b;
     f.rowout = d_ro; f.sig = sig; f.bsig = bsig; f.n_sig = n_sig; f.ctx = d_ctx; f.ticket = d_ticket;
     f.K = a.K; f.P = a.P; f.dout = a.dout; f.n_blocks = (int)((nr + 255) / 256);
+    f.mode = 0; f.fstate = nullptr; f.partials_stride = a.partials_stride; f.lp_has = nullptr;
+    if (defer) {
+      int* d_has = nullptr; int* d_xrow = nullptr; T* d_xalpha = nullptr; T* d_fstate = nullptr;
+      if ((*rc = dmalloc(&d_has, nr * 4)) != SSN_OK) return true;
+      if ((*rc = dmalloc(&d_xrow, (int64_t)K * din * 4)) != SSN_OK) return true;
+      if ((*rc = dmalloc(&d_xalpha, (int64_t)K * din * (int64_t)sizeof(T))) != SSN_OK) return true;
+      if ((*rc = dmalloc(&d_fstate, 2 * nr * (int64_t)sizeof(T))) != SSN_OK) return true;
+      fused_bufs.insert(fused_bufs.end(), {(void*)d_has, (void*)d_xrow, (void*)d_xalpha, (void*)d_fstate});
+      hipMemcpy(d_has, lp_has.data(), (size_t)nr * 4, hipMemcpyHostToDevice);
+      hipMemcpy(d_xrow, xrow.data(), (size_t)(K * din) * 4, hipMemcpyHostToDevice);
+      hipMemset(d_fstate, 0, (size_t)(2 * nr) * sizeof(T));
+      if ((*rc = upload(xalpha.data(), d_xalpha, 1, K * din, K * din)) != SSN_OK) return true;
+      a.defer = 1; a.sub = 0; a.didx = f.didx; a.lp_has = d_has; a.lp_a = d_a; a.lp_b = d_b; a.fstate = d_fstate;
+      a.xrow = d_xrow; a.xalpha = d_xalpha; a.rowout = d_ro; a.bsig = bsig; a.sig_w = sig;
+      f.fstate = d_fstate; f.lp_has = d_has;
+      fin_flush = f; fin_flush.mode = 1;
+      fin_begin = f; fin_begin.mode = 2;
+      items.push_back(it);
+      fused_core = fused_defer = true;
+      return true;
+    }
     items.push_back(it);
     items.push_back(fi);
     fused_core = true;
@@ -835,6 +897,7 @@ struct Sim final : ssn_sim {
     CHK(dmalloc(&d_mops, (int64_t)mops.size() * (int64_t)sizeof(MOp)));
     HIPCHK(hipMemcpy(d_mops, mops.data(), mops.size() * sizeof(MOp), hipMemcpyHostToDevice));
     launches_per_step = (int)items.size() - (can_fuse ? 1 : 0);
+    if (fused_defer) launches_per_step = 1;
     int n_core_ops = 0;
     for (int i = 0; i < m->n_ops; ++i) n_core_ops += m->ops[i].stage == 1;
     bool core_probe = false;
@@ -886,6 +949,16 @@ struct Sim final : ssn_sim {
 
   // `count` consecutive steps; fused = tail(s)+head(s+1) in one launch
   hipError_t launch_steps(int count, bool fused) {
+    if (fused_defer) {                          // one k_ensarray per timestep; the clock advances once for the group
+      for (int s = 0; s < count; ++s) {
+        items[0].ens.sub = s;
+        hipError_t e = launch_item(items[0], nullptr, nullptr);
+        if (e != hipSuccess) return e;
+      }
+      items[0].ens.sub = 0;
+      hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, (long long)count);
+      return hipGetLastError();
+    }
     const int n_items = (int)items.size();
     for (int s = 0; s < count; ++s) {
       for (int i = 0; i < n_items; ++i) {
@@ -940,22 +1013,26 @@ struct Sim final : ssn_sim {
         HIPCHK(hipGetLastError());
         HIPCHK(run_batch(pre_ops, (int)B, step0));
       }
+      if (fused_defer) HIPCHK(ssn::launch_ens_finish<T>(stream, fin_begin));
       if (core_empty) {
         // nothing is stepped one timestep at a time (purely feed-forward model): just advance the clock
         hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, (long long)B);
         HIPCHK(hipGetLastError());
       } else if (profile) {
-        for (int64_t s = 0; s < B; ++s)
+        for (int64_t s = 0; s < B; ++s) {
           for (auto& it : items) {
             if (it.dominant) { HIPCHK(launch_item(it, ev_pool[ev_used], ev_pool[ev_used + 1])); ev_used += 2; }
             else HIPCHK(launch_item(it, nullptr, nullptr));
           }
+          if (fused_defer) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, 1LL); HIPCHK(hipGetLastError()); }
+        }
       } else {
         int64_t left = B;
         if (graph_exec)
           for (; left >= steps_per_graph; left -= steps_per_graph) HIPCHK(hipGraphLaunch(graph_exec, stream));
         if (left > 0) HIPCHK(launch_steps((int)left, true));
       }
+      if (fused_defer) HIPCHK(ssn::launch_ens_finish<T>(stream, fin_flush));
       if (bsig) {
         HIPCHK(run_batch(post_ops, (int)B, step0));
         HIPCHK(hipMemcpyAsync(bsig, bsig + (size_t)B * n_sig, (size_t)n_sig * sizeof(T), hipMemcpyDeviceToDevice, stream));

@@ -154,9 +154,11 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
   if (v < v_end) load_sweep(v);
 
   T x[DIN];
-  {
+  long long step = 0;
+  if (a.xrows || a.defer) step = a.ctx->step + a.sub;
+  if (!a.defer) {
     const T* xsrc = a.sig;
-    if (a.xrows) xsrc = a.xrows + (size_t)(a.ctx->step - a.ctx->block_start + 1) * a.n_sig;
+    if (a.xrows) xsrc = a.xrows + (size_t)(step - a.ctx->block_start + 1) * a.n_sig;
 #pragma unroll
     for (int d = 0; d < DIN; ++d) {
       const long long xi = a.x_off + (long long)k * DIN + d;
@@ -165,6 +167,50 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
         if (xi >= a.rec_dst[j] && xi < a.rec_dst[j] + a.rec_len[j]) xv += a.rec_alpha[j] * a.sig[a.rec_src[j] + (xi - a.rec_dst[j])];
       x[d] = xv;
     }
+  } else {
+    // Deferred finish.  A handful of lanes do the scalar work and broadcast through LDS:
+    //  * lane d < DIN: this step's input x[d] = pre-stage row + alpha * (filter state after step-1), where
+    //    that state is completed here from step-1's partial sums if it is still pending;
+    //  * workgroup p == 0, lanes 64 + r (r < DOUT): publish step-1's decoded row r (signal, filter state,
+    //    hand-off to the post stage).  Every workgroup of an ensemble derives identical values from
+    //    identical inputs, so nothing else needs to wait for the publisher.
+    __shared__ T s_x[DIN];
+    const int par = (int)(step & 1);
+    const long long NR = (long long)a.K * DOUT;
+    const bool pending = (step - 1) > a.ctx->finished;
+    const T* prev = a.partials + (size_t)(par ^ 1) * a.partials_stride + (size_t)k * a.P * DOUT;
+    const int tid = threadIdx.x;
+    if (tid < DIN) {
+      const long long e = (long long)k * DIN + tid;
+      const T* xsrc = a.xrows + (size_t)(step - a.ctx->block_start + 1) * a.n_sig;
+      T xv = xsrc[a.x_off + e];
+      const int xr = a.xrow[e];
+      if (xr >= 0) {
+        const long long i = (long long)k * DOUT + xr;
+        T st;
+        if (pending) {
+          T v = T(0);
+          for (int q = 0; q < a.P; ++q) v += prev[(size_t)q * DOUT + xr];
+          st = a.lp_a[i] * a.fstate[(size_t)par * NR + i] + a.lp_b[i] * v;
+        } else {
+          st = a.fstate[(size_t)(par ^ 1) * NR + i];
+        }
+        xv += a.xalpha[e] * st;
+      }
+      s_x[tid] = xv;
+    } else if (p == 0 && pending && tid >= 64 && tid < 64 + DOUT) {
+      const int r = tid - 64;
+      const long long i = (long long)k * DOUT + r;
+      T v = T(0);
+      for (int q = 0; q < a.P; ++q) v += prev[(size_t)q * DOUT + r];
+      const int dst = a.didx[i];
+      a.sig_w[dst] = v;
+      if (a.lp_has[i]) a.fstate[(size_t)(par ^ 1) * NR + i] = a.lp_a[i] * a.fstate[(size_t)par * NR + i] + a.lp_b[i] * v;
+      if (a.rowout[i]) a.bsig[(size_t)(step - a.ctx->block_start) * a.n_sig + dst] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < DIN; ++d) x[d] = s_x[d];
   }
 
   T acc[DOUT];
@@ -256,7 +302,8 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
   __syncthreads();
   if (threadIdx.x < DOUT) {
     const int r = threadIdx.x;
-    a.partials[((size_t)k * a.P + p) * DOUT + r] = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+    T* out = a.partials + (a.defer ? (size_t)(step & 1) * a.partials_stride : (size_t)0);
+    out[((size_t)k * a.P + p) * DOUT + r] = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
   }
 }
 
@@ -295,22 +342,35 @@ hipError_t launch_state_unpack(hipStream_t s, const T* src, T* out, int64_t n, i
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_ens_finish(FinishArgs<T> f) {
-  const long long step = f.ctx->step;
+  const long long step = f.ctx->step;           // mode 0: step being finished; modes 1, 2: first step not yet run
   const int i = blockIdx.x * 256 + threadIdx.x;
+  const long long NR = (long long)f.K * f.dout;
   if (i < f.K * f.dout) {
-    const int k = i / f.dout, r = i - k * f.dout;
-    T s = T(0);
-    for (int p = 0; p < f.P; ++p) s += f.partials[((size_t)k * f.P + p) * f.dout + r];
-    const int dst = f.didx[i];
-    f.sig[dst] = s;
     const int st = f.lp_state[i];
-    if (st >= 0) f.sig[st] = f.lp_a[i] * f.sig[st] + f.lp_b[i] * s;
-    if (f.rowout[i]) f.bsig[(size_t)(step - f.ctx->block_start + 1) * f.n_sig + dst] = s;
+    if (f.mode == 2) {                           // begin: filter states of step-1 from the signal vector
+      f.fstate[(size_t)((step - 1) & 1) * NR + i] = st >= 0 ? f.sig[st] : T(0);
+    } else {
+      const long long t = f.mode == 1 ? step - 1 : step;        // the step whose results are completed here
+      const int k = i / f.dout, r = i - k * f.dout;
+      const T* part = f.partials + (f.mode == 1 ? (size_t)(t & 1) * f.partials_stride : (size_t)0);
+      T s = T(0);
+      for (int p = 0; p < f.P; ++p) s += part[((size_t)k * f.P + p) * f.dout + r];
+      const int dst = f.didx[i];
+      f.sig[dst] = s;
+      if (st >= 0) {
+        if (f.mode == 1) f.sig[st] = f.lp_a[i] * f.fstate[(size_t)((t - 1) & 1) * NR + i] + f.lp_b[i] * s;
+        else f.sig[st] = f.lp_a[i] * f.sig[st] + f.lp_b[i] * s;
+      }
+      if (f.rowout[i]) f.bsig[(size_t)(t - f.ctx->block_start + 1) * f.n_sig + dst] = s;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned int old = atomicAdd(f.ticket, 1u);
-    if (old % (unsigned)f.n_blocks == (unsigned)f.n_blocks - 1u) f.ctx->step = step + 1;   // every block has read `step`
+    if (old % (unsigned)f.n_blocks == (unsigned)f.n_blocks - 1u) {       // every block has read `step`
+      if (f.mode == 0) f.ctx->step = step + 1;
+      else f.ctx->finished = step - 1;
+    }
   }
 }
 

@@ -37,6 +37,22 @@ struct EnsArgs {
   long long rec_dst[4], rec_src[4], rec_len[4];
   T rec_alpha[4];
   int fast;            // LIF fast variant: packed state word (+ neuron-major spike-sparse decoders if dout >= 3)
+  // deferred finish (one launch per timestep): the prologue of step t completes step t-1 for its own
+  // ensemble - sums the previous partials, updates the recurrent filter states, hands results on - and
+  // the partials / filter states ping-pong between two buffers by step parity.
+  int defer;
+  int sub;                         // step offset of this launch inside a captured graph (step = ctx->step + sub)
+  long long partials_stride;       // elements between the two partial buffers
+  const int* didx;                 // [K*dout] destination signal per row
+  const int* lp_has;               // [K*dout] 1: row feeds a lowpass filter state
+  const T* lp_a;                   // [K*dout]
+  const T* lp_b;                   // [K*dout]
+  T* fstate;                       // [2][K*dout] filter states, index parity = step parity
+  const int* xrow;                 // [K*din] row (0..dout-1) of the same ensemble whose filter state feeds this input, or -1
+  const T* xalpha;                 // [K*din]
+  const unsigned char* rowout;     // [K*dout] 1: decoded value also goes to the post stage's block row
+  T* bsig;
+  T* sig_w;
 };
 
 // Finish of a fused recurrent ensemble array: one thread per decoded row (k, r):
@@ -56,6 +72,12 @@ struct FinishArgs {
   StepCtx* ctx;
   unsigned int* ticket;
   int K, P, dout, n_blocks;
+  // deferred-finish cores: mode 0 = classic finish of this step; 1 = flush (finish the block's last step from
+  // the ping-pong buffers, publish filter states to the signal vector); 2 = begin (load filter states)
+  int mode;
+  T* fstate;
+  long long partials_stride;
+  const int* lp_has;
 };
 
 enum MicroKind {
@@ -90,6 +112,7 @@ struct StepCtx {
   int probe_overflow;
   int pad;
   long long block_start; // step number at which the current time-batched block began
+  long long finished;    // deferred-finish cores: last step whose finish has been applied
 };
 
 // One operator of a time-batched stage, executed for rows t = 0..B-1 of the block.  Row r of the block

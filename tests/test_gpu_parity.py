@@ -264,13 +264,15 @@ def test_fused_recurrent_core_equals_generic_path(Simulator):
     pm = small_pathint(ssp_dim=55, n=2500, T=10.0, limit=0.2)
     model = build(pm.model, n_eval_points=600)
     outs = []
-    for flags in (0, 1):
+    for flags in (32, 1, 16):     # deferred finish (1 launch/step) | generic programs | fused with separate finish kernel
         with Simulator(None, model=model, dtype="f64", flags=flags, block_steps=96) as sim:
-            sim.run_steps(300)
+            sim.run_steps(150)
+            sim.run_steps(150)        # block boundaries, eager remainders and a second call: flush/begin paths
             outs.append(sim.data[pm.probe])
             outs.append(sim.counters()["launches_per_step"])
-    assert outs[1] == 2 and outs[3] == 2
+    assert outs[1] == 1 and outs[3] == 2 and outs[5] == 2
     np.testing.assert_array_equal(outs[0], outs[2])
+    np.testing.assert_array_equal(outs[0], outs[4])
     # LIF fast path (packed state word, spike-sparse neuron-major decoders) vs the generic kernel: same bits
     with Simulator(None, model=model, dtype="f64", flags=2, block_steps=96) as sim:
         sim.run_steps(300)
