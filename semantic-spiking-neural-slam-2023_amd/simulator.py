@@ -193,6 +193,7 @@ class Simulator:
         for key in self._probe_index:
             self._chunks[key] = []
         self.data = SimulationData(self)
+        self._fetched = {}
         self._prepared_until = 0
         self.n_steps = 0
 
@@ -242,6 +243,7 @@ class Simulator:
             self._check(self._lib.ssn_set_table(self._h, tid, rows.ctypes.data, rows.shape[0], tb["width"],
                                                 idx.ctypes.data, idx.size, first))
         self._check(self._lib.ssn_reserve_probes(self._h, n_steps))
+        self._fetched = {}               # sample counts restart with the new reservation
         self._prepared_until = first + n_steps
 
     def set_table_device(self, table_id, rows_dev_ptr, n_rows, idx, first_step):
@@ -289,24 +291,19 @@ class Simulator:
         return b
 
     def _collect(self):
+        """Fetch the probe samples produced since the last fetch (incremental within a reservation)."""
         self._uncollected = False
-        # samples of the current reservation are re-read in full and replace its previous chunk
         for key, (kind, j, p) in self._probe_index.items():
             if kind != "sig":
                 continue
             n = int(self._lib.ssn_probe_count(self._h, j))
-            out = np.empty((n, p["width"]), dtype=np.float64)
-            if n:
-                self._check(self._lib.ssn_read_probe(self._h, j, out.ctypes.data, 0, n))
-            tag = self._reservation_tag()
-            chunks = self._chunks[key]
-            if chunks and isinstance(chunks[-1], tuple) and chunks[-1][0] == tag:
-                chunks[-1] = (tag, out)
-            else:
-                chunks.append((tag, out))
-
-    def _reservation_tag(self):
-        return self._prepared_until
+            have = self._fetched.get(key, 0)
+            if n <= have:
+                continue
+            out = np.empty((n - have, p["width"]), dtype=np.float64)
+            self._check(self._lib.ssn_read_probe(self._h, j, out.ctypes.data, have, n - have))
+            self._chunks[key].append(out)
+            self._fetched[key] = n
 
     def _probe_array(self, key):
         kind, j, p = self._probe_index[key]
@@ -367,3 +364,4 @@ class Simulator:
         self._prepared_until = 0
         for k in self._chunks:
             self._chunks[k] = []
+        self._fetched = {}
