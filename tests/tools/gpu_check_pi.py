@@ -1,7 +1,7 @@
 """GPU bring-up check: PathIntegration on the HIP backend vs the oracle (f64 tight, f32 loose).
 usage: gpu_check_pi.py ssp_dim n_per_vco steps [n_eval_points] [oracle_steps]"""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from sspslam_amd import harness as H
 from sspslam_amd.builder import build

@@ -1,6 +1,6 @@
 """SLAMNetwork on the HIP backend vs the oracle.  usage: gpu_check_slam.py ssp_dim pi_n mem_n circonv_n steps oracle_steps [n_eval]"""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from collections import Counter
 from sspslam_amd import harness as H

@@ -1,7 +1,7 @@
 """Step the oracle and the HIP backend side by side and report the first signal ranges that diverge,
 with the operator that writes them.  usage: gpu_debug_compare.py [steps]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from sspslam_amd import harness as H
 from sspslam_amd.builder import build, op_access
