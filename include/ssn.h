@@ -117,7 +117,11 @@ typedef struct ssn_model_desc {
                                          4 = LIF fast path with dense decoders (no spike-sparse gather),
                                          8 = dense decoder products for dense ensembles (no k_spmv_partial),
                                          16 = fused recurrent-array core always with a separate finish kernel,
-                                         (default: finish deferred into the next step's prologue, 1 launch per step) */
+                                         (default: finish deferred into the next step's prologue, 1 launch per step),
+                                         32 = single-workgroup neuron kernel that also emits the spike list for
+                                              k_spmv_partial (experiment, measured 2 % slower on SLAM config 3),
+                                         64 = programs stage their signal ranges through LDS (experiment, measured
+                                              5 % slower on SLAM config 3 than operating on global memory)          */
 } ssn_model_desc;
 
 typedef struct ssn_counters {

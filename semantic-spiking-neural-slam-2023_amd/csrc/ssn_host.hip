@@ -71,7 +71,7 @@ struct Buf {
   int64_t ldt = 0;
 };
 
-enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV };
+enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_NEURONS_COMPACT };
 
 }  // namespace
 
@@ -109,6 +109,7 @@ struct Sim final : ssn_sim {
     int rows = 0, cols = 0, ld = 0, set = 0, n = 0;
     T scalar = 0;
     ssn::NeuronParams<T> np;
+    int* list = nullptr; int* count = nullptr;     // spike list (k_neurons_compact -> k_spmv_partial)
   };
 
   int device = 0;
@@ -130,11 +131,19 @@ struct Sim final : ssn_sim {
   ssn::FinishArgs<T> fin_begin, fin_flush;
   std::vector<void*> fused_bufs;
   std::set<int> sparse_w;                     // decoder buffers multiplied with a LIF spike vector
+  std::vector<std::pair<int64_t, std::pair<int*, int*>>> spike_lists;   // spike signal offset -> (list, count)
   std::vector<ssn::BatchOp<T>> pre_ops, post_ops;
   std::vector<ssn_range> pre_to_core, core_to_post;
   std::vector<unsigned char> batched_mask;    // signals owned by a batched stage (for ssn_read_signal)
   std::vector<MOp> mops;                     // [head][middle programs...][tail][head copy]
   MOp* d_mops = nullptr;
+  std::vector<ssn::ProgDesc> prog_descs;     // one per program (+ a copy of the head behind the tail)
+  std::vector<ssn::ProgSeg> prog_segs;
+  std::vector<int> prog_lds;                 // dynamic LDS bytes per program launch
+  ssn::ProgDesc* d_progs = nullptr;
+  ssn::ProgSeg* d_segs = nullptr;
+  static constexpr int LDS_CAP = 128 * 1024;
+  std::vector<std::pair<const void*, std::pair<const int32_t*, int64_t>>> host_idx;   // device idx ptr -> host copy
   int head_begin = 0, head_count = 0, tail_begin = 0, tail_count = 0;
   bool can_fuse = false;
   ssn::StepCtx* d_ctx = nullptr;
@@ -180,6 +189,8 @@ struct Sim final : ssn_sim {
     if (sig) hipFree(sig);
     if (bsig) hipFree(bsig);
     if (d_mops) hipFree(d_mops);
+    if (d_progs) hipFree(d_progs);
+    if (d_segs) hipFree(d_segs);
     if (d_ctx) hipFree(d_ctx);
     if (d_tables) hipFree(d_tables);
     if (d_pslots) hipFree(d_pslots);
@@ -662,6 +673,83 @@ struct Sim final : ssn_sim {
     return true;
   }
 
+  // LDS staging plan of one program: collect the signal ranges its operators touch, lay them out in LDS,
+  // translate the operators' offsets.  Leaves the program in global-memory mode (no segments) when the ranges
+  // do not fit or there is nothing to gain.
+  int stage_program(std::vector<MOp>& ops, std::vector<ssn::ProgSeg>& segs_out, int* lds_bytes) {
+    *lds_bytes = 0;
+    if (!(flags & 64)) return SSN_OK;   // measured slower than global-memory programs on SLAM config 3: opt-in
+    struct Rg { int64_t lo, hi; bool w; };
+    std::vector<Rg> rs;
+    int levels = 0;
+    for (auto& op : ops) {
+      levels += op.barrier ? 1 : 0;
+      switch (op.kind) {
+        case ssn::M_FILL: case ssn::M_TABLE: case ssn::M_ARGMAX_GATHER: case ssn::M_REDUCE_SET: case ssn::M_REDUCE_INC: case ssn::M_ROW_IN:
+          rs.push_back({op.dst, op.dst + op.len, true}); break;
+        case ssn::M_AXPY_INC: case ssn::M_AXPY_SET: case ssn::M_LOWPASS:
+          rs.push_back({op.dst, op.dst + op.len, true}); rs.push_back({op.src, op.src + op.len, false}); break;
+        case ssn::M_MATVEC_INC: case ssn::M_MATVEC_SET:
+          rs.push_back({op.dst, op.dst + op.len, true}); rs.push_back({op.src, op.src + op.i0, false}); break;
+        case ssn::M_GATE:
+          rs.push_back({op.dst, op.dst + op.len, true}); rs.push_back({op.src, op.src + 2 * op.len + 1, false}); break;
+        case ssn::M_PROBE: case ssn::M_ROW_OUT:
+          rs.push_back({op.src, op.src + op.len, false}); break;
+        case ssn::M_ENS_FINISH: {
+          const int32_t* hi = nullptr; int64_t n = 0;
+          for (auto& h : host_idx) if (h.first == op.p1) { hi = h.second.first; n = h.second.second; }
+          if (!hi) return SSN_OK;
+          for (int64_t j = 0; j < n; ++j) rs.push_back({hi[j], (int64_t)hi[j] + 1, true});
+          break;
+        }
+        default: break;
+      }
+    }
+    if (rs.empty() || ops.size() < 3 || levels < 1) return SSN_OK;
+    std::sort(rs.begin(), rs.end(), [](const Rg& a, const Rg& b) { return a.lo < b.lo; });
+    std::vector<Rg> mg;
+    for (auto& r : rs) {
+      if (!mg.empty() && r.lo <= mg.back().hi) { mg.back().hi = std::max(mg.back().hi, r.hi); mg.back().w = mg.back().w || r.w; }
+      else mg.push_back(r);
+    }
+    int64_t total = 0;
+    std::vector<int64_t> loff(mg.size());
+    for (size_t i = 0; i < mg.size(); ++i) { loff[i] = total; total += (mg[i].hi - mg[i].lo + 3) / 4 * 4; }
+    if (total * (int64_t)sizeof(T) > LDS_CAP - 1024 || mg.size() > 4096) return SSN_OK;
+    auto tr = [&](int64_t off) -> int64_t {
+      size_t lo = 0, hi = mg.size();
+      while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (mg[mid].lo <= off) lo = mid; else hi = mid; }
+      return loff[lo] + (off - mg[lo].lo);
+    };
+    for (auto& op : ops) {
+      switch (op.kind) {
+        case ssn::M_FILL: case ssn::M_TABLE: case ssn::M_ARGMAX_GATHER: case ssn::M_REDUCE_SET: case ssn::M_REDUCE_INC: case ssn::M_ROW_IN:
+          op.dst = tr(op.dst); break;
+        case ssn::M_AXPY_INC: case ssn::M_AXPY_SET: case ssn::M_LOWPASS: case ssn::M_MATVEC_INC: case ssn::M_MATVEC_SET: case ssn::M_GATE:
+          op.dst = tr(op.dst); op.src = tr(op.src); break;
+        case ssn::M_PROBE: case ssn::M_ROW_OUT:
+          op.src = tr(op.src); break;
+        case ssn::M_ENS_FINISH: {
+          const int32_t* hi = nullptr; int64_t n = 0;
+          for (auto& h : host_idx) if (h.first == op.p1) { hi = h.second.first; n = h.second.second; }
+          std::vector<int32_t> t((size_t)n);
+          for (int64_t j = 0; j < n; ++j) t[(size_t)j] = (int32_t)tr(hi[j]);
+          int32_t* d = nullptr;
+          CHK(dmalloc(&d, n * 4));
+          scratch_bufs.push_back(d);
+          HIPCHK(hipMemcpy(d, t.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+          op.p1 = d;
+          break;
+        }
+        default: break;
+      }
+    }
+    for (size_t i = 0; i < mg.size(); ++i)
+      segs_out.push_back(ssn::ProgSeg{mg[i].lo, (int)loff[i], (int)(mg[i].hi - mg[i].lo), mg[i].w ? 1 : 0, 0});
+    *lds_bytes = (int)(total * (int64_t)sizeof(T));
+    return SSN_OK;
+  }
+
   int plan(const ssn_model_desc* m) {
     int frc = SSN_OK;
     const bool fused = !(flags & 1) && try_fused_core(m, &frc);
@@ -692,7 +780,7 @@ struct Sim final : ssn_sim {
     for (auto& r : pre_to_core) {        // the pre stage's results for this timestep
       if (fused) break;
       MOp op{};
-      op.kind = ssn::M_ROW_IN; op.dst = r.lo; op.len = r.hi - r.lo; op.p0 = bsig; op.i0 = n_sig;
+      op.kind = ssn::M_ROW_IN; op.dst = r.lo; op.len = r.hi - r.lo; op.p0 = bsig; op.i0 = n_sig; op.i1 = r.lo;
       push_micro(op, -10, false);
     }
     std::vector<std::pair<int, ssn::BatchOp<T>>> pre_sorted, post_sorted;
@@ -754,6 +842,7 @@ struct Sim final : ssn_sim {
             scratch_bufs.push_back(partial);
             Item it; it.type = IT_SPMV; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.dst = partial;
             it.rows = (int)o.i[2]; it.cols = (int)o.i[3]; it.ld = (int)w.ldt; it.n = chunks;
+            for (auto& sl : spike_lists) if (sl.first == o.i[1]) { it.list = sl.second.first; it.count = sl.second.second; }
             items.push_back(it);
             MOp r{};
             r.kind = o.i[5] ? ssn::M_REDUCE_SET : ssn::M_REDUCE_INC; r.dst = o.i[0]; r.len = o.i[2]; r.i0 = chunks; r.i1 = rows_pad; r.p0 = partial;
@@ -778,6 +867,7 @@ struct Sim final : ssn_sim {
           MOp f{};
           f.kind = ssn::M_ENS_FINISH; f.len = (int64_t)a.K * a.dout; f.i0 = a.P; f.i1 = a.dout;
           f.p0 = a.partials; f.p1 = bufs[o.i[8]].d;
+          host_idx.push_back({bufs[o.i[8]].d, {(const int32_t*)m->buffers[o.i[8]].data, (int64_t)a.K * a.dout}});
           push_micro(f, o.level, true);
           break;
         }
@@ -785,6 +875,19 @@ struct Sim final : ssn_sim {
           flush();
           Item it; it.type = IT_NEURONS; it.src = sig + o.i[0]; it.dst = sig + o.i[1]; it.n = (int)o.i[2];
           it.V = (T*)bufs[o.i[3]].d; it.R = (T*)bufs[o.i[4]].d; it.np = neuron_params(o.i[5], o.f); it.scalar = (T)o.f[3];
+          bool feeds_sparse = false;     // does a spike-sparse decoder product read this ensemble's spikes?
+          for (int j = 0; j < m->n_ops; ++j) {
+            const ssn_op_desc& q = m->ops[j];
+            if (q.kind == SSN_OP_MATVEC && q.stage == 1 && q.i[1] == o.i[1] && q.i[3] == o.i[2] && bufs[q.i[4]].transposed) feeds_sparse = true;
+          }
+          if (feeds_sparse && (flags & 32) && o.i[5] == SSN_LIF && o.i[2] <= 16384) {   // measured slower: opt-in
+            it.type = IT_NEURONS_COMPACT;
+            CHK(dmalloc(&it.list, (o.i[2] + 16) * 4));
+            CHK(dmalloc(&it.count, 64));
+            HIPCHK(hipMemset(it.count, 0, 64));
+            scratch_bufs.push_back(it.list); scratch_bufs.push_back(it.count);
+            spike_lists.push_back({o.i[1], {it.list, it.count}});
+          }
           items.push_back(it);
           break;
         }
@@ -844,7 +947,7 @@ struct Sim final : ssn_sim {
     for (auto& r : core_to_post) {       // hand this timestep's results to the post stage
       if (fused) break;
       MOp op{};
-      op.kind = ssn::M_ROW_OUT; op.src = r.lo; op.len = r.hi - r.lo; op.p0 = bsig; op.i0 = n_sig;
+      op.kind = ssn::M_ROW_OUT; op.src = r.lo; op.len = r.hi - r.lo; op.p0 = bsig; op.i0 = n_sig; op.i1 = r.lo;
       push_micro(op, -11, first_out);
       first_out = false;
     }
@@ -874,26 +977,44 @@ struct Sim final : ssn_sim {
       dom_units = (int64_t)a.K * a.n;
       dom_bytes = (double)dom_units * (a.din + a.dout + 5) * sizeof(T);
     }
-    // micro-op storage: programs in order, then a copy of the head behind the tail for the fused launch
+    // micro-op storage: programs in order, then a copy of the head behind the tail for the fused launch.
+    // Each program gets an LDS staging plan when the signals it touches fit (see stage_program).
     int n_prog = (int)programs.size();
-    std::vector<int> begin(n_prog, 0);
     mops.clear();
+    prog_descs.clear();
+    prog_segs.clear();
+    prog_lds.assign(n_prog + 1, 0);
     for (int p = 0; p < n_prog; ++p) {
-      begin[p] = (int)mops.size();
-      mops.insert(mops.end(), programs[p].begin(), programs[p].end());
+      ssn::ProgDesc pd{};
+      pd.op_begin = (int)mops.size(); pd.op_count = (int)programs[p].size();
+      pd.seg_begin = (int)prog_segs.size();
+      std::vector<MOp> ops = programs[p];
+      int rc_stage = stage_program(ops, prog_segs, &prog_lds[p]);
+      CHK(rc_stage);
+      pd.seg_count = (int)prog_segs.size() - pd.seg_begin;
+      mops.insert(mops.end(), ops.begin(), ops.end());
+      prog_descs.push_back(pd);
     }
     int pi = 0;
     for (auto& it : items)
-      if (it.type == IT_PROGRAM) { it.op_begin = begin[pi]; it.op_count = (int)programs[pi].size(); ++pi; }
+      if (it.type == IT_PROGRAM) { it.op_begin = pi; it.op_count = 1; ++pi; }      // op_begin = program index
     can_fuse = !fused && items.size() >= 2 && items.front().type == IT_PROGRAM && items.back().type == IT_PROGRAM;
     if (can_fuse) {
-      head_begin = items.front().op_begin; head_count = items.front().op_count;
-      tail_begin = items.back().op_begin; tail_count = items.back().op_count;
-      // tail is the last program, so appending a copy of the head makes [tail][head] contiguous
-      std::vector<MOp> head(programs.front());
-      head[0].barrier = 1;
-      mops.insert(mops.end(), head.begin(), head.end());
+      // the tail is the last program: a copy of the head's descriptor behind it makes [tail, head] one launch
+      ssn::ProgDesc hd = prog_descs.front();
+      const int hb = (int)mops.size();
+      for (int j = 0; j < hd.op_count; ++j) mops.push_back(mops[(size_t)(hd.op_begin + j)]);
+      mops[(size_t)hb].barrier = 1;
+      hd.op_begin = hb;
+      prog_descs.push_back(hd);
+      prog_lds[n_prog] = std::max(prog_lds[n_prog - 1], prog_lds[0]);
+      tail_begin = n_prog - 1;
     }
+    CHK(dmalloc(&d_progs, (int64_t)std::max<size_t>(1, prog_descs.size()) * (int64_t)sizeof(ssn::ProgDesc)));
+    CHK(dmalloc(&d_segs, (int64_t)std::max<size_t>(1, prog_segs.size()) * (int64_t)sizeof(ssn::ProgSeg)));
+    if (!prog_descs.empty()) HIPCHK(hipMemcpy(d_progs, prog_descs.data(), prog_descs.size() * sizeof(ssn::ProgDesc), hipMemcpyHostToDevice));
+    if (!prog_segs.empty()) HIPCHK(hipMemcpy(d_segs, prog_segs.data(), prog_segs.size() * sizeof(ssn::ProgSeg), hipMemcpyHostToDevice));
+    ssn::program_set_max_lds<T>(LDS_CAP);
     CHK(dmalloc(&d_mops, (int64_t)mops.size() * (int64_t)sizeof(MOp)));
     HIPCHK(hipMemcpy(d_mops, mops.data(), mops.size() * sizeof(MOp), hipMemcpyHostToDevice));
     launches_per_step = (int)items.size() - (can_fuse ? 1 : 0);
@@ -928,7 +1049,7 @@ struct Sim final : ssn_sim {
   // ---- launching --------------------------------------------------------------------------
   hipError_t launch_item(const Item& it, hipEvent_t e0, hipEvent_t e1) {
     switch (it.type) {
-      case IT_PROGRAM: return ssn::launch_program<T>(stream, d_mops + it.op_begin, it.op_count, sig, d_ctx);
+      case IT_PROGRAM: return ssn::launch_program<T>(stream, d_mops, d_progs + it.op_begin, 1, d_segs, prog_lds[it.op_begin], sig, d_ctx);
       case IT_ENS: {
         if (e0) { hipError_t e = hipEventRecord(e0, stream); if (e != hipSuccess) return e; }
         hipError_t e = ssn::launch_ensarray<T>(stream, it.ens);
@@ -939,7 +1060,8 @@ struct Sim final : ssn_sim {
       case IT_MATVEC: return ssn::launch_matvec<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set);
       case IT_MATVEC_ORDERED: return ssn::launch_matvec_ordered<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld);
       case IT_FINISH: return ssn::launch_ens_finish<T>(stream, it.fin);
-      case IT_SPMV: return ssn::launch_spmv_partial<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n);
+      case IT_SPMV: return ssn::launch_spmv_partial<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count);
+      case IT_NEURONS_COMPACT: return ssn::launch_neurons_compact<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count);
       case IT_NEURONS: return ssn::launch_neurons<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar);
       case IT_PES: return ssn::launch_pes<T>(stream, it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar);
       case IT_VOJA: return ssn::launch_voja<T>(stream, it.Wm, it.src, it.aux0, it.aux1, it.aux2, it.rows, it.cols, it.ld, it.scalar);
@@ -966,7 +1088,7 @@ struct Sim final : ssn_sim {
         hipError_t e = hipSuccess;
         if (fused && can_fuse && i == 0 && s > 0) continue;               // head already ran with the previous tail
         if (fused && can_fuse && i == n_items - 1 && s + 1 < count)
-          e = ssn::launch_program<T>(stream, d_mops + tail_begin, tail_count + head_count, sig, d_ctx);
+          e = ssn::launch_program<T>(stream, d_mops, d_progs + tail_begin, 2, d_segs, prog_lds[tail_begin + 1], sig, d_ctx);
         else
           e = launch_item(it, nullptr, nullptr);
         if (e != hipSuccess) return e;

@@ -416,12 +416,27 @@ hipError_t launch_ensarray(hipStream_t s, const EnsArgs<T>& a) {
 // the dozen tiny nengo operators between two big kernels into a single launch.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__ ops, int n_ops,
-                                                  T* __restrict__ sig, StepCtx* __restrict__ ctx) {
+__global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__ all_ops, const ProgDesc* __restrict__ progs, int n_progs,
+                                                  const ProgSeg* __restrict__ segs, T* __restrict__ gsig, StepCtx* __restrict__ ctx) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
   __shared__ T sred[16];
   __shared__ int sidx[16];
   const int tid = threadIdx.x;
   long long step = ctx->step;          // steps completed before the one being executed
+ for (int pi = 0; pi < n_progs; ++pi) {
+  const ProgDesc pd = progs[pi];
+  const MicroOp<T>* ops = all_ops + pd.op_begin;
+  const int n_ops = pd.op_count;
+  T* sig = gsig;
+  if (pd.seg_count > 0) {              // stage this program's signals in LDS
+    sig = (T*)lds_raw;
+    if (pi > 0) __syncthreads();
+    for (int sgi = 0; sgi < pd.seg_count; ++sgi) {
+      const ProgSeg sg = segs[pd.seg_begin + sgi];
+      for (int i = tid; i < sg.len; i += 1024) sig[sg.loff + i] = gsig[sg.goff + i];
+    }
+    __syncthreads();
+  }
   for (int o = 0; o < n_ops; ++o) {
     const MicroOp<T> op = ops[o];
     if (op.barrier) __syncthreads();
@@ -527,12 +542,12 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
       }
       case M_ROW_IN: {    // p0 = bsig, i0 = n_sig: sig[dst..] = bsig[row][dst..], row = step - block_start + 1
         const T* row = (const T*)op.p0 + (size_t)(step - ctx->block_start + 1) * op.i0;
-        for (long long i = tid; i < op.len; i += 1024) sig[op.dst + i] = row[op.dst + i];
+        for (long long i = tid; i < op.len; i += 1024) sig[op.dst + i] = row[op.i1 + i];      // i1 = offset in the signal vector
         break;
       }
       case M_ROW_OUT: {   // bsig[row][src..] = sig[src..]
         T* row = (T*)op.p0 + (size_t)(step - ctx->block_start + 1) * op.i0;
-        for (long long i = tid; i < op.len; i += 1024) row[op.src + i] = sig[op.src + i];
+        for (long long i = tid; i < op.len; i += 1024) row[op.i1 + i] = sig[op.src + i];
         break;
       }
       case M_REDUCE_SET:
@@ -553,12 +568,27 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
         break;
     }
   }
+  if (pd.seg_count > 0) {              // write the ranges this program modified back to the signal vector
+    __syncthreads();
+    for (int sgi = 0; sgi < pd.seg_count; ++sgi) {
+      const ProgSeg sg = segs[pd.seg_begin + sgi];
+      if (!sg.dirty) continue;
+      for (int i = tid; i < sg.len; i += 1024) gsig[sg.goff + i] = sig[sg.loff + i];
+    }
+  }
+ }
 }
 
 template <typename T>
-hipError_t launch_program(hipStream_t s, const MicroOp<T>* d_ops, int n_ops, T* sig, StepCtx* ctx) {
-  hipLaunchKernelGGL((k_program<T>), dim3(1), dim3(1024), 0, s, d_ops, n_ops, sig, ctx);
+hipError_t launch_program(hipStream_t s, const MicroOp<T>* d_ops, const ProgDesc* progs, int n_progs, const ProgSeg* segs, int lds_bytes,
+                          T* sig, StepCtx* ctx) {
+  hipLaunchKernelGGL((k_program<T>), dim3(1), dim3(1024), (size_t)lds_bytes, s, d_ops, progs, n_progs, segs, sig, ctx);
   return hipGetLastError();
+}
+
+template <typename T>
+hipError_t program_set_max_lds(int bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_program<T>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -611,24 +641,32 @@ hipError_t launch_matvec(hipStream_t s, const T* Wm, const T* src, T* dst, int r
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_spmv_partial(const T* __restrict__ Wt, int ldt, const T* __restrict__ spikes,
-                                                      int n, int rows, T* __restrict__ partial, int rows_pad, int chunks) {
+                                                      int n, int rows, T* __restrict__ partial, int rows_pad, int chunks,
+                                                      const int* __restrict__ glist, const int* __restrict__ gcount) {
   extern __shared__ unsigned char smem[];
-  int* list = (int*)smem;                       // [n] compacted indices
   __shared__ int counts[257];
   const int tid = threadIdx.x;
-  const int per = (n + 255) / 256;
-  const int lo = min(n, tid * per), hi = min(n, lo + per);
-  int cnt = 0;
-  for (int i = lo; i < hi; ++i) cnt += spikes[i] != T(0);
-  counts[tid + 1] = cnt;
-  if (tid == 0) counts[0] = 0;
-  __syncthreads();
-  if (tid == 0) for (int t = 1; t <= 256; ++t) counts[t] += counts[t - 1];
-  __syncthreads();
-  int w = counts[tid];
-  for (int i = lo; i < hi; ++i) if (spikes[i] != T(0)) list[w++] = i;
-  __syncthreads();
-  const int m = counts[256];
+  const int* list = glist;                      // spike list produced by k_neurons_compact ...
+  int m;
+  if (glist) {
+    m = gcount[0];
+  } else {                                      // ... or compacted here (ascending order, blocked scan)
+    int* llist = (int*)smem;
+    const int per = (n + 255) / 256;
+    const int lo = min(n, tid * per), hi = min(n, lo + per);
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i) cnt += spikes[i] != T(0);
+    counts[tid + 1] = cnt;
+    if (tid == 0) counts[0] = 0;
+    __syncthreads();
+    if (tid == 0) for (int t = 1; t <= 256; ++t) counts[t] += counts[t - 1];
+    __syncthreads();
+    int w = counts[tid];
+    for (int i = lo; i < hi; ++i) if (spikes[i] != T(0)) llist[w++] = i;
+    __syncthreads();
+    m = counts[256];
+    list = llist;
+  }
   const int c = blockIdx.y;
   const int b = (int)((long long)m * c / chunks), e = (int)((long long)m * (c + 1) / chunks);
   const int r = blockIdx.x * 256 + tid;
@@ -646,9 +684,54 @@ __global__ __launch_bounds__(256) void k_spmv_partial(const T* __restrict__ Wt, 
 }
 
 template <typename T>
-hipError_t launch_spmv_partial(hipStream_t s, const T* Wt, int ldt, const T* spikes, int n, int rows, T* partial, int rows_pad, int chunks) {
-  hipLaunchKernelGGL((k_spmv_partial<T>), dim3((rows + 255) / 256, chunks), dim3(256), (size_t)n * sizeof(int), s,
-                     Wt, ldt, spikes, n, rows, partial, rows_pad, chunks);
+hipError_t launch_spmv_partial(hipStream_t s, const T* Wt, int ldt, const T* spikes, int n, int rows, T* partial, int rows_pad, int chunks,
+                               const int* list, const int* count) {
+  hipLaunchKernelGGL((k_spmv_partial<T>), dim3((rows + 255) / 256, chunks), dim3(256), list ? (size_t)16 : (size_t)n * sizeof(int), s,
+                     Wt, ldt, spikes, n, rows, partial, rows_pad, chunks, list, count);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_neurons_compact: neuron step of a dense ensemble (n <= 16384) by ONE 1024-thread workgroup that also
+// leaves the ascending list of spiking neurons for the spike-sparse decoder products.  Each thread owns a
+// contiguous block of neurons, so a workgroup-wide exclusive scan of the per-thread spike counts gives
+// every thread its place in the list.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void k_neurons_compact(NeuronParams<T> np, const T* __restrict__ J, T* __restrict__ out,
+                                                          T* __restrict__ V, T* __restrict__ R, int n, T amp,
+                                                          int* __restrict__ list, int* __restrict__ count) {
+  __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + 1023) / 1024;            // <= 16
+  const int lo = min(n, tid * per), hi = min(n, lo + per);
+  unsigned mask = 0;
+  for (int i = lo; i < hi; ++i) {
+    T v = V[i], r = R[i];
+    const T a = neuron_step(np, J[i], v, r);
+    V[i] = v; R[i] = r;
+    out[i] = amp * a;
+    if (a != T(0)) mask |= 1u << (i - lo);
+  }
+  const int cnt = __popc(mask);
+  int incl = cnt;                                // inclusive scan inside the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+  int pos = base + incl - cnt;
+  for (int i = lo; i < hi; ++i) if (mask & (1u << (i - lo))) list[pos++] = i;
+  if (tid == 1023) count[0] = base + incl;
+}
+
+template <typename T>
+hipError_t launch_neurons_compact(hipStream_t s, const NeuronParams<T>& np, const T* J, T* out, T* V, T* R, int n, T amp, int* list, int* count) {
+  hipLaunchKernelGGL((k_neurons_compact<T>), dim3(1), dim3(1024), 0, s, np, J, out, V, R, n, amp, list, count);
   return hipGetLastError();
 }
 
@@ -906,11 +989,13 @@ hipError_t launch_convert_out(hipStream_t s, const T* src, double* dst, int64_t 
   template hipError_t launch_ensarray<T>(hipStream_t, const EnsArgs<T>&);                                    \
   template hipError_t launch_dec_pack<T>(hipStream_t, const T*, T*, int, int, int, int, int, int);           \
   template hipError_t launch_state_unpack<T>(hipStream_t, const T*, T*, int64_t, int);                       \
-  template hipError_t launch_program<T>(hipStream_t, const MicroOp<T>*, int, T*, StepCtx*);                  \
+  template hipError_t launch_program<T>(hipStream_t, const MicroOp<T>*, const ProgDesc*, int, const ProgSeg*, int, T*, StepCtx*); \
+  template hipError_t program_set_max_lds<T>(int);                                                          \
   template hipError_t launch_ens_finish<T>(hipStream_t, const FinishArgs<T>&);                               \
   template hipError_t launch_matvec<T>(hipStream_t, const T*, const T*, T*, int, int, int, int);            \
   template hipError_t launch_matvec_ordered<T>(hipStream_t, const T*, const T*, T*, int, int, int);         \
-  template hipError_t launch_spmv_partial<T>(hipStream_t, const T*, int, const T*, int, int, T*, int, int);  \
+  template hipError_t launch_spmv_partial<T>(hipStream_t, const T*, int, const T*, int, int, T*, int, int, const int*, const int*);  \
+  template hipError_t launch_neurons_compact<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T, int*, int*);     \
   template hipError_t launch_transpose<T>(hipStream_t, const T*, T*, int, int, int, int);                   \
   template hipError_t launch_neurons<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T); \
   template hipError_t launch_pes<T>(hipStream_t, T*, const T*, const T*, int, int, int, T);                 \

@@ -96,6 +96,11 @@ struct MicroOp {
   long long i0, i1;
 };
 
+// LDS-staged programs: the signal ranges a program touches are loaded into LDS once, its operators run there
+// (their offsets are pre-translated by the host), dirty ranges are written back once.
+struct ProgSeg { long long goff; int loff; int len; int dirty; int pad; };
+struct ProgDesc { int op_begin, op_count, seg_begin, seg_count; };
+
 struct TableSlot {     // lives in device memory; re-pointed by ssn_set_table without re-planning
   const void* rows;    // [n_rows][width] in simulator dtype
   const int* idx;      // [n_idx]
@@ -135,12 +140,16 @@ template <typename T> hipError_t launch_ensarray(hipStream_t, const EnsArgs<T>&)
 template <typename T> hipError_t launch_dec_pack(hipStream_t, const T* src, T* dst, int K, int dout, int n, int n_pad, int DP, int unpack);
 template <typename T> hipError_t launch_state_unpack(hipStream_t, const T* src, T* out, int64_t n, int want_refractory);
 template <typename T> hipError_t launch_ens_finish(hipStream_t, const FinishArgs<T>&);
-template <typename T> hipError_t launch_program(hipStream_t, const MicroOp<T>*, int, T*, StepCtx*);
+template <typename T> hipError_t launch_program(hipStream_t, const MicroOp<T>* ops, const ProgDesc* progs, int n_progs, const ProgSeg* segs,
+                                               int lds_bytes, T* sig, StepCtx* ctx);
+template <typename T> hipError_t program_set_max_lds(int bytes);
 template <typename T> hipError_t launch_matvec(hipStream_t, const T* W, const T* src, T* dst, int rows, int cols, int ld, int set);
 template <typename T> hipError_t launch_matvec_ordered(hipStream_t, const T* Wt, const T* x, T* y, int rows, int cols, int ldt);
 template <typename T> hipError_t launch_transpose(hipStream_t, const T* src, T* dst, int rows, int cols, int ld, int ldt);
 template <typename T> hipError_t launch_spmv_partial(hipStream_t, const T* Wt, int ldt, const T* spikes, int n, int rows, T* partial,
-                                                     int rows_pad, int chunks);
+                                                     int rows_pad, int chunks, const int* list, const int* count);
+template <typename T> hipError_t launch_neurons_compact(hipStream_t, const NeuronParams<T>&, const T* J, T* out, T* V, T* R, int n, T amp,
+                                                        int* list, int* count);
 template <typename T> hipError_t launch_neurons(hipStream_t, const NeuronParams<T>&, const T* J, T* out, T* V, T* R, int n, T amp);
 template <typename T> hipError_t launch_pes(hipStream_t, T* W, const T* err, const T* act, int rows, int cols, int ld, T kappa);
 template <typename T> hipError_t launch_voja(hipStream_t, T* E, const T* spk, const T* key, const T* learn, const T* scale,

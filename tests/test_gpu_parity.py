@@ -217,6 +217,19 @@ def test_slam_f32_within_cosine_bar(Simulator):
     assert ce.max() < 1e-3, ce.max()
 
 
+def test_slam_optin_plans_equal_default(Simulator):
+    """flags 32 (single-workgroup neuron kernel emitting the spike list) and 64 (LDS-staged programs) are
+    alternative plans of the same operators: same trajectory as the default plan (f64)."""
+    sm = _small_slam(weights_every=None)
+    model = build(sm.model)
+    outs = []
+    for flags in (0, 32 | 64):
+        with Simulator(None, model=model, dtype="f64", flags=flags) as sim:
+            sim.run_steps(120)
+            outs.append(sim.data[sm.probe])
+    np.testing.assert_allclose(outs[1], outs[0], atol=1e-12, rtol=0)
+
+
 def test_feedforward_model_runs_fully_batched(Simulator):
     """No neurons at all (the multi-GPU read-out is such a model): every operator runs time-batched -
     GEMM over the block, lowpass scans with carry across block boundaries (block = 64 here)."""
@@ -264,7 +277,7 @@ def test_fused_recurrent_core_equals_generic_path(Simulator):
     pm = small_pathint(ssp_dim=55, n=2500, T=10.0, limit=0.2)
     model = build(pm.model, n_eval_points=600)
     outs = []
-    for flags in (32, 1, 16):     # deferred finish (1 launch/step) | generic programs | fused with separate finish kernel
+    for flags in (0, 1, 16):      # deferred finish (1 launch/step) | generic programs | fused with separate finish kernel
         with Simulator(None, model=model, dtype="f64", flags=flags, block_steps=96) as sim:
             sim.run_steps(150)
             sim.run_steps(150)        # block boundaries, eager remainders and a second call: flush/begin paths
