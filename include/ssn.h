@@ -120,6 +120,8 @@ typedef struct ssn_model_desc {
                                          (default: finish deferred into the next step's prologue, 1 launch per step),
                                          32 = single-workgroup neuron kernel that also emits the spike list for
                                               k_spmv_partial (experiment, measured 2 % slower on SLAM config 3),
+                                         128 = no whole-block kernel for a recurrent array of independent ensembles
+                                              (k_ens_block): step it once per timestep (k_ensarray) instead,
                                          64 = programs stage their signal ranges through LDS (experiment, measured
                                               5 % slower on SLAM config 3 than operating on global memory)          */
 } ssn_model_desc;

@@ -1,0 +1,319 @@
+// ssn_block.hpp - k_ens_block: a recurrent ensemble array stepped through a whole time block in ONE launch.
+//
+// Applies when the per-timestep core is an array of K ensembles whose only recurrence is
+// ensemble k -> Lowpass -> ensemble k (the path integrator's VCO array, reference
+// sspslam/networks/pathintegration.py:150-164): the K oscillators are then independent of each other
+// inside a block - everything else they read (the velocity terms) was produced for all B timesteps of
+// the block by the time-batched pre stage.  So instead of streaming every neuron parameter from HBM once
+// per timestep (k_ensarray, HBM-bound: (din + dout + 5) words per neuron-step), one workgroup takes one
+// ensemble, loads its encoders, biases, decoders and LIF state words into REGISTERS once (10 words per
+// neuron at din 3, dout 5 - the 256 CUs' vector register files hold 128 MiB), and runs all B timesteps
+// with a single workgroup barrier per step.  HBM traffic drops by the block length (256x); the kernel is
+// bound by VALU issue instead.
+//
+// Per timestep and workgroup:
+//   x[d]   = pre-stage row (block buffer) + alpha[d] * filter_state[xrow[d]]           (uniform, scalar)
+//   for each of the thread's NPT neurons: J = e.x + bias; LIF step on the packed state word; acc += spike*dec
+//   acc[dout] -> DPP wave reduction -> LDS [parity][dout][wave] -> barrier -> every thread adds the wave sums
+//   in fixed order (deterministic; all threads hold identical totals)
+//   filter_state[r] = a[r]*filter_state[r] + b[r]*total[r]; thread r hands total[r] to the post stage's row.
+// At the end the state words go back to HBM and thread r publishes decoded value / filter state r to the
+// signal vector (what k_ens_finish does after every step of the per-step plan).
+#pragma once
+#include "ssn_launch.hpp"
+
+#ifndef SSN_BLOCK_GROUP
+#define SSN_BLOCK_GROUP 2
+#endif
+
+namespace ssn {
+
+// sum over the 64 lanes of a wave, result valid in lane 63 (fixed order -> deterministic)
+__device__ inline float wave_sum_dpp(float v) {
+  int x;
+#define SSN_DPP_ADD(ctrl, rmask)                                                                             \
+  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false);                    \
+  v += __builtin_bit_cast(float, x);
+  SSN_DPP_ADD(0xB1, 0xF)     // quad_perm [1,0,3,2]
+  SSN_DPP_ADD(0x4E, 0xF)     // quad_perm [2,3,0,1]
+  SSN_DPP_ADD(0x141, 0xF)    // row_half_mirror
+  SSN_DPP_ADD(0x140, 0xF)    // row_mirror: every lane of a 16-lane row holds the row sum
+  SSN_DPP_ADD(0x142, 0xA)    // row_bcast15 -> rows 1, 3
+  SSN_DPP_ADD(0x143, 0xC)    // row_bcast31 -> rows 2, 3: lane 63 = total
+#undef SSN_DPP_ADD
+  return v;
+}
+// sum within each 16-lane row, result in every lane of the row
+__device__ inline float row_sum_dpp(float v) {
+  int x;
+#define SSN_DPP_ADD(ctrl)                                                                                    \
+  x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false);                      \
+  v += __builtin_bit_cast(float, x);
+  SSN_DPP_ADD(0xB1) SSN_DPP_ADD(0x4E) SSN_DPP_ADD(0x141) SSN_DPP_ADD(0x140)
+#undef SSN_DPP_ADD
+  return v;
+}
+__device__ inline double wave_sum_dpp(double v) {     // parity/test instantiation: plain shuffles, result in every lane
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <typename T, int DIN, int DOUT, int NPT, int TPB, bool ENC_LDS>
+__global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
+  extern __shared__ __align__(16) unsigned char ssn_block_dyn[];
+  T* const e_lds = reinterpret_cast<T*>(ssn_block_dyn);       // ENC_LDS: encoders [DIN][nthr * NPT]
+  constexpr int DP = DOUT <= 4 ? 4 : 8;
+  const int k = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int nthr = NPT == 1 ? (int)blockDim.x : TPB;      // variants with NPT > 1 always run full workgroups
+  const int lane = tid & 63, wave = tid >> 6;
+  const size_t row = (size_t)a.n_pad;
+  const T* __restrict__ enc = a.enc + (size_t)k * DIN * row;
+  const T* __restrict__ bias = a.bias + (size_t)k * row;
+  T* __restrict__ Sp = a.S + (size_t)k * row;
+  const NeuronParams<T> np = a.np;
+  const LifMath<T> lm(np);
+
+  // ---- parameters and state of this thread's neurons -> registers (neuron i = q * nthr + tid: coalesced) ----
+  T e[ENC_LDS ? 1 : NPT][DIN], b[NPT], s[NPT], dc[NPT][DOUT];
+  const int cap = nthr * NPT;
+#pragma unroll
+  for (int q = 0; q < NPT; ++q) {
+    const int i = q * nthr + tid;
+    const bool ok = i < a.n;
+#pragma unroll
+    for (int d = 0; d < DIN; ++d) {
+      const T ev = ok ? enc[d * row + i] : T(0);
+      if constexpr (ENC_LDS) e_lds[d * cap + i] = ev; else e[q][d] = ev;
+    }
+    b[q] = ok ? bias[i] : T(0);
+    s[q] = ok ? Sp[i] : T(0);
+    if (a.dec_neuron_major) {
+      const T* dp = a.dec + ((size_t)k * row + i) * DP;
+#pragma unroll
+      for (int r = 0; r < DOUT; ++r) dc[q][r] = ok ? dp[r] : T(0);
+    } else {
+      const T* dp = a.dec + (size_t)k * DOUT * row + i;
+#pragma unroll
+      for (int r = 0; r < DOUT; ++r) dc[q][r] = ok ? dp[r * row] : T(0);
+    }
+  }
+
+  // ---- per-row constants (uniform) -------------------------------------------------------------------------
+  T fs[DOUT], la[DOUT], lb[DOUT], xa[DIN];
+  int xr[DIN];
+#pragma unroll
+  for (int r = 0; r < DOUT; ++r) {
+    const long long i = (long long)k * DOUT + r;
+    const int st = a.lp_state[i];
+    fs[r] = st >= 0 ? a.sig[st] : T(0);
+    la[r] = st >= 0 ? a.lp_a[i] : T(0);
+    lb[r] = st >= 0 ? a.lp_b[i] : T(0);
+  }
+#pragma unroll
+  for (int d = 0; d < DIN; ++d) {
+    xr[d] = a.xrow[(long long)k * DIN + d];
+    xa[d] = a.xalpha[(long long)k * DIN + d];
+  }
+
+  // ---- LDS: wave sums (two parities), and the block-buffer traffic of CH timesteps at a time so that no global
+  //      memory operation sits inside the time loop (a workgroup barrier waits for every outstanding one) ----
+  constexpr int CH = 128;                    // timesteps per input/output chunk
+  constexpr int XP = 4;                      // words per timestep of inputs (DIN <= 4): one 16-byte LDS read
+  constexpr int RW = DOUT <= 4 ? 64 : 128;   // wave-sum slots per parity: [r][16 waves]
+  __shared__ __align__(16) T red[2][RW];
+  __shared__ __align__(16) T xs[CH][XP];
+  __shared__ T os[CH][DOUT];
+  __shared__ int s_dst[DOUT];
+  __shared__ int s_out[DOUT];
+  for (int i = tid; i < 2 * RW; i += nthr) (&red[0][0])[i] = T(0);     // waves that do not exist add 0
+  if (tid < DOUT) { s_dst[tid] = a.didx[(long long)k * DOUT + tid]; s_out[tid] = a.rowout[(long long)k * DOUT + tid] ? 1 : 0; }
+  const T* __restrict__ xbase = a.xrows + (size_t)a.row0 * a.n_sig + a.x_off + (long long)k * DIN;
+  T tot[DOUT];
+#pragma unroll
+  for (int r = 0; r < DOUT; ++r) tot[r] = T(0);
+
+  for (int j0 = 0; j0 < a.B; j0 += CH) {
+    const int cn = min(CH, a.B - j0);
+    __syncthreads();                         // previous chunk: every wave is past its last xs read / os write
+    if (j0 > 0) {                            // hand the previous chunk's decoded rows to the post stage
+      for (int i = tid; i < CH * DOUT; i += nthr) {
+        const int jj = i / DOUT, r = i - jj * DOUT;
+        if (s_out[r]) a.bsig[(size_t)(a.row0 + j0 - CH + jj) * a.n_sig + s_dst[r]] = os[jj][r];
+      }
+    }
+    for (int i = tid; i < cn * DIN; i += nthr) {
+      const int jj = i / DIN, d = i - jj * DIN;
+      xs[jj][d] = xbase[(size_t)(j0 + jj) * a.n_sig + d];
+    }
+    __syncthreads();
+
+    for (int jj = 0; jj < cn; ++jj) {
+      T xin[XP];
+      if constexpr (sizeof(T) == 4) *(float4*)xin = *(const float4*)xs[jj];
+      else { *(double2*)xin = *(const double2*)xs[jj]; *(double2*)(xin + 2) = *(const double2*)(xs[jj] + 2); }
+      T x[DIN];
+#pragma unroll
+      for (int d = 0; d < DIN; ++d) {
+        T st = T(0);
+#pragma unroll
+        for (int r = 0; r < DOUT; ++r) st = xr[d] == r ? fs[r] : st;
+        x[d] = xr[d] >= 0 ? xin[d] + xa[d] * st : xin[d];
+      }
+      T acc[DOUT];
+#pragma unroll
+      for (int r = 0; r < DOUT; ++r) acc[r] = T(0);
+#pragma unroll
+      for (int q = 0; q < NPT; ++q) {
+        T J = b[q];
+#pragma unroll
+        for (int d = 0; d < DIN; ++d) {
+          if constexpr (ENC_LDS) J += e_lds[d * cap + q * nthr + tid] * x[d];      // own entries only: no barrier needed
+          else J += e[q][d] * x[d];
+        }
+        // packed state word -> nengo's LIF step, same operations as k_ensarray's fast path
+        const T sw = s[q];
+        T V = sw < T(0) ? T(0) : sw;
+        T R = (sw < T(0) ? -sw : T(0)) - np.dt;
+        T delta = np.dt - R;
+        delta = delta < T(0) ? T(0) : (delta > np.dt ? np.dt : delta);
+        V = V - (J - V) * lm.decay(delta);
+        T spk = T(0);
+        if (V > T(1)) {
+          const T t_spike = np.dt + np.tau_rc * lm.spike_time_term(V, J);
+          R = np.tau_ref + t_spike;
+          V = T(0);
+          spk = T(1);
+        } else if (V < T(0)) {
+          V = T(0);
+        }
+        s[q] = R > np.dt ? -R : V;
+#pragma unroll
+        for (int r = 0; r < DOUT; ++r) acc[r] = fma(spk, dc[q][r], acc[r]);      // spk is 0 or 1: exact add
+      }
+      const int par = jj & 1;
+#pragma unroll
+      for (int r = 0; r < DOUT; ++r) {
+        const T w = wave_sum_dpp(acc[r]);
+        if (lane == 63) red[par][r * 16 + wave] = w;
+      }
+      __syncthreads();
+      if constexpr (sizeof(T) == 4) {
+        // slot r*16 + w sits in lane r*16 + w: a 16-lane DPP row reduction adds the waves, readlane makes the
+        // totals scalar (identical in every wave: same inputs, same fixed order)
+        float v0 = red[par][lane];
+        v0 = row_sum_dpp(v0);
+#pragma unroll
+        for (int r = 0; r < (DOUT < 4 ? DOUT : 4); ++r) tot[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), r * 16));
+        if constexpr (DOUT > 4) {
+          float v1 = red[par][64 + lane];
+          v1 = row_sum_dpp(v1);
+#pragma unroll
+          for (int r = 4; r < DOUT; ++r) tot[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v1), (r - 4) * 16));
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < DOUT; ++r) {
+          T t = T(0);
+#pragma unroll
+          for (int w = 0; w < 16; ++w) t += red[par][r * 16 + w];
+          tot[r] = t;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < DOUT; ++r) fs[r] = la[r] * fs[r] + lb[r] * tot[r];    // rows without a filter: la = lb = 0
+      if (tid < DOUT) {
+        T v = T(0);
+#pragma unroll
+        for (int r = 0; r < DOUT; ++r) v = tid == r ? tot[r] : v;
+        os[jj][tid] = v;
+      }
+    }
+  }
+  __syncthreads();
+  {                                          // last chunk's decoded rows
+    const int j0 = (a.B - 1) / CH * CH, cn = a.B - j0;
+    for (int i = tid; i < cn * DOUT; i += nthr) {
+      const int jj = i / DOUT, r = i - jj * DOUT;
+      if (s_out[r]) a.bsig[(size_t)(a.row0 + j0 + jj) * a.n_sig + s_dst[r]] = os[jj][r];
+    }
+  }
+
+  // ---- state back to HBM; decoded values and filter states of the last step to the signal vector ------------
+  int tid2 = tid;
+  asm volatile("" : "+v"(tid2));      // fresh addresses: keeps NPT pointers from staying live across the time loop
+#pragma unroll
+  for (int q = 0; q < NPT; ++q) {
+    const int i = q * nthr + tid2;
+    if (i < a.n) Sp[i] = s[q];
+  }
+  if (tid < DOUT && a.B > 0) {
+    T v = T(0), f = T(0);
+#pragma unroll
+    for (int r = 0; r < DOUT; ++r) { v = tid == r ? tot[r] : v; f = tid == r ? fs[r] : f; }
+    a.sig_w[s_dst[tid]] = v;
+    const int st = a.lp_state[(long long)k * DOUT + tid];
+    if (st >= 0) a.sig_w[st] = f;
+  }
+}
+
+// (workgroup size, neurons per thread, encoders in LDS) variants.  The register budget of a wave is
+// 512 / (waves per SIMD): 1024 threads -> 128 registers, 512 -> 256, 256 -> 512 (incl. AGPRs); a neuron needs
+// din + dout + 2 persistent words (10 at din 3, dout 5), 7 with the encoders in LDS.
+template <typename T, int DIN, int DOUT, int NPT, int TPB, bool ENC_LDS>
+static hipError_t launch_block_variant(hipStream_t s, const BlockArgs<T>& a) {
+  const int lds = ENC_LDS ? DIN * a.threads * NPT * (int)sizeof(T) : 0;
+  static bool configured = false;
+  if (ENC_LDS && !configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ens_block<T, DIN, DOUT, NPT, TPB, ENC_LDS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DIN * TPB * NPT * (int)sizeof(T));
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  hipLaunchKernelGGL((k_ens_block<T, DIN, DOUT, NPT, TPB, ENC_LDS>), dim3((unsigned)a.K), dim3((unsigned)a.threads), lds, s, a);
+  return hipGetLastError();
+}
+
+template <typename T, int DIN, int DOUT>
+static hipError_t launch_block_npt(hipStream_t s, const BlockArgs<T>& a) {
+  const int key = (a.tpb * 100 + a.npt) * 2 + (a.enc_lds ? 1 : 0);
+  switch (key) {
+#define SSN_CASE(TPB, N, L) case (TPB * 100 + N) * 2 + L: return launch_block_variant<T, DIN, DOUT, N, TPB, (L != 0)>(s, a);
+    SSN_CASE(1024, 1, 0) SSN_CASE(1024, 2, 0) SSN_CASE(1024, 4, 0)
+#undef SSN_CASE
+#define SSN_CASE(TPB, N, L) case (TPB * 100 + N) * 2 + L: if constexpr (sizeof(T) == 4) return launch_block_variant<T, DIN, DOUT, N, TPB, (L != 0)>(s, a); else return hipErrorInvalidValue;
+    SSN_CASE(1024, 6, 0) SSN_CASE(1024, 10, 1) SSN_CASE(768, 14, 1) SSN_CASE(512, 16, 0) SSN_CASE(512, 20, 0) SSN_CASE(512, 20, 1) SSN_CASE(256, 40, 0)
+#undef SSN_CASE
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <typename T>
+bool ens_block_supported(int din, int dout, int n, int* threads, int* tpb, int* npt, int* enc_lds) {
+  if (!(din == 3 && dout >= 3 && dout <= 5)) return false;
+  struct V { int tpb, npt, lds; };
+  const V f32v[] = {{1024, 1, 0}, {1024, 2, 0}, {1024, 4, 0}, {1024, 6, 0}, {1024, 10, 1}, {768, 14, 1}, {512, 20, 1}, {256, 40, 0}, {512, 16, 0}, {512, 20, 0}};
+  const V f64v[] = {{1024, 1, 0}, {1024, 2, 0}, {1024, 4, 0}};
+  const V* vs = sizeof(T) == 4 ? f32v : f64v;
+  const int nv = sizeof(T) == 4 ? 10 : 3;
+  int want_tpb = 0, want_npt = 0, want_lds = 0;
+  if (const char* env = getenv("SSN_BLOCK_VARIANT")) sscanf(env, "%d,%d,%d", &want_tpb, &want_npt, &want_lds);   // tuning knob
+  for (int i = 0; i < nv; ++i) {
+    if (want_tpb && (vs[i].tpb != want_tpb || vs[i].npt != want_npt || vs[i].lds != want_lds)) continue;
+    int th = vs[i].tpb;
+    if (vs[i].npt == 1 && n < th) th = std::max(64, (n + 63) / 64 * 64);
+    if ((int64_t)th * vs[i].npt >= n) { *threads = th; *tpb = vs[i].tpb; *npt = vs[i].npt; *enc_lds = vs[i].lds; return true; }
+  }
+  return false;
+}
+
+template <typename T>
+hipError_t launch_ens_block(hipStream_t s, const BlockArgs<T>& a) {
+  if (a.din == 3 && a.dout == 5) return launch_block_npt<T, 3, 5>(s, a);
+  if (a.din == 3 && a.dout == 4) return launch_block_npt<T, 3, 4>(s, a);
+  if (a.din == 3 && a.dout == 3) return launch_block_npt<T, 3, 3>(s, a);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace ssn

@@ -129,6 +129,8 @@ struct Sim final : ssn_sim {
   bool fused_core = false;                    // core == one recurrent ensemble array: [k_ensarray, k_ens_finish]
   bool fused_defer = false;                   // ... with the finish deferred into the next step's prologue: [k_ensarray]
   ssn::FinishArgs<T> fin_begin, fin_flush;
+  bool fused_block = false;                   // ... stepped a whole block per launch: [k_ens_block] (ssn_block.hpp)
+  ssn::BlockArgs<T> blk;
   std::vector<void*> fused_bufs;
   std::set<int> sparse_w;                     // decoder buffers multiplied with a LIF spike vector
   std::vector<std::pair<int64_t, std::pair<int*, int*>>> spike_lists;   // spike signal offset -> (list, count)
@@ -606,7 +608,43 @@ struct Sim final : ssn_sim {
         }
       }
     }
-    // ---- plan: [k_ensarray (fused prologue), k_ens_finish] -------------------------------------------
+    // ---- plan A: the ensembles are independent inside a block -> one k_ens_block launch per block -----
+    int blk_threads = 0, blk_tpb = 0, blk_npt = 0, blk_lds = 0;
+    if (defer && !(flags & 128) && ens_fast(eo) &&
+        ssn::ens_block_supported<T>((int)din, (int)dout, (int)eo.i[2], &blk_threads, &blk_tpb, &blk_npt, &blk_lds)) {
+      const int64_t nr = K * dout;
+      int* d_lp = nullptr; T* d_a = nullptr; T* d_b = nullptr; unsigned char* d_ro = nullptr; int* d_xrow = nullptr; T* d_xalpha = nullptr;
+      if ((*rc = dmalloc(&d_lp, nr * 4)) != SSN_OK) return true;
+      if ((*rc = dmalloc(&d_a, nr * (int64_t)sizeof(T))) != SSN_OK) return true;
+      if ((*rc = dmalloc(&d_b, nr * (int64_t)sizeof(T))) != SSN_OK) return true;
+      if ((*rc = dmalloc(&d_ro, nr)) != SSN_OK) return true;
+      if ((*rc = dmalloc(&d_xrow, (int64_t)K * din * 4)) != SSN_OK) return true;
+      if ((*rc = dmalloc(&d_xalpha, (int64_t)K * din * (int64_t)sizeof(T))) != SSN_OK) return true;
+      fused_bufs.insert(fused_bufs.end(), {(void*)d_lp, (void*)d_a, (void*)d_b, (void*)d_ro, (void*)d_xrow, (void*)d_xalpha});
+      hipMemcpy(d_lp, lp_state.data(), (size_t)nr * 4, hipMemcpyHostToDevice);
+      hipMemcpy(d_ro, rowout.data(), (size_t)nr, hipMemcpyHostToDevice);
+      hipMemcpy(d_xrow, xrow.data(), (size_t)(K * din) * 4, hipMemcpyHostToDevice);
+      if ((*rc = upload(lp_a.data(), d_a, 1, nr, nr)) != SSN_OK) return true;
+      if ((*rc = upload(lp_b.data(), d_b, 1, nr, nr)) != SSN_OK) return true;
+      if ((*rc = upload(xalpha.data(), d_xalpha, 1, K * din, K * din)) != SSN_OK) return true;
+      ssn::EnsArgs<T> ea;
+      fill_ens_args(eo, ea);
+      blk = ssn::BlockArgs<T>{};
+      blk.enc = ea.enc; blk.bias = ea.bias; blk.dec = ea.dec; blk.S = ea.V;
+      blk.xrows = bsig; blk.bsig = bsig; blk.sig = sig; blk.sig_w = sig;
+      blk.didx = (const int*)bufs[eo.i[8]].d; blk.lp_state = d_lp; blk.lp_a = d_a; blk.lp_b = d_b;
+      blk.xrow = d_xrow; blk.xalpha = d_xalpha; blk.rowout = d_ro;
+      blk.n_sig = n_sig; blk.x_off = eo.i[0];
+      blk.K = ea.K; blk.n = ea.n; blk.n_pad = ea.n_pad; blk.din = ea.din; blk.dout = ea.dout;
+      blk.B = 0; blk.row0 = 1; blk.threads = blk_threads; blk.tpb = blk_tpb; blk.npt = blk_npt; blk.enc_lds = blk_lds;
+      blk.dec_neuron_major = ea.fast == 1 ? 1 : 0;
+      blk.np = ea.np;
+      dom_units = (int64_t)ea.K * ea.n * block;
+      dom_bytes = (double)dom_units * (ea.din + ea.dout + 5) * sizeof(T);
+      fused_core = fused_block = true;
+      return true;
+    }
+    // ---- plan B: [k_ensarray (fused prologue), k_ens_finish] ------------------------------------------
     Item it; it.type = IT_ENS;
     fill_ens_args(eo, it.ens);
     ssn::EnsArgs<T>& a = it.ens;
@@ -1019,6 +1057,7 @@ struct Sim final : ssn_sim {
     HIPCHK(hipMemcpy(d_mops, mops.data(), mops.size() * sizeof(MOp), hipMemcpyHostToDevice));
     launches_per_step = (int)items.size() - (can_fuse ? 1 : 0);
     if (fused_defer) launches_per_step = 1;
+    if (fused_block) launches_per_step = 0;      // one launch per block
     int n_core_ops = 0;
     for (int i = 0; i < m->n_ops; ++i) n_core_ops += m->ops[i].stage == 1;
     bool core_probe = false;
@@ -1098,7 +1137,7 @@ struct Sim final : ssn_sim {
   }
 
   int capture() {
-    if (steps_per_graph <= 1) return SSN_OK;
+    if (steps_per_graph <= 1 || fused_block) return SSN_OK;
     HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
     hipError_t e = launch_steps(steps_per_graph, true);
     hipError_t e2 = hipStreamEndCapture(stream, &graph);
@@ -1116,7 +1155,7 @@ struct Sim final : ssn_sim {
     for (auto& it : items) n_dom += it.dominant ? 1 : 0;
     size_t ev_used = 0;
     if (profile) {
-      const size_t need = (size_t)(2 * n * std::max(1, n_dom));
+      const size_t need = fused_block ? (size_t)(2 * (n / std::max(1, block) + 2)) : (size_t)(2 * n * std::max(1, n_dom));
       if (need > 400000) return fail(SSN_EINVAL, "profile run too long (%lld steps): at most 200000 timed launches", (long long)n);
       while (ev_pool.size() < need) {
         hipEvent_t ev;
@@ -1136,7 +1175,15 @@ struct Sim final : ssn_sim {
         HIPCHK(run_batch(pre_ops, (int)B, step0));
       }
       if (fused_defer) HIPCHK(ssn::launch_ens_finish<T>(stream, fin_begin));
-      if (core_empty) {
+      if (fused_block) {
+        const bool timed = profile && B == block && ev_used + 2 <= ev_pool.size();
+        blk.B = (int)B;
+        if (timed) HIPCHK(hipEventRecord(ev_pool[ev_used], stream));
+        HIPCHK(ssn::launch_ens_block<T>(stream, blk));
+        if (timed) { HIPCHK(hipEventRecord(ev_pool[ev_used + 1], stream)); ev_used += 2; }
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, (long long)B);
+        HIPCHK(hipGetLastError());
+      } else if (core_empty) {
         // nothing is stepped one timestep at a time (purely feed-forward model): just advance the clock
         hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, (long long)B);
         HIPCHK(hipGetLastError());

@@ -985,7 +985,13 @@ hipError_t launch_convert_out(hipStream_t s, const T* src, double* dst, int64_t 
   return hipGetLastError();
 }
 
+}  // namespace ssn
+#include "ssn_block.hpp"
+namespace ssn {
+
 #define SSN_INSTANTIATE(T)                                                                                   \
+  template hipError_t launch_ens_block<T>(hipStream_t, const BlockArgs<T>&);                                 \
+  template bool ens_block_supported<T>(int, int, int, int*, int*, int*, int*);                                         \
   template hipError_t launch_ensarray<T>(hipStream_t, const EnsArgs<T>&);                                    \
   template hipError_t launch_dec_pack<T>(hipStream_t, const T*, T*, int, int, int, int, int, int);           \
   template hipError_t launch_state_unpack<T>(hipStream_t, const T*, T*, int64_t, int);                       \

@@ -80,6 +80,35 @@ struct FinishArgs {
   const int* lp_has;
 };
 
+// Whole-block launch of a recurrent ensemble array whose ensembles are independent inside a block
+// (ssn_block.hpp): one workgroup per ensemble, parameters and state held in registers for B timesteps.
+template <typename T>
+struct BlockArgs {
+  const T* enc;        // [K][din][n_pad]
+  const T* bias;       // [K][n_pad]
+  const T* dec;        // [K][n_pad][DP] (dec_neuron_major) or [K][dout][n_pad]
+  T* S;                // [K][n_pad] packed LIF state words
+  const T* xrows;      // block buffer (pre-stage rows)
+  T* bsig;             // block buffer (rows handed to the post stage)
+  const T* sig;        // signal vector: filter states in
+  T* sig_w;            // signal vector: decoded values / filter states out
+  const int* didx;     // [K*dout] destination signal per decoded row
+  const int* lp_state; // [K*dout] filter-state signal fed by the row, or -1
+  const T* lp_a;       // [K*dout]
+  const T* lp_b;       // [K*dout]
+  const int* xrow;     // [K*din] row of the same ensemble whose filter state feeds this input, or -1
+  const T* xalpha;     // [K*din]
+  const unsigned char* rowout;   // [K*dout] 1: decoded value goes to the post stage's block row
+  long long n_sig, x_off;
+  int K, n, n_pad, din, dout;
+  int B;               // timesteps in this launch
+  int row0;            // block-buffer row of the launch's first timestep
+  int threads, tpb, npt;   // workgroup size, kernel variant (launch bound, neurons per thread): threads * npt >= n
+  int dec_neuron_major;
+  int enc_lds;         // kernel variant keeps the encoders in LDS instead of registers
+  NeuronParams<T> np;
+};
+
 enum MicroKind {
   M_FILL = 1, M_AXPY_INC, M_AXPY_SET, M_LOWPASS, M_TABLE, M_MATVEC_INC, M_MATVEC_SET, M_ENS_FINISH,
   M_GATE, M_ARGMAX_GATHER, M_PROBE, M_STEP_END, M_ROW_IN, M_ROW_OUT, M_REDUCE_SET, M_REDUCE_INC
@@ -140,6 +169,8 @@ template <typename T> hipError_t launch_ensarray(hipStream_t, const EnsArgs<T>&)
 template <typename T> hipError_t launch_dec_pack(hipStream_t, const T* src, T* dst, int K, int dout, int n, int n_pad, int DP, int unpack);
 template <typename T> hipError_t launch_state_unpack(hipStream_t, const T* src, T* out, int64_t n, int want_refractory);
 template <typename T> hipError_t launch_ens_finish(hipStream_t, const FinishArgs<T>&);
+template <typename T> hipError_t launch_ens_block(hipStream_t, const BlockArgs<T>&);
+template <typename T> bool ens_block_supported(int din, int dout, int n, int* threads, int* tpb, int* npt, int* enc_lds);
 template <typename T> hipError_t launch_program(hipStream_t, const MicroOp<T>* ops, const ProgDesc* progs, int n_progs, const ProgSeg* segs,
                                                int lds_bytes, T* sig, StepCtx* ctx);
 template <typename T> hipError_t program_set_max_lds(int bytes);

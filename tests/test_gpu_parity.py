@@ -277,7 +277,7 @@ def test_fused_recurrent_core_equals_generic_path(Simulator):
     pm = small_pathint(ssp_dim=55, n=2500, T=10.0, limit=0.2)
     model = build(pm.model, n_eval_points=600)
     outs = []
-    for flags in (0, 1, 16):      # deferred finish (1 launch/step) | generic programs | fused with separate finish kernel
+    for flags in (128, 1, 16):    # deferred finish (1 launch/step) | generic programs | fused with separate finish kernel
         with Simulator(None, model=model, dtype="f64", flags=flags, block_steps=96) as sim:
             sim.run_steps(150)
             sim.run_steps(150)        # block boundaries, eager remainders and a second call: flush/begin paths
@@ -293,3 +293,39 @@ def test_fused_recurrent_core_equals_generic_path(Simulator):
     ref = OracleSimulator(model)
     ref.run_steps(300)
     np.testing.assert_allclose(outs[0], ref.probe_data(0), atol=1e-9, rtol=0)
+    # default plan: the whole block in one launch (k_ens_block, one workgroup per VCO, state in registers);
+    # same arithmetic per neuron, the spike sums are added in a different (fixed) order
+    with Simulator(None, model=model, dtype="f64", block_steps=96) as sim:
+        sim.run_steps(150)
+        sim.run_steps(150)
+        assert sim.counters()["launches_per_step"] == 0
+        np.testing.assert_allclose(sim.data[pm.probe], ref.probe_data(0), atol=1e-9, rtol=0)
+        # neuron state and filter states were written back: continuing per-timestep from here stays on the oracle
+        v_buf = next(o for o in model.ops if o["kind"] == "ensarray")["v"]
+        got_v = sim.read_buffer(v_buf)
+        np.testing.assert_allclose(got_v, np.asarray(ref.buf[v_buf]).reshape(got_v.shape), atol=1e-9, rtol=0)
+
+
+def test_block_kernel_variants_f32(Simulator):
+    """k_ens_block register/LDS variants (neurons per thread 1..6 by size; forced ones through the tuning knob)
+    against the per-timestep kernel: f32, short window, cosine bar."""
+    import os
+    for n, variant in ((700, None), (1500, None), (3000, None), (5000, None), (5000, "1024,10,1"), (5000, "768,14,1"), (5000, "512,20,1"), (5000, "512,16,0"), (5000, "256,40,0")):
+        pm = small_pathint(ssp_dim=19, n=n, T=10.0, limit=0.2)
+        model = build(pm.model, n_eval_points=300)
+        with Simulator(None, model=model, dtype="f32", flags=128, block_steps=64) as sim:
+            sim.run_steps(150)
+            want = sim.data[pm.probe]
+        os.environ.pop("SSN_BLOCK_VARIANT", None)
+        if variant:
+            os.environ["SSN_BLOCK_VARIANT"] = variant
+        try:
+            with Simulator(None, model=model, dtype="f32", block_steps=64) as sim:
+                sim.run_steps(100)
+                sim.run_steps(50)
+                assert sim.counters()["launches_per_step"] == 0
+                got = sim.data[pm.probe]
+        finally:
+            os.environ.pop("SSN_BLOCK_VARIANT", None)
+        ce = H.cosine_error(got[20:], want[20:])
+        assert ce.max() < 1e-3, (n, variant, ce.max())
