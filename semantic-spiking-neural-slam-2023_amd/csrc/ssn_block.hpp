@@ -20,11 +20,8 @@
 // At the end the state words go back to HBM and thread r publishes decoded value / filter state r to the
 // signal vector (what k_ens_finish does after every step of the per-step plan).
 #pragma once
+#include <type_traits>
 #include "ssn_launch.hpp"
-
-#ifndef SSN_BLOCK_GROUP
-#define SSN_BLOCK_GROUP 2
-#endif
 
 namespace ssn {
 
@@ -59,14 +56,75 @@ __device__ inline double wave_sum_dpp(double v) {     // parity/test instantiati
   return v;
 }
 
+// Branch-free f32 LIF step on the packed state word (s >= 0: voltage; s < 0: minus the remaining refractory
+// time), TWO neurons per call in the two halves of 64-bit register pairs so that the multiplies / adds / FMAs
+// issue as packed v_pk_*_f32 (2 flops per lane per issue slot - the kernel is VALU-issue bound).  Value for value
+// the arithmetic of k_ensarray's fast path (-R' = min(s,0) + dt is the exact negation of R - dt, and so on),
+// except expm1's Taylor polynomial stopping one term earlier (below).  The spike branch is evaluated for every
+// lane and selected: at ~4 % spikes per step some lane of a wave takes it for 93 % of the neurons anyway.
+// Requires dt/tau_rc <= 1/8 (Taylor range) and tau_ref >= dt; the host planner checks both.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+struct LifConstF32 { float dt, neg_dt, neg_inv_tau, tau_rc_ln2, tau_ref_dt; };
+
+__device__ inline f32x2 lif_packed_step_f32x2(f32x2 J, f32x2& s, const LifConstF32& c) {
+  // min / max against 0 on the bit pattern (negative floats are negative integers): one instruction each,
+  // where fminf / fmaxf cost a NaN-quieting pre-pass in IEEE mode
+  const i32x2 sb = __builtin_bit_cast(i32x2, s);
+  const f32x2 m = __builtin_bit_cast(f32x2, __builtin_elementwise_min(sb, (i32x2)(0)));    // -(remaining refractory time)
+  const f32x2 V0 = __builtin_bit_cast(f32x2, __builtin_elementwise_max(sb, (i32x2)(0)));
+  const f32x2 negR = m + c.dt;                     // -(R - dt)
+  f32x2 delta = negR + c.dt;                       // dt - (R - dt)
+  delta.x = __builtin_amdgcn_fmed3f(delta.x, 0.0f, c.dt);
+  delta.y = __builtin_amdgcn_fmed3f(delta.y, 0.0f, c.dt);
+  const f32x2 x = delta * c.neg_inv_tau;
+  f32x2 q = (f32x2)(1.0f / 120.0f);                // expm1(x)/x to x^4/120: next term < 4e-8 relative at |x| <= 1/8
+  q = __builtin_elementwise_fma(q, x, (f32x2)(1.0f / 24.0f));
+  q = __builtin_elementwise_fma(q, x, (f32x2)(1.0f / 6.0f));
+  q = __builtin_elementwise_fma(q, x, (f32x2)(0.5f));
+  q = __builtin_elementwise_fma(q, x, (f32x2)(1.0f));
+  const f32x2 V = V0 - (J - V0) * (q * x);
+  const f32x2 vm1 = V - 1.0f, jm1 = J - 1.0f;
+  f32x2 rc;
+  rc.x = __builtin_amdgcn_rcpf(jm1.x);
+  rc.y = __builtin_amdgcn_rcpf(jm1.y);
+  const f32x2 omu = 1.0f - vm1 * rc;               // 1 - (V - 1) / (J - 1)
+  f32x2 lg2;
+  lg2.x = __builtin_amdgcn_logf(omu.x);            // log2; used only where the neuron spiked
+  lg2.y = __builtin_amdgcn_logf(omu.y);
+  const f32x2 Rs = __builtin_elementwise_fma((f32x2)(c.tau_rc_ln2), lg2, (f32x2)(c.tau_ref_dt));   // tau_ref + dt + tau_rc ln(1-u)
+  const f32x2 Vc = __builtin_bit_cast(f32x2, __builtin_elementwise_max(__builtin_bit_cast(i32x2, V), (i32x2)(0)));
+  f32x2 spk;
+  {
+    const float s_ns = negR.x < c.neg_dt ? negR.x : Vc.x;      // still refractory after this step ? -R : V
+    const bool sp = V.x > 1.0f;
+    s.x = sp ? -Rs.x : s_ns;                                   // (tau_ref >= dt: a spike is always followed by a refractory step)
+    spk.x = sp ? 1.0f : 0.0f;
+  }
+  {
+    const float s_ns = negR.y < c.neg_dt ? negR.y : Vc.y;
+    const bool sp = V.y > 1.0f;
+    s.y = sp ? -Rs.y : s_ns;
+    spk.y = sp ? 1.0f : 0.0f;
+  }
+  return spk;
+}
+
+// Neurons are dealt to threads in groups of PK adjacent neurons (PK = 2 for f32: one 64-bit register pair,
+// 1 for f64): neuron index of (group g, thread tid, component c) = (g * nthr + tid) * PK + c - coalesced.
 template <typename T, int DIN, int DOUT, int NPT, int TPB, bool ENC_LDS>
 __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   extern __shared__ __align__(16) unsigned char ssn_block_dyn[];
   T* const e_lds = reinterpret_cast<T*>(ssn_block_dyn);       // ENC_LDS: encoders [DIN][nthr * NPT]
+  constexpr bool F32 = sizeof(T) == 4;
+  constexpr int PK = F32 ? 2 : 1;
+  constexpr int NG = NPT / PK;
+  static_assert(NPT % PK == 0, "f32 variants handle neuron pairs");
+  using G = typename std::conditional<F32, f32x2, T>::type;   // one group of neurons
   constexpr int DP = DOUT <= 4 ? 4 : 8;
   const int k = blockIdx.x;
   const int tid = threadIdx.x;
-  const int nthr = NPT == 1 ? (int)blockDim.x : TPB;      // variants with NPT > 1 always run full workgroups
+  const int nthr = NG == 1 ? (int)blockDim.x : TPB;       // variants with more than one group always run full workgroups
   const int lane = tid & 63, wave = tid >> 6;
   const size_t row = (size_t)a.n_pad;
   const T* __restrict__ enc = a.enc + (size_t)k * DIN * row;
@@ -74,29 +132,35 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   T* __restrict__ Sp = a.S + (size_t)k * row;
   const NeuronParams<T> np = a.np;
   const LifMath<T> lm(np);
+  const LifConstF32 lc{(float)np.dt, -(float)np.dt, -1.0f / (float)np.tau_rc, (float)np.tau_rc * 0.6931471805599453f,
+                       (float)np.tau_ref + (float)np.dt};
 
-  // ---- parameters and state of this thread's neurons -> registers (neuron i = q * nthr + tid: coalesced) ----
-  T e[ENC_LDS ? 1 : NPT][DIN], b[NPT], s[NPT], dc[NPT][DOUT];
+  // ---- parameters and state of this thread's neurons -> registers ---------------------------------------------
+  G e[ENC_LDS ? 1 : NG][DIN], b[NG], s[NG], dc[NG][DOUT];
   const int cap = nthr * NPT;
+  auto comp = [](G& v, int c) -> T& { if constexpr (F32) return c == 0 ? reinterpret_cast<T*>(&v)[0] : reinterpret_cast<T*>(&v)[1]; else return v; };
 #pragma unroll
-  for (int q = 0; q < NPT; ++q) {
-    const int i = q * nthr + tid;
-    const bool ok = i < a.n;
+  for (int g = 0; g < NG; ++g) {
 #pragma unroll
-    for (int d = 0; d < DIN; ++d) {
-      const T ev = ok ? enc[d * row + i] : T(0);
-      if constexpr (ENC_LDS) e_lds[d * cap + i] = ev; else e[q][d] = ev;
-    }
-    b[q] = ok ? bias[i] : T(0);
-    s[q] = ok ? Sp[i] : T(0);
-    if (a.dec_neuron_major) {
-      const T* dp = a.dec + ((size_t)k * row + i) * DP;
+    for (int c = 0; c < PK; ++c) {
+      const int i = (g * nthr + tid) * PK + c;
+      const bool ok = i < a.n;
 #pragma unroll
-      for (int r = 0; r < DOUT; ++r) dc[q][r] = ok ? dp[r] : T(0);
-    } else {
-      const T* dp = a.dec + (size_t)k * DOUT * row + i;
+      for (int d = 0; d < DIN; ++d) {
+        const T ev = ok ? enc[d * row + i] : T(0);
+        if constexpr (ENC_LDS) e_lds[d * cap + i] = ev; else comp(e[g][d], c) = ev;
+      }
+      comp(b[g], c) = ok ? bias[i] : T(0);
+      comp(s[g], c) = ok ? Sp[i] : T(0);
+      if (a.dec_neuron_major) {
+        const T* dp = a.dec + ((size_t)k * row + i) * DP;
 #pragma unroll
-      for (int r = 0; r < DOUT; ++r) dc[q][r] = ok ? dp[r * row] : T(0);
+        for (int r = 0; r < DOUT; ++r) comp(dc[g][r], c) = ok ? dp[r] : T(0);
+      } else {
+        const T* dp = a.dec + (size_t)k * DOUT * row + i;
+#pragma unroll
+        for (int r = 0; r < DOUT; ++r) comp(dc[g][r], c) = ok ? dp[r * row] : T(0);
+      }
     }
   }
 
@@ -161,36 +225,49 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
         for (int r = 0; r < DOUT; ++r) st = xr[d] == r ? fs[r] : st;
         x[d] = xr[d] >= 0 ? xin[d] + xa[d] * st : xin[d];
       }
-      T acc[DOUT];
+      G accg[DOUT];
 #pragma unroll
-      for (int r = 0; r < DOUT; ++r) acc[r] = T(0);
+      for (int r = 0; r < DOUT; ++r) accg[r] = G(0);
 #pragma unroll
-      for (int q = 0; q < NPT; ++q) {
-        T J = b[q];
+      for (int g = 0; g < NG; ++g) {
+        G J = b[g];
 #pragma unroll
         for (int d = 0; d < DIN; ++d) {
-          if constexpr (ENC_LDS) J += e_lds[d * cap + q * nthr + tid] * x[d];      // own entries only: no barrier needed
-          else J += e[q][d] * x[d];
+          // ENC_LDS: a thread reads back only the entries it wrote itself - no barrier needed
+          if constexpr (ENC_LDS) J += *reinterpret_cast<const G*>(e_lds + d * cap + (g * nthr + tid) * PK) * x[d];
+          else J += e[g][d] * x[d];
         }
-        // packed state word -> nengo's LIF step, same operations as k_ensarray's fast path
-        const T sw = s[q];
-        T V = sw < T(0) ? T(0) : sw;
-        T R = (sw < T(0) ? -sw : T(0)) - np.dt;
-        T delta = np.dt - R;
-        delta = delta < T(0) ? T(0) : (delta > np.dt ? np.dt : delta);
-        V = V - (J - V) * lm.decay(delta);
-        T spk = T(0);
-        if (V > T(1)) {
-          const T t_spike = np.dt + np.tau_rc * lm.spike_time_term(V, J);
-          R = np.tau_ref + t_spike;
-          V = T(0);
-          spk = T(1);
-        } else if (V < T(0)) {
-          V = T(0);
+        G spk;
+        if constexpr (F32) spk = lif_packed_step_f32x2(J, s[g], lc);
+        else {
+          // packed state word -> nengo's LIF step, operation for operation k_ensarray's fast path
+          const T sw = s[g];
+          T V = sw < T(0) ? T(0) : sw;
+          T R = (sw < T(0) ? -sw : T(0)) - np.dt;
+          T delta = np.dt - R;
+          delta = delta < T(0) ? T(0) : (delta > np.dt ? np.dt : delta);
+          V = V - (J - V) * lm.decay(delta);
+          spk = T(0);
+          if (V > T(1)) {
+            const T t_spike = np.dt + np.tau_rc * lm.spike_time_term(V, J);
+            R = np.tau_ref + t_spike;
+            V = T(0);
+            spk = T(1);
+          } else if (V < T(0)) {
+            V = T(0);
+          }
+          s[g] = R > np.dt ? -R : V;
         }
-        s[q] = R > np.dt ? -R : V;
 #pragma unroll
-        for (int r = 0; r < DOUT; ++r) acc[r] = fma(spk, dc[q][r], acc[r]);      // spk is 0 or 1: exact add
+        for (int r = 0; r < DOUT; ++r) {           // spk is 0 or 1: exact add
+          if constexpr (F32) accg[r] = __builtin_elementwise_fma(spk, dc[g][r], accg[r]);
+          else accg[r] = fma(spk, dc[g][r], accg[r]);
+        }
+      }
+      T acc[DOUT];
+#pragma unroll
+      for (int r = 0; r < DOUT; ++r) {
+        if constexpr (F32) acc[r] = accg[r].x + accg[r].y; else acc[r] = accg[r];
       }
       const int par = jj & 1;
 #pragma unroll
@@ -244,9 +321,12 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   int tid2 = tid;
   asm volatile("" : "+v"(tid2));      // fresh addresses: keeps NPT pointers from staying live across the time loop
 #pragma unroll
-  for (int q = 0; q < NPT; ++q) {
-    const int i = q * nthr + tid2;
-    if (i < a.n) Sp[i] = s[q];
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int c = 0; c < PK; ++c) {
+      const int i = (g * nthr + tid2) * PK + c;
+      if (i < a.n) Sp[i] = comp(s[g], c);
+    }
   }
   if (tid < DOUT && a.B > 0) {
     T v = T(0), f = T(0);
@@ -280,7 +360,10 @@ static hipError_t launch_block_npt(hipStream_t s, const BlockArgs<T>& a) {
   const int key = (a.tpb * 100 + a.npt) * 2 + (a.enc_lds ? 1 : 0);
   switch (key) {
 #define SSN_CASE(TPB, N, L) case (TPB * 100 + N) * 2 + L: return launch_block_variant<T, DIN, DOUT, N, TPB, (L != 0)>(s, a);
-    SSN_CASE(1024, 1, 0) SSN_CASE(1024, 2, 0) SSN_CASE(1024, 4, 0)
+    SSN_CASE(1024, 2, 0) SSN_CASE(1024, 4, 0)
+#undef SSN_CASE
+#define SSN_CASE(TPB, N, L) case (TPB * 100 + N) * 2 + L: if constexpr (sizeof(T) == 8) return launch_block_variant<T, DIN, DOUT, N, TPB, (L != 0)>(s, a); else return hipErrorInvalidValue;
+    SSN_CASE(1024, 1, 0)
 #undef SSN_CASE
 #define SSN_CASE(TPB, N, L) case (TPB * 100 + N) * 2 + L: if constexpr (sizeof(T) == 4) return launch_block_variant<T, DIN, DOUT, N, TPB, (L != 0)>(s, a); else return hipErrorInvalidValue;
     SSN_CASE(1024, 6, 0) SSN_CASE(1024, 10, 1) SSN_CASE(768, 14, 1) SSN_CASE(512, 16, 0) SSN_CASE(512, 20, 0) SSN_CASE(512, 20, 1) SSN_CASE(256, 40, 0)
@@ -293,16 +376,17 @@ template <typename T>
 bool ens_block_supported(int din, int dout, int n, int* threads, int* tpb, int* npt, int* enc_lds) {
   if (!(din == 3 && dout >= 3 && dout <= 5)) return false;
   struct V { int tpb, npt, lds; };
-  const V f32v[] = {{1024, 1, 0}, {1024, 2, 0}, {1024, 4, 0}, {1024, 6, 0}, {1024, 10, 1}, {768, 14, 1}, {512, 20, 1}, {256, 40, 0}, {512, 16, 0}, {512, 20, 0}};
+  const V f32v[] = {{1024, 2, 0}, {1024, 4, 0}, {1024, 6, 0}, {1024, 10, 1}, {768, 14, 1}, {512, 20, 1}, {256, 40, 0}, {512, 16, 0}, {512, 20, 0}};
   const V f64v[] = {{1024, 1, 0}, {1024, 2, 0}, {1024, 4, 0}};
   const V* vs = sizeof(T) == 4 ? f32v : f64v;
-  const int nv = sizeof(T) == 4 ? 10 : 3;
+  const int nv = sizeof(T) == 4 ? 9 : 3;
   int want_tpb = 0, want_npt = 0, want_lds = 0;
   if (const char* env = getenv("SSN_BLOCK_VARIANT")) sscanf(env, "%d,%d,%d", &want_tpb, &want_npt, &want_lds);   // tuning knob
   for (int i = 0; i < nv; ++i) {
     if (want_tpb && (vs[i].tpb != want_tpb || vs[i].npt != want_npt || vs[i].lds != want_lds)) continue;
     int th = vs[i].tpb;
-    if (vs[i].npt == 1 && n < th) th = std::max(64, (n + 63) / 64 * 64);
+    const int pk = sizeof(T) == 4 ? 2 : 1;         // neurons per group; single-group variants run n / pk threads
+    if (vs[i].npt == pk && n < th * pk) th = std::max(64, ((n + pk - 1) / pk + 63) / 64 * 64);
     if ((int64_t)th * vs[i].npt >= n) { *threads = th; *tpb = vs[i].tpb; *npt = vs[i].npt; *enc_lds = vs[i].lds; return true; }
   }
   return false;

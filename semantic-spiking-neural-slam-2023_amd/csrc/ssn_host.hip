@@ -610,7 +610,7 @@ struct Sim final : ssn_sim {
     }
     // ---- plan A: the ensembles are independent inside a block -> one k_ens_block launch per block -----
     int blk_threads = 0, blk_tpb = 0, blk_npt = 0, blk_lds = 0;
-    if (defer && !(flags & 128) && ens_fast(eo) &&
+    if (defer && !(flags & 128) && ens_fast(eo) && (sizeof(T) == 8 || (dt <= 0.125 * eo.f[0] && eo.f[1] >= dt)) &&
         ssn::ens_block_supported<T>((int)din, (int)dout, (int)eo.i[2], &blk_threads, &blk_tpb, &blk_npt, &blk_lds)) {
       const int64_t nr = K * dout;
       int* d_lp = nullptr; T* d_a = nullptr; T* d_b = nullptr; unsigned char* d_ro = nullptr; int* d_xrow = nullptr; T* d_xalpha = nullptr;

@@ -310,7 +310,7 @@ def test_block_kernel_variants_f32(Simulator):
     """k_ens_block register/LDS variants (neurons per thread 1..6 by size; forced ones through the tuning knob)
     against the per-timestep kernel: f32, short window, cosine bar."""
     import os
-    for n, variant in ((700, None), (1500, None), (3000, None), (5000, None), (5000, "1024,10,1"), (5000, "768,14,1"), (5000, "512,20,1"), (5000, "512,16,0"), (5000, "256,40,0")):
+    for n, variant in ((60, None), (700, None), (1500, None), (3000, None), (5000, None), (5000, "1024,10,1"), (5000, "768,14,1"), (5000, "512,20,1"), (5000, "512,16,0"), (5000, "256,40,0")):
         pm = small_pathint(ssp_dim=19, n=n, T=10.0, limit=0.2)
         model = build(pm.model, n_eval_points=300)
         with Simulator(None, model=model, dtype="f32", flags=128, block_steps=64) as sim:
