@@ -49,7 +49,9 @@ def parse():
     ap.add_argument("--eval-points", type=int, default=4000,
                     help="decoder-solve eval points per VCO (nengo's default max(1500, 2n) = 20000 costs ~10x the build)")
     ap.add_argument("--cpu-steps", type=int, default=60, help="oracle timesteps for the cpu_baseline / parity leg (0 = skip)")
-    ap.add_argument("--profile-steps", type=int, default=500)
+    ap.add_argument("--sim-block", type=int, default=1024,
+                    help="timesteps per time-batched block inside the simulator (one k_ens_block launch each)")
+    ap.add_argument("--profile-steps", type=int, default=0, help="roofline leg length; 0 = 2 full simulator blocks")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path with several ranks sharing one GPU (RCCL needs one GPU per rank)")
@@ -82,6 +84,8 @@ def main():
     from sspslam_amd.sharding import ShardedPathIntegration
 
     dt = 0.001
+    if args.profile_steps <= 0:
+        args.profile_steps = 2 * args.sim_block
     n_total = (args.steps + args.warmup) * args.block
     T_path = max(20.0, (n_total + args.profile_steps + 10) * dt)
     space = H.make_ssp_space(2, args.ssp_dim)
@@ -98,7 +102,7 @@ def main():
     t0 = time.time()
     if world == 1:
         model = build(pm.model, dt=dt, n_eval_points=args.eval_points)
-        sim = Simulator(None, model=model, dtype=args.dtype, device=local_rank)
+        sim = Simulator(None, model=model, dtype=args.dtype, device=local_rank, block_steps=args.sim_block)
         runner = None
     else:
         # ranks that share a GPU (rehearsal only) build one after the other: concurrent rocSOLVER use from
@@ -108,7 +112,7 @@ def main():
         for turn in range(world if shared else 1):
             if not shared or turn == rank:
                 runner = ShardedPathIntegration(pm, rank, world, dt=dt, dtype=args.dtype, device=local_rank,
-                                                n_eval_points=args.eval_points, block=args.block)
+                                                n_eval_points=args.eval_points, block=args.block, block_steps=args.sim_block)
             if shared:
                 dist.barrier()
         sim, model = runner.sim, runner.model

@@ -111,7 +111,7 @@ typedef struct ssn_model_desc {
   int32_t n_core_to_post;
   const ssn_range* pre_to_core;
   const ssn_range* core_to_post;
-  int32_t block_steps;                /* timesteps per time-batched block; 0 = library default (256) */
+  int32_t block_steps;                /* timesteps per time-batched block; 0 = library default (1024, or 256 for very wide models) */
   int32_t flags;                      /* debug / A-B switches: 1 = no fused recurrent-array core (generic programs),
                                          2 = no LIF fast path (unpacked state, dense row-major decoders),
                                          4 = LIF fast path with dense decoders (no spike-sparse gather),

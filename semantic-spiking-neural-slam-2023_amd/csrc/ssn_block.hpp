@@ -376,7 +376,7 @@ template <typename T>
 bool ens_block_supported(int din, int dout, int n, int* threads, int* tpb, int* npt, int* enc_lds) {
   if (!(din == 3 && dout >= 3 && dout <= 5)) return false;
   struct V { int tpb, npt, lds; };
-  const V f32v[] = {{1024, 2, 0}, {1024, 4, 0}, {1024, 6, 0}, {1024, 10, 1}, {768, 14, 1}, {512, 20, 1}, {256, 40, 0}, {512, 16, 0}, {512, 20, 0}};
+  const V f32v[] = {{1024, 2, 0}, {1024, 4, 0}, {1024, 6, 0}, {512, 20, 1}, {1024, 10, 1}, {768, 14, 1}, {256, 40, 0}, {512, 16, 0}, {512, 20, 0}};
   const V f64v[] = {{1024, 1, 0}, {1024, 2, 0}, {1024, 4, 0}};
   const V* vs = sizeof(T) == 4 ? f32v : f64v;
   const int nv = sizeof(T) == 4 ? 9 : 3;

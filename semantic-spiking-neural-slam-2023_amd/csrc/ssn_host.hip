@@ -472,7 +472,8 @@ struct Sim final : ssn_sim {
     for (auto& p : probes) staged = staged || p.stage != 1;
     batched_mask.assign((size_t)n_sig, 0);
     if (staged) {
-      block = m->block_steps > 0 ? m->block_steps : 256;
+      // default: 1024 timesteps per block while the block buffer stays under 256 MiB, else 256
+      block = m->block_steps > 0 ? m->block_steps : ((int64_t)1025 * n_sig * (int64_t)sizeof(T) <= (256ll << 20) ? 1024 : 256);
       CHK(dmalloc(&bsig, (int64_t)(block + 1) * n_sig * (int64_t)sizeof(T)));
       CHK(init_bsig());
       pre_to_core.assign(m->pre_to_core, m->pre_to_core + m->n_pre_to_core);

@@ -940,11 +940,70 @@ __global__ __launch_bounds__(256) void kb_gemm(BatchOp<T> o) {
     }
 }
 
+// f32 GEMM on the matrix cores: v_mfma_f32_32x32x2_f32 takes f32 operands and accumulates an exact f32 FMA
+// chain (MI355X_MICROARCH.md: the f32 MFMA rate equals the packed-FMA vector peak, but needs no register
+// blocking to get there).  64 x 64 output tile per 256-thread workgroup (4 waves x one 32x32 accumulator),
+// K in slabs of 32 through LDS, next slab prefetched into registers while the current one is multiplied.
+// Operand lanes: A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31]; result: col = l & 31,
+// row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5)  (cdna_hip_programming.md, MFMA layouts).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int BK>
+__global__ __launch_bounds__(256) void kb_gemm_mfma_f32(BatchOp<float> o) {
+  __shared__ float As[64][BK + 1];
+  __shared__ float Ws[64][BK + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int t0 = blockIdx.y * 64, r0 = blockIdx.x * 64;
+  const float* __restrict__ A = o.bsig + (size_t)(1 - o.src_prev) * o.n_sig + o.src;
+  const float* __restrict__ Wm = (const float*)o.p0;
+  const int rows = (int)o.len, cols = o.cols;
+  const int lr = tid >> 5, lc = tid & 31;          // this thread stages rows lr + 8 i (i = 0..7), column lc of a slab
+  float ra[8], rw[8];
+  auto fetch = [&](int k0) {
+    const int c = k0 + lc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = t0 + lr + 8 * i, r = r0 + lr + 8 * i;
+      ra[i] = (t < o.B && c < cols) ? A[(size_t)t * o.n_sig + c] : 0.0f;
+      rw[i] = (r < rows && c < cols) ? Wm[(size_t)r * o.ld + c] : 0.0f;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+  fetch(0);
+  for (int k0 = 0; k0 < cols; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { As[lr + 8 * i][lc] = ra[i]; Ws[lr + 8 * i][lc] = rw[i]; }
+    __syncthreads();
+    if (k0 + BK < cols) fetch(k0 + BK);
+    const float* ap = &As[wm * 32 + (lane & 31)][lane >> 5];
+    const float* wp = &Ws[wn * 32 + (lane & 31)][lane >> 5];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], wp[kk], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  const int r = r0 + wn * 32 + (lane & 31);
+  if (r < rows) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int t = t0 + wm * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+      if (t < o.B) {
+        float* d = o.bsig + (size_t)(t + 1) * o.n_sig + o.dst + r;
+        if (o.kind == M_MATVEC_SET) *d = acc[v]; else *d += acc[v];
+      }
+    }
+  }
+}
+
 template <typename T>
 hipError_t launch_batch_op(hipStream_t s, const BatchOp<T>& o) {
   if (o.B <= 0 || o.len <= 0) return hipSuccess;
   if (o.kind == M_LOWPASS) {
     hipLaunchKernelGGL((kb_lowpass<T>), dim3((unsigned)((o.len + 63) / 64)), dim3(64), 0, s, o);
+  } else if ((o.kind == M_MATVEC_INC || o.kind == M_MATVEC_SET) && sizeof(T) == 4 && o.cols >= 64 && o.len >= 32 && o.B >= 32) {
+    if constexpr (sizeof(T) == 4)
+      hipLaunchKernelGGL((kb_gemm_mfma_f32<32>), dim3((unsigned)((o.len + 63) / 64), (unsigned)((o.B + 63) / 64)), dim3(256), 0, s, o);
   } else if (o.kind == M_MATVEC_INC || o.kind == M_MATVEC_SET) {
     hipLaunchKernelGGL((kb_gemm<T>), dim3((unsigned)((o.len + 31) / 32), (unsigned)((o.B + 31) / 32)), dim3(256), 0, s, o);
   } else {

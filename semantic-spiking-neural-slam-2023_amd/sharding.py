@@ -51,7 +51,8 @@ class _BlockFeed:
 
 class ShardedPathIntegration:
     def __init__(self, pm, rank, world, dt=0.001, dtype="f32", device=0, n_eval_points=None, block=1000,
-                 sim_factory=None, dist=None, gather_device=None, async_readout=True):
+                 sim_factory=None, dist=None, gather_device=None, async_readout=True, block_steps=0,
+                 device_exchange=None):
         """``pm``: object from ``harness.make_pathint_model`` (model, pathintegrator, probe)."""
         if dist is None:
             import torch.distributed as dist
@@ -64,8 +65,10 @@ class ShardedPathIntegration:
             from .simulator import Simulator
 
             def sim_factory(model):
-                return Simulator(None, model=model, dtype=dtype, device=device)
+                return Simulator(None, model=model, dtype=dtype, device=device, block_steps=block_steps)
         self.gather_device = gather_device
+        self.dtype = dtype
+        self.device_exchange = device_exchange     # None: automatic (RCCL backend + HIP simulator); True/False: forced
         # --- this rank's VCO shard: probe = local slice of the oscillator output node ----------------
         with pm.model:
             width = 3 * (self.hi - self.lo)
@@ -107,9 +110,48 @@ class ShardedPathIntegration:
             self._warm = True
 
     def _replay(self, full, first, n):
+        if not isinstance(full, np.ndarray):
+            # device path: the gathered block is already in HBM in the simulator's dtype - it becomes the
+            # read-out's input table without a host round trip
+            self.readout.prepare_tables_device({0: (full.data_ptr(), n, np.arange(n, dtype=np.int32))}, n)
+            self.readout.run_steps(n)
+            return
         self.feed.rows, self.feed.first = np.ascontiguousarray(full), first
         self.readout.prepare(n)
         self.readout.run_steps(n)
+
+    def _device_exchange(self):
+        """True when the block exchange can stay in HBM: RCCL backend and the HIP simulator (not the test double)."""
+        if not hasattr(self.sim, "read_probe_device") or self.gather_device is not None or self.device_exchange is False:
+            return False
+        if self.device_exchange:
+            return True
+        return self.world > 1 and self.dist.is_initialized() and self.dist.get_backend() == "nccl"
+
+    def _gather_device(self, n):
+        """This rank's last n osc samples (device) -> (n, 3K) device tensor on every rank, one all-gather."""
+        import torch
+        tdt = torch.float32 if self.dtype == "f32" else torch.float64
+        dev = torch.device("cuda", torch.cuda.current_device())
+        width = 3 * (self.hi - self.lo)
+        send = torch.zeros((n, 3 * self.per), dtype=tdt, device=dev)
+        torch.cuda.current_stream().synchronize()      # the simulator copies on its own stream
+        if width:
+            have = self.sim.probe_count(self.osc_probe)
+            if width == 3 * self.per:
+                self.sim.read_probe_device(self.osc_probe, send.data_ptr(), have - n, n)
+            else:
+                tmp = torch.empty((n, width), dtype=tdt, device=dev)
+                self.sim.read_probe_device(self.osc_probe, tmp.data_ptr(), have - n, n)
+                send[:, :width] = tmp
+        out = torch.empty((self.world, n, 3 * self.per), dtype=tdt, device=dev)
+        if self.dist.is_initialized():
+            self.dist.all_gather_into_tensor(out, send)
+        else:                                          # single process (tests): nothing to exchange
+            out[0] = send
+        full = out.permute(1, 0, 2).reshape(n, self.world * 3 * self.per)[:, :3 * self.K].contiguous()
+        torch.cuda.current_stream().synchronize()      # the read-out simulator runs on its own HIP stream
+        return full
 
     def _readout_loop(self):
         while True:
@@ -149,6 +191,18 @@ class ShardedPathIntegration:
 
     def run_block(self, n=None):
         n = self.block if n is None else int(n)
+        if self._device_exchange():
+            self.sim.run_steps(n, collect=False)
+            full = self._gather_device(n)
+            if self.readout is not None:
+                if self._jobs is not None:
+                    if self._error is not None:
+                        self.flush()
+                    self._jobs.put((full, self.n_steps, n))
+                else:
+                    self._replay(full, self.n_steps, n)
+            self.n_steps += n
+            return
         self.sim.run_steps(n, collect=True)
         if self.osc_probe is not None:
             local = self.sim.probe_tail(self.osc_probe, n)

@@ -246,6 +246,26 @@ class Simulator:
         self._fetched = {}               # sample counts restart with the new reservation
         self._prepared_until = first + n_steps
 
+    def prepare_tables_device(self, tables, n_steps):
+        """Like ``prepare`` for inputs that are already in HBM (multi-GPU exchange): ``tables`` maps table id ->
+        (device pointer to rows [n_rows][width] in the simulator's dtype, n_rows, int32 row index per step)."""
+        n_steps = int(n_steps)
+        if getattr(self, "_uncollected", False):
+            self._collect()
+        first = self.n_steps
+        if set(tables) != set(range(len(self.model.tables))):
+            raise fe.SimulationError("prepare_tables_device needs every table of the model")
+        for tid, (ptr, n_rows, idx) in tables.items():
+            self.set_table_device(tid, ptr, n_rows, idx, first)
+        self._check(self._lib.ssn_reserve_probes(self._h, n_steps))
+        self._fetched = {}
+        self._prepared_until = first + n_steps
+
+    def probe_count(self, probe):
+        """Samples of a signal probe held on the device in the current reservation."""
+        kind, j, p = self._probe_index[probe]
+        return int(self._lib.ssn_probe_count(self._h, j))
+
     def set_table_device(self, table_id, rows_dev_ptr, n_rows, idx, first_step):
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         tb = self.model.tables[table_id]

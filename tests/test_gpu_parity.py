@@ -271,6 +271,36 @@ def test_sharded_runner_on_hip_matches_unsharded(Simulator):
     r.close()
 
 
+def test_sharded_runner_device_exchange(Simulator):
+    """The all-device block exchange (probe -> RCCL all-gather -> read-out table, no host copies) on a
+    single-rank RCCL group: same read-out as the oracle."""
+    import torch.distributed as dist
+    from sspslam_amd.sharding import ShardedPathIntegration
+    pm = small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2)
+    model = build(pm.model)
+    ref = OracleSimulator(model)
+    ref.run_steps(300)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1)
+        created = True
+    try:
+        for dtype, tol in (("f64", 1e-9), ("f32", None)):
+            pm2 = small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2)
+            r = ShardedPathIntegration(pm2, 0, 1, dtype=dtype, block=128, device_exchange=True)
+            r.prepare(300)
+            r.run_steps(300)
+            got = r.probe_data()
+            if tol:
+                np.testing.assert_allclose(got, ref.probe_data(0), atol=tol, rtol=0)
+            else:
+                assert H.cosine_error(got[20:], ref.probe_data(0)[20:]).max() < 1e-3
+            r.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_fused_recurrent_core_equals_generic_path(Simulator):
     """The fused [k_ensarray prologue + k_ens_finish] core and the generic program path are two plans of
     the same operators: identical trajectories (f64), incl. multi-chunk ensembles (n > 1024)."""
