@@ -21,5 +21,9 @@ for l in body[lo:hi]:
         continue
     c[l.split()[0]] += 1
 print("instructions per timestep (one wave):", sum(c.values()), " scratch ops:", sum(v for k, v in c.items() if k.startswith("scratch")))
+trans = ("v_rcp", "v_log", "v_exp", "v_rsq", "v_sqrt", "v_sin", "v_cos")
+valu = sum(v for k, v in c.items() if k.startswith("v_"))
+slots = sum(v * (2 if k.startswith(trans) else 1) for k, v in c.items() if k.startswith("v_"))
+print("VALU instructions %d, issue slots of 4 cycles %d (transcendentals count 2: 8-cycle issue, MI355X_MICROARCH.md)" % (valu, slots))
 for k, v in c.most_common(40):
     print("  %-28s %d" % (k, v))
