@@ -112,7 +112,7 @@ __device__ inline f32x2 lif_packed_step_f32x2(f32x2 J, f32x2& s, const LifConstF
 
 // Neurons are dealt to threads in groups of PK adjacent neurons (PK = 2 for f32: one 64-bit register pair,
 // 1 for f64): neuron index of (group g, thread tid, component c) = (g * nthr + tid) * PK + c - coalesced.
-template <typename T, int DIN, int DOUT, int NPT, int TPB, bool ENC_LDS>
+template <typename T, int DIN, int DOUT, int NPT, int TPB, bool ENC_LDS, bool CLUSTER>
 __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   extern __shared__ __align__(16) unsigned char ssn_block_dyn[];
   T* const e_lds = reinterpret_cast<T*>(ssn_block_dyn);       // ENC_LDS: encoders [DIN][nthr * NPT]
@@ -122,7 +122,16 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   static_assert(NPT % PK == 0, "f32 variants handle neuron pairs");
   using G = typename std::conditional<F32, f32x2, T>::type;   // one group of neurons
   constexpr int DP = DOUT <= 4 ? 4 : 8;
-  const int k = blockIdx.x;
+  // Cluster mode (a.P > 1, few ensembles per GPU): P workgroups share one ensemble's neurons and exchange their
+  // partial sums once per timestep.  Members of a cluster get block indices that are equal mod 8, i.e. land on
+  // one XCD under round-robin placement (a speed bonus for the exchange, never needed for correctness).
+  int k = blockIdx.x, p = 0;
+  if (CLUSTER && a.P > 1) {
+    const int b8 = blockIdx.x / (8 * a.P), rem = blockIdx.x - b8 * 8 * a.P;
+    k = b8 * 8 + (rem & 7);
+    p = rem >> 3;
+    if (k >= a.K) return;                                  // padding of the last group of 8 ensembles
+  }
   const int tid = threadIdx.x;
   const int nthr = NG == 1 ? (int)blockDim.x : TPB;       // variants with more than one group always run full workgroups
   const int lane = tid & 63, wave = tid >> 6;
@@ -143,12 +152,13 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   for (int g = 0; g < NG; ++g) {
 #pragma unroll
     for (int c = 0; c < PK; ++c) {
-      const int i = (g * nthr + tid) * PK + c;
+      const int li = (g * nthr + tid) * PK + c;          // index inside this workgroup's share
+      const int i = p * cap + li;
       const bool ok = i < a.n;
 #pragma unroll
       for (int d = 0; d < DIN; ++d) {
         const T ev = ok ? enc[d * row + i] : T(0);
-        if constexpr (ENC_LDS) e_lds[d * cap + i] = ev; else comp(e[g][d], c) = ev;
+        if constexpr (ENC_LDS) e_lds[d * cap + li] = ev; else comp(e[g][d], c) = ev;
       }
       comp(b[g], c) = ok ? bias[i] : T(0);
       comp(s[g], c) = ok ? Sp[i] : T(0);
@@ -191,6 +201,9 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   __shared__ T os[CH][DOUT];
   __shared__ int s_dst[DOUT];
   __shared__ int s_out[DOUT];
+  constexpr int PMAX = 4;                    // largest cluster
+  constexpr int GV = sizeof(T) / 4;          // 32-bit payload words per value (exchange granule = {payload, tag})
+  __shared__ unsigned int xt[2][CLUSTER ? PMAX * DOUT * GV : 1];
   for (int i = tid; i < 2 * RW; i += nthr) (&red[0][0])[i] = T(0);     // waves that do not exist add 0
   if (tid < DOUT) { s_dst[tid] = a.didx[(long long)k * DOUT + tid]; s_out[tid] = a.rowout[(long long)k * DOUT + tid] ? 1 : 0; }
   const T* __restrict__ xbase = a.xrows + (size_t)a.row0 * a.n_sig + a.x_off + (long long)k * DIN;
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
     if (j0 > 0) {                            // hand the previous chunk's decoded rows to the post stage
       for (int i = tid; i < CH * DOUT; i += nthr) {
         const int jj = i / DOUT, r = i - jj * DOUT;
-        if (s_out[r]) a.bsig[(size_t)(a.row0 + j0 - CH + jj) * a.n_sig + s_dst[r]] = os[jj][r];
+        if (s_out[r] && p == 0) a.bsig[(size_t)(a.row0 + j0 - CH + jj) * a.n_sig + s_dst[r]] = os[jj][r];
       }
     }
     for (int i = tid; i < cn * DIN; i += nthr) {
@@ -298,6 +311,50 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
           tot[r] = t;
         }
       }
+      if (CLUSTER && a.P > 1) {
+        // ---- cluster exchange: publish this workgroup's partial sums as 8-byte {payload, tag = step} granules
+        //      (one atomic store each: data and flag arrive together), collect the P partials of the step, add
+        //      them in member order - every member ends up with bit-identical totals.  Two parities of slots:
+        //      a member can only publish step t+2 after every other member has read its step-t granules.
+        const unsigned int tag = (unsigned int)(a.step0 + j0 + jj + 1);
+        unsigned long long* slot = a.xch + (((size_t)k * 2 + par) * PMAX) * (DOUT * GV);
+        const int nmine = DOUT * GV, nall = a.P * DOUT * GV;
+        if (wave == 0) {
+          if (lane < nmine) {
+            const int r = lane / GV, w = lane - r * GV;
+            T v = T(0);
+#pragma unroll
+            for (int q = 0; q < DOUT; ++q) v = r == q ? tot[q] : v;
+            unsigned int bits;
+            if constexpr (GV == 1) bits = __builtin_bit_cast(unsigned int, v);
+            else { const unsigned long long u = __builtin_bit_cast(unsigned long long, v); bits = w ? (unsigned int)(u >> 32) : (unsigned int)u; }
+            __hip_atomic_store(slot + p * nmine + lane, ((unsigned long long)tag << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (lane < nall) {
+            unsigned long long gr = 0;
+            int spins = 0;
+            for (;;) {
+              gr = __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if ((unsigned int)(gr >> 32) == tag) break;
+              if (++spins > (1 << 22)) { *a.err = 1; break; }          // a missing member: give up, the host reports it
+              __builtin_amdgcn_s_sleep(1);
+            }
+            xt[par][lane] = (unsigned int)gr;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < DOUT; ++r) {
+          T t = T(0);
+          for (int q = 0; q < a.P; ++q) {
+            T v;
+            if constexpr (GV == 1) v = __builtin_bit_cast(T, xt[par][q * nmine + r]);
+            else v = __builtin_bit_cast(T, ((unsigned long long)xt[par][q * nmine + r * GV + 1] << 32) | xt[par][q * nmine + r * GV]);
+            t += v;
+          }
+          tot[r] = t;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < DOUT; ++r) fs[r] = la[r] * fs[r] + lb[r] * tot[r];    // rows without a filter: la = lb = 0
       if (tid < DOUT) {
@@ -313,7 +370,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
     const int j0 = (a.B - 1) / CH * CH, cn = a.B - j0;
     for (int i = tid; i < cn * DOUT; i += nthr) {
       const int jj = i / DOUT, r = i - jj * DOUT;
-      if (s_out[r]) a.bsig[(size_t)(a.row0 + j0 + jj) * a.n_sig + s_dst[r]] = os[jj][r];
+      if (s_out[r] && p == 0) a.bsig[(size_t)(a.row0 + j0 + jj) * a.n_sig + s_dst[r]] = os[jj][r];
     }
   }
 
@@ -324,11 +381,11 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   for (int g = 0; g < NG; ++g) {
 #pragma unroll
     for (int c = 0; c < PK; ++c) {
-      const int i = (g * nthr + tid2) * PK + c;
+      const int i = p * cap + (g * nthr + tid2) * PK + c;
       if (i < a.n) Sp[i] = comp(s[g], c);
     }
   }
-  if (tid < DOUT && a.B > 0) {
+  if (tid < DOUT && a.B > 0 && p == 0) {
     T v = T(0), f = T(0);
 #pragma unroll
     for (int r = 0; r < DOUT; ++r) { v = tid == r ? tot[r] : v; f = tid == r ? fs[r] : f; }
@@ -341,17 +398,24 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
 // (workgroup size, neurons per thread, encoders in LDS) variants.  The register budget of a wave is
 // 512 / (waves per SIMD): 1024 threads -> 128 registers, 512 -> 256, 256 -> 512 (incl. AGPRs); a neuron needs
 // din + dout + 2 persistent words (10 at din 3, dout 5), 7 with the encoders in LDS.
-template <typename T, int DIN, int DOUT, int NPT, int TPB, bool ENC_LDS>
+template <typename T, int DIN, int DOUT, int NPT, int TPB, bool ENC_LDS, bool CLUSTER = false>
 static hipError_t launch_block_variant(hipStream_t s, const BlockArgs<T>& a) {
+  // cluster mode is compiled only for the variants a shard of a big ensemble lands on (and the f64 test sizes)
+  constexpr bool HAS_CLUSTER = !ENC_LDS && ((sizeof(T) == 8) || (TPB == 512 && (NPT == 6 || NPT == 10)));
+  if constexpr (!CLUSTER && HAS_CLUSTER) {
+    if (a.P > 1) return launch_block_variant<T, DIN, DOUT, NPT, TPB, ENC_LDS, true>(s, a);
+  }
+  if (!CLUSTER && a.P > 1) return hipErrorInvalidValue;
   const int lds = ENC_LDS ? DIN * a.threads * NPT * (int)sizeof(T) : 0;
   static bool configured = false;
   if (ENC_LDS && !configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ens_block<T, DIN, DOUT, NPT, TPB, ENC_LDS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ens_block<T, DIN, DOUT, NPT, TPB, ENC_LDS, CLUSTER>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DIN * TPB * NPT * (int)sizeof(T));
     if (e != hipSuccess) return e;
     configured = true;
   }
-  hipLaunchKernelGGL((k_ens_block<T, DIN, DOUT, NPT, TPB, ENC_LDS>), dim3((unsigned)a.K), dim3((unsigned)a.threads), lds, s, a);
+  const unsigned grid = a.P > 1 ? (unsigned)((a.K + 7) / 8 * 8 * a.P) : (unsigned)a.K;
+  hipLaunchKernelGGL((k_ens_block<T, DIN, DOUT, NPT, TPB, ENC_LDS, CLUSTER>), dim3(grid), dim3((unsigned)a.threads), lds, s, a);
   return hipGetLastError();
 }
 
@@ -366,7 +430,7 @@ static hipError_t launch_block_npt(hipStream_t s, const BlockArgs<T>& a) {
     SSN_CASE(1024, 1, 0)
 #undef SSN_CASE
 #define SSN_CASE(TPB, N, L) case (TPB * 100 + N) * 2 + L: if constexpr (sizeof(T) == 4) return launch_block_variant<T, DIN, DOUT, N, TPB, (L != 0)>(s, a); else return hipErrorInvalidValue;
-    SSN_CASE(1024, 6, 0) SSN_CASE(1024, 10, 1) SSN_CASE(768, 14, 1) SSN_CASE(512, 16, 0) SSN_CASE(512, 20, 0) SSN_CASE(512, 20, 1) SSN_CASE(256, 40, 0)
+    SSN_CASE(1024, 6, 0) SSN_CASE(512, 6, 0) SSN_CASE(512, 10, 0) SSN_CASE(1024, 10, 1) SSN_CASE(768, 14, 1) SSN_CASE(512, 16, 0) SSN_CASE(512, 20, 0) SSN_CASE(512, 20, 1) SSN_CASE(256, 40, 0)
 #undef SSN_CASE
     default: return hipErrorInvalidValue;
   }
@@ -376,10 +440,10 @@ template <typename T>
 bool ens_block_supported(int din, int dout, int n, int* threads, int* tpb, int* npt, int* enc_lds) {
   if (!(din == 3 && dout >= 3 && dout <= 5)) return false;
   struct V { int tpb, npt, lds; };
-  const V f32v[] = {{1024, 2, 0}, {1024, 4, 0}, {1024, 6, 0}, {512, 20, 1}, {1024, 10, 1}, {768, 14, 1}, {256, 40, 0}, {512, 16, 0}, {512, 20, 0}};
+  const V f32v[] = {{1024, 2, 0}, {1024, 4, 0}, {512, 6, 0}, {1024, 6, 0}, {512, 10, 0}, {512, 20, 1}, {1024, 10, 1}, {768, 14, 1}, {256, 40, 0}, {512, 16, 0}, {512, 20, 0}};
   const V f64v[] = {{1024, 1, 0}, {1024, 2, 0}, {1024, 4, 0}};
   const V* vs = sizeof(T) == 4 ? f32v : f64v;
-  const int nv = sizeof(T) == 4 ? 9 : 3;
+  const int nv = sizeof(T) == 4 ? 11 : 3;
   int want_tpb = 0, want_npt = 0, want_lds = 0;
   if (const char* env = getenv("SSN_BLOCK_VARIANT")) sscanf(env, "%d,%d,%d", &want_tpb, &want_npt, &want_lds);   // tuning knob
   for (int i = 0; i < nv; ++i) {

@@ -131,6 +131,7 @@ struct Sim final : ssn_sim {
   ssn::FinishArgs<T> fin_begin, fin_flush;
   bool fused_block = false;                   // ... stepped a whole block per launch: [k_ens_block] (ssn_block.hpp)
   ssn::BlockArgs<T> blk;
+  int64_t blk_xch_bytes = 0;
   std::vector<void*> fused_bufs;
   std::set<int> sparse_w;                     // decoder buffers multiplied with a LIF spike vector
   std::vector<std::pair<int64_t, std::pair<int*, int*>>> spike_lists;   // spike signal offset -> (list, count)
@@ -611,8 +612,26 @@ struct Sim final : ssn_sim {
     }
     // ---- plan A: the ensembles are independent inside a block -> one k_ens_block launch per block -----
     int blk_threads = 0, blk_tpb = 0, blk_npt = 0, blk_lds = 0;
+    // cluster size: with few ensembles per GPU (multi-GPU shards) P workgroups could split one ensemble's neurons
+    // (every workgroup of the grid must then be resident at once: they wait for each other every timestep)
+    int blk_P = 1;
+    {
+      hipDeviceProp_t prop;
+      int n_cu = 256;
+      if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+      const int64_t k8 = (K + 7) / 8 * 8;
+      // Measured on MI355X (tools/bench_shard.py, 127- and 64-VCO shards of config 2): one workgroup per VCO
+      // 2.95 us/step, P = 2: 3.3, P = 4: 3.6 - the per-step exchange (~1.6 us) costs more than the halved neuron
+      // work saves, so clusters are never chosen automatically.
+      if (const char* env = getenv("SSN_BLOCK_CLUSTER")) {           // experiment / test knob
+        const int want = atoi(env);
+        if ((want == 1 || want == 2 || want == 4) && k8 * want <= n_cu) blk_P = want;
+      }
+    }
+    const int pk = sizeof(T) == 4 ? 2 : 1;
+    const int n_share = (int)(((eo.i[2] + blk_P - 1) / blk_P + pk - 1) / pk * pk);
     if (defer && !(flags & 128) && ens_fast(eo) && (sizeof(T) == 8 || (dt <= 0.125 * eo.f[0] && eo.f[1] >= dt)) &&
-        ssn::ens_block_supported<T>((int)din, (int)dout, (int)eo.i[2], &blk_threads, &blk_tpb, &blk_npt, &blk_lds)) {
+        ssn::ens_block_supported<T>((int)din, (int)dout, n_share, &blk_threads, &blk_tpb, &blk_npt, &blk_lds)) {
       const int64_t nr = K * dout;
       int* d_lp = nullptr; T* d_a = nullptr; T* d_b = nullptr; unsigned char* d_ro = nullptr; int* d_xrow = nullptr; T* d_xalpha = nullptr;
       if ((*rc = dmalloc(&d_lp, nr * 4)) != SSN_OK) return true;
@@ -640,6 +659,18 @@ struct Sim final : ssn_sim {
       blk.B = 0; blk.row0 = 1; blk.threads = blk_threads; blk.tpb = blk_tpb; blk.npt = blk_npt; blk.enc_lds = blk_lds;
       blk.dec_neuron_major = ea.fast == 1 ? 1 : 0;
       blk.np = ea.np;
+      blk.P = blk_P; blk.step0 = 0;
+      if (blk_P > 1 && (int64_t)blk_threads * blk_npt * blk_P < ea.n) return false;      // (single-group variants shrink the workgroup)
+      {
+        const int64_t xb = (int64_t)K * 2 * 4 * dout * (int64_t)(sizeof(T) / 4) * 8;
+        unsigned long long* d_x = nullptr; int* d_err = nullptr;
+        if ((*rc = dmalloc(&d_x, xb)) != SSN_OK) return true;
+        if ((*rc = dmalloc(&d_err, 64)) != SSN_OK) return true;
+        hipMemset(d_x, 0, (size_t)xb);
+        hipMemset(d_err, 0, 64);
+        fused_bufs.insert(fused_bufs.end(), {(void*)d_x, (void*)d_err});
+        blk.xch = d_x; blk.err = d_err; blk_xch_bytes = xb;
+      }
       dom_units = (int64_t)ea.K * ea.n * block;
       dom_bytes = (double)dom_units * (ea.din + ea.dout + 5) * sizeof(T);
       fused_core = fused_block = true;
@@ -1179,6 +1210,7 @@ struct Sim final : ssn_sim {
       if (fused_block) {
         const bool timed = profile && B == block && ev_used + 2 <= ev_pool.size();
         blk.B = (int)B;
+        blk.step0 = step0;
         if (timed) HIPCHK(hipEventRecord(ev_pool[ev_used], stream));
         HIPCHK(ssn::launch_ens_block<T>(stream, blk));
         if (timed) { HIPCHK(hipEventRecord(ev_pool[ev_used + 1], stream)); ev_used += 2; }
@@ -1224,6 +1256,11 @@ struct Sim final : ssn_sim {
     ssn::StepCtx ctx;
     HIPCHK(hipMemcpy(&ctx, d_ctx, sizeof ctx, hipMemcpyDeviceToHost));
     if (ctx.step != steps_done) return fail(SSN_EHIP, "device step counter %lld != host %lld", (long long)ctx.step, (long long)steps_done);
+    if (fused_block && blk.P > 1) {
+      int err = 0;
+      HIPCHK(hipMemcpy(&err, blk.err, 4, hipMemcpyDeviceToHost));
+      if (err) return fail(SSN_EHIP, "k_ens_block: a workgroup of a %d-workgroup cluster never arrived (grid not fully resident?)", blk.P);
+    }
     if (ctx.probe_overflow) return fail(SSN_EINVAL, "probe storage overflow: call ssn_reserve_probes before ssn_run_steps");
     return SSN_OK;
   }
@@ -1235,6 +1272,7 @@ struct Sim final : ssn_sim {
     for (auto& b : bufs)
       if (b.keep) CHK(upload_buf(b, b.host.data()));
     HIPCHK(hipMemset(d_ctx, 0, sizeof(ssn::StepCtx)));
+    if (fused_block && blk.xch) HIPCHK(hipMemset(blk.xch, 0, (size_t)blk_xch_bytes));     // exchange tags restart with the clock
     CHK(init_bsig());
     steps_done = 0;
     reserve_first = reserve_n = 0;

@@ -106,6 +106,10 @@ struct BlockArgs {
   int threads, tpb, npt;   // workgroup size, kernel variant (launch bound, neurons per thread): threads * npt >= n
   int dec_neuron_major;
   int enc_lds;         // kernel variant keeps the encoders in LDS instead of registers
+  int P;               // workgroups per ensemble (cluster mode when > 1; n <= P * threads * npt)
+  long long step0;     // absolute number of the launch's first timestep (exchange tags)
+  unsigned long long* xch;   // cluster exchange granules [K][2][4][dout * sizeof(T)/4]
+  int* err;            // set to 1 when a cluster member never showed up
   NeuronParams<T> np;
 };
 

@@ -336,6 +336,36 @@ def test_fused_recurrent_core_equals_generic_path(Simulator):
         np.testing.assert_allclose(got_v, np.asarray(ref.buf[v_buf]).reshape(got_v.shape), atol=1e-9, rtol=0)
 
 
+def test_block_kernel_cluster_mode(Simulator):
+    """Cluster mode of k_ens_block (multi-GPU shards with few VCOs per GPU): 2 or 4 workgroups share one VCO's
+    neurons and exchange partial sums every timestep through tagged 8-byte granules."""
+    import os
+    pm = small_pathint(ssp_dim=55, n=2500, T=10.0, limit=0.2)
+    model = build(pm.model, n_eval_points=600)
+    ref = OracleSimulator(model)
+    ref.run_steps(300)
+    v_buf = next(o for o in model.ops if o["kind"] == "ensarray")["v"]
+    try:
+        for P in (2, 4):
+            os.environ["SSN_BLOCK_CLUSTER"] = str(P)
+            with Simulator(None, model=model, dtype="f64", block_steps=96) as sim:
+                sim.run_steps(150)
+                sim.run_steps(150)
+                assert sim.counters()["launches_per_step"] == 0
+                np.testing.assert_allclose(sim.data[pm.probe], ref.probe_data(0), atol=1e-9, rtol=0)
+                got_v = sim.read_buffer(v_buf)
+                np.testing.assert_allclose(got_v, np.asarray(ref.buf[v_buf]).reshape(got_v.shape), atol=1e-9, rtol=0)
+                sim.reset()                                   # exchange tags restart with the clock
+                sim.run_steps(300)
+                np.testing.assert_allclose(sim.data[pm.probe][-300:], ref.probe_data(0), atol=1e-9, rtol=0)
+            with Simulator(None, model=model, dtype="f32", block_steps=96) as sim:
+                sim.run_steps(300)
+                ce = H.cosine_error(sim.data[pm.probe][20:], ref.probe_data(0)[20:])
+                assert ce.max() < 1e-3, (P, ce.max())
+    finally:
+        os.environ.pop("SSN_BLOCK_CLUSTER", None)
+
+
 def test_block_kernel_variants_f32(Simulator):
     """k_ens_block register/LDS variants (neurons per thread 1..6 by size; forced ones through the tuning knob)
     against the per-timestep kernel: f32, short window, cosine bar."""

@@ -1,5 +1,6 @@
 """Per-rank step time of the VCO-sharded path integrator, measured on one GPU: builds shard `rank` of `world`
-of the config-2 model and times its core (no exchange, no read-out).  usage: bench_shard.py world [flags...]"""
+of the config-2 model and times its core (no exchange, no read-out).  usage: bench_shard.py world [flags...]
+A flag value >= 1000 means: flags 0 with SSN_BLOCK_CLUSTER = value - 1000 (workgroups per VCO)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,11 +23,16 @@ t0 = time.time()
 model = build(pm.model, n_eval_points=1000, vco_shard=(0, world), probes=[p], prune=True)
 print("shard 0/%d: VCOs [%d,%d) built in %.1fs" % (world, lo, hi, time.time() - t0), flush=True)
 for flags in flag_list:
+    os.environ.pop("SSN_BLOCK_CLUSTER", None)
+    if flags >= 1000:
+        os.environ["SSN_BLOCK_CLUSTER"] = str(flags - 1000)
+    tag = flags
+    flags = 0 if flags >= 1000 else flags
     sim = Simulator(None, model=model, dtype="f32", flags=flags)
     sim.prepare(6000)
     sim.run_steps(1000, collect=False)
     t0 = time.perf_counter(); sim.run_steps(4000, collect=False); el = time.perf_counter() - t0
     c = sim.counters()
-    print("flags %2d: %.2f us/step (device %.2f), launches/step %d -> %.1f sim-s/wall-s per rank" %
-          (flags, el / 4000 * 1e6, c["last_run_ms"] / 4000 * 1e3, c["launches_per_step"], 4.0 / el), flush=True)
+    print("flags %4d: %.2f us/step (device %.2f), launches/step %d -> %.1f sim-s/wall-s per rank" %
+          (tag, el / 4000 * 1e6, c["last_run_ms"] / 4000 * 1e3, c["launches_per_step"], 4.0 / el), flush=True)
     sim.close()
