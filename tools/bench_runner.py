@@ -7,7 +7,8 @@ from sspslam_amd.sharding import ShardedPathIntegration
 space = H.make_ssp_space(2, 1015)
 path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
 pm = H.make_pathint_model(space, path, vels, int(sys.argv[1]) if len(sys.argv) > 1 else 10000, seed=0)
-r = ShardedPathIntegration(pm, 0, 1, dtype="f32", n_eval_points=1000, block=1000)
+dev = len(sys.argv) > 2 and sys.argv[2] == "device"        # all-device block exchange (what RCCL ranks use)
+r = ShardedPathIntegration(pm, 0, 1, dtype="f32", n_eval_points=1000, block=1000, device_exchange=dev)
 r.prepare(12000)
 r.run_block(); r.flush()
 for label in ("async",):
