@@ -122,6 +122,8 @@ typedef struct ssn_model_desc {
                                               k_spmv_partial (experiment, measured 2 % slower on SLAM config 3),
                                          128 = no whole-block kernel for a recurrent array of independent ensembles
                                               (k_ens_block): step it once per timestep (k_ensarray) instead,
+                                         256 = generic plan: fork the independent branches of a timestep over several
+                                              streams inside the step graph (data-hazard analysis in the planner),
                                          64 = programs stage their signal ranges through LDS (experiment, measured
                                               5 % slower on SLAM config 3 than operating on global memory)          */
 } ssn_model_desc;

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
 template <typename T, int DIN, int DOUT, int NPT, int TPB, bool ENC_LDS, bool CLUSTER = false>
 static hipError_t launch_block_variant(hipStream_t s, const BlockArgs<T>& a) {
   // cluster mode is compiled only for the variants a shard of a big ensemble lands on (and the f64 test sizes)
-  constexpr bool HAS_CLUSTER = !ENC_LDS && ((sizeof(T) == 8) || (TPB == 512 && (NPT == 6 || NPT == 10)));
+  constexpr bool HAS_CLUSTER = !ENC_LDS && ((sizeof(T) == 8) || (TPB == 512 && (NPT == 6 || NPT == 10)) || (TPB == 1024 && NPT <= 4));
   if constexpr (!CLUSTER && HAS_CLUSTER) {
     if (a.P > 1) return launch_block_variant<T, DIN, DOUT, NPT, TPB, ENC_LDS, true>(s, a);
   }

@@ -218,16 +218,18 @@ def test_slam_f32_within_cosine_bar(Simulator):
 
 
 def test_slam_optin_plans_equal_default(Simulator):
-    """flags 32 (single-workgroup neuron kernel emitting the spike list) and 64 (LDS-staged programs) are
-    alternative plans of the same operators: same trajectory as the default plan (f64)."""
+    """flags 32 (single-workgroup neuron kernel emitting the spike list), 64 (LDS-staged programs) and 256
+    (independent branches of a timestep forked over several streams inside the step graph) are alternative
+    plans of the same operators: same trajectory as the default plan (f64)."""
     sm = _small_slam(weights_every=None)
     model = build(sm.model)
     outs = []
-    for flags in (0, 32 | 64):
+    for flags in (0, 32 | 64, 256):
         with Simulator(None, model=model, dtype="f64", flags=flags) as sim:
             sim.run_steps(120)
             outs.append(sim.data[sm.probe])
     np.testing.assert_allclose(outs[1], outs[0], atol=1e-12, rtol=0)
+    np.testing.assert_array_equal(outs[2], outs[0])
 
 
 def test_feedforward_model_runs_fully_batched(Simulator):
