@@ -52,7 +52,7 @@ class _BlockFeed:
 class ShardedPathIntegration:
     def __init__(self, pm, rank, world, dt=0.001, dtype="f32", device=0, n_eval_points=None, block=1000,
                  sim_factory=None, dist=None, gather_device=None, async_readout=True, block_steps=0,
-                 device_exchange=None):
+                 device_exchange=None, defer_readout=16):
         """``pm``: object from ``harness.make_pathint_model`` (model, pathintegrator, probe)."""
         if dist is None:
             import torch.distributed as dist
@@ -69,6 +69,12 @@ class ShardedPathIntegration:
         self.gather_device = gather_device
         self.dtype = dtype
         self.device_exchange = device_exchange     # None: automatic (RCCL backend + HIP simulator); True/False: forced
+        # Device path: rank 0's GPU is (nearly) full while its VCO shard is being stepped - at two ranks 254 of the
+        # 256 CUs hold a k_ens_block workgroup for the whole block - so read-out kernels launched meanwhile would
+        # crawl on the few free CUs.  Gathered blocks (6 MB each at d = 1015) are therefore kept in HBM and replayed
+        # through the read-out `defer_readout` blocks at a time, or when flush() / probe_data() asks for them.
+        self.defer_readout = int(defer_readout)
+        self._pending = []
         # --- this rank's VCO shard: probe = local slice of the oscillator output node ----------------
         with pm.model:
             width = 3 * (self.hi - self.lo)
@@ -105,6 +111,8 @@ class ShardedPathIntegration:
 
     def prepare(self, n_steps):
         self.sim.prepare(n_steps)
+        if self.readout is not None and hasattr(self.readout, "reserve_probes"):
+            self.readout.reserve_probes(n_steps)
         if self.world > 1 and not self._warm and self.dist.is_initialized():
             self._gather(np.zeros((1, 3 * (self.hi - self.lo))))   # the first collective sets up the communicator: untimed
             self._warm = True
@@ -113,8 +121,8 @@ class ShardedPathIntegration:
         if not isinstance(full, np.ndarray):
             # device path: the gathered block is already in HBM in the simulator's dtype - it becomes the
             # read-out's input table without a host round trip
-            self.readout.prepare_tables_device({0: (full.data_ptr(), n, np.arange(n, dtype=np.int32))}, n)
-            self.readout.run_steps(n)
+            self.readout.prepare_tables_device({0: (full.data_ptr(), n, np.arange(n, dtype=np.int32))}, n, reserve=False)
+            self.readout.run_steps(n, collect=False)      # samples stay in HBM until probe_data() asks for them
             return
         self.feed.rows, self.feed.first = np.ascontiguousarray(full), first
         self.readout.prepare(n)
@@ -166,8 +174,14 @@ class ShardedPathIntegration:
             finally:
                 self._jobs.task_done()
 
+    def _drain_pending(self):
+        pending, self._pending = self._pending, []
+        for job in pending:
+            self._replay(*job)
+
     def flush(self):
         """Wait until the read-out has consumed every block handed to it."""
+        self._drain_pending()
         if self._jobs is not None:
             self._jobs.join()
             if self._error is not None:
@@ -195,12 +209,9 @@ class ShardedPathIntegration:
             self.sim.run_steps(n, collect=False)
             full = self._gather_device(n)
             if self.readout is not None:
-                if self._jobs is not None:
-                    if self._error is not None:
-                        self.flush()
-                    self._jobs.put((full, self.n_steps, n))
-                else:
-                    self._replay(full, self.n_steps, n)
+                self._pending.append((full, self.n_steps, n))
+                if len(self._pending) >= max(1, self.defer_readout):
+                    self._drain_pending()
             self.n_steps += n
             return
         self.sim.run_steps(n, collect=True)

@@ -246,13 +246,27 @@ class Simulator:
         self._fetched = {}               # sample counts restart with the new reservation
         self._prepared_until = first + n_steps
 
-    def prepare_tables_device(self, tables, n_steps):
-        """Like ``prepare`` for inputs that are already in HBM (multi-GPU exchange): ``tables`` maps table id ->
-        (device pointer to rows [n_rows][width] in the simulator's dtype, n_rows, int32 row index per step)."""
-        n_steps = int(n_steps)
+    def reserve_probes(self, n_steps):
+        """Probe storage for the next ``n_steps`` steps (drops device-side samples: they are fetched first)."""
         if getattr(self, "_uncollected", False):
             self._collect()
+        self._check(self._lib.ssn_reserve_probes(self._h, int(n_steps)))
+        self._fetched = {}
+        self._reserved_until = self.n_steps + int(n_steps)
+
+    def prepare_tables_device(self, tables, n_steps, reserve=True):
+        """Like ``prepare`` for inputs that are already in HBM (multi-GPU exchange): ``tables`` maps table id ->
+        (device pointer to rows [n_rows][width] in the simulator's dtype, n_rows, int32 row index per step).
+        ``reserve=False``: probe storage was reserved for a longer stretch by ``reserve_probes``."""
+        n_steps = int(n_steps)
         first = self.n_steps
+        if not reserve and getattr(self, "_reserved_until", 0) >= first + n_steps:
+            for tid, (ptr, n_rows, idx) in tables.items():
+                self.set_table_device(tid, ptr, n_rows, idx, first)
+            self._prepared_until = first + n_steps
+            return
+        if getattr(self, "_uncollected", False):
+            self._collect()
         if set(tables) != set(range(len(self.model.tables))):
             raise fe.SimulationError("prepare_tables_device needs every table of the model")
         for tid, (ptr, n_rows, idx) in tables.items():
@@ -326,6 +340,8 @@ class Simulator:
             self._fetched[key] = n
 
     def _probe_array(self, key):
+        if getattr(self, "_uncollected", False) and not self.closed:
+            self._collect()              # run_steps(collect=False) left samples on the device
         kind, j, p = self._probe_index[key]
         chunks = [c[1] if isinstance(c, tuple) else c for c in self._chunks[key]]
         if not chunks:
