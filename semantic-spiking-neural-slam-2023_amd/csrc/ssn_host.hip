@@ -1105,6 +1105,18 @@ struct Sim final : ssn_sim {
     core_empty = bsig && n_core_ops == 0 && !core_probe;
     if (core_empty) launches_per_step = 0;
     if (!fused) analyse_dependencies(programs, item_prog);
+    if (getenv("SSN_DEBUG_PLAN")) {
+      int pj = 0;
+      for (size_t i = 0; i < items.size(); ++i) {
+        if (items[i].type != IT_PROGRAM) { fprintf(stderr, "[ssn] plan item %2zu type %d rows %d cols %d n %d\n", i, items[i].type, items[i].rows, items[i].cols, items[i].n); continue; }
+        const auto& pr = programs[(size_t)item_prog[(size_t)pj++]];
+        long long elems = 0; int levels = 1;
+        for (size_t q = 0; q < pr.size(); ++q) { elems += pr[q].len * (pr[q].kind == ssn::M_MATVEC_INC || pr[q].kind == ssn::M_MATVEC_SET ? pr[q].i0 : 1); if (q && pr[q].barrier) ++levels; }
+        fprintf(stderr, "[ssn] plan item %2zu program: %zu ops, %d levels, %lld elements:", i, pr.size(), levels, elems);
+        for (auto& o : pr) fprintf(stderr, " %d/%lld", o.kind, o.len);
+        fprintf(stderr, "\n");
+      }
+    }
     return SSN_OK;
   }
 

@@ -134,6 +134,106 @@ def make_slam_model(ssp_space, path, vels, n_landmarks=10, pi_n_neurons=500, mem
     return out
 
 
+def make_slamview_model(ssp_space, path, vels, n_landmarks=10, pi_n_neurons=500, mem_n_neurons=None,
+                        circonv_n_neurons=100, view_rad=0.2, update_thres=0.2, shift_rate=0.2,
+                        voja_learning_rate=5e-4, pes_learning_rate=1e-3, tau_pi=0.05, seed=0, dt=0.001,
+                        init_time=0.05, weights_sample_every=None):
+    """The model of ``run_slamview.py:88-137``: SLAMViewNetwork fed with the bound view SSP of the landmarks in
+    sight (``get_slamview_input_functions``)."""
+    from .networks import SLAMViewNetwork, get_slamview_input_functions
+    d = ssp_space.ssp_dim
+    domain_dim = ssp_space.domain_dim
+    if mem_n_neurons is None:
+        mem_n_neurons = 10 * d
+    obj_locs = 0.9 * 2 * (Rd_sampling(n_landmarks, domain_dim, seed=seed) - 0.5)
+    vec_to_landmarks = obj_locs[None, :, :] - path[:, None, :]
+    lm_space = SPSpace(n_landmarks, d, seed=seed)
+    real_ssp = ssp_space.encode(path)
+    velocity_func, vel_scaling_factor, is_landmark_in_view, landmark_func = get_slamview_input_functions(
+        ssp_space, lm_space, vels, vec_to_landmarks, view_rad, dt=dt)
+    out = SlamModel()
+    model = nengo.Network(seed=seed)
+    with model:
+        vel_input = nengo.Node(velocity_func, label="vel_input")
+        init_state = nengo.Node(lambda t: real_ssp[int((t - dt) / dt)] if t < init_time else np.zeros(d),
+                                label="init_state")
+        landmark_input = nengo.Node(landmark_func, label="lm_view")
+        landmark_inview = nengo.Node(is_landmark_in_view, label="lm_in_view")
+        out.slam = SLAMViewNetwork(ssp_space, lm_space, view_rad, n_landmarks, pi_n_neurons, mem_n_neurons,
+                                   circonv_n_neurons, tau_pi=tau_pi, update_thres=update_thres,
+                                   vel_scaling_factor=vel_scaling_factor, shift_rate=shift_rate,
+                                   voja_learning_rate=voja_learning_rate, pes_learning_rate=pes_learning_rate,
+                                   clean_up_method="grid", gc_n_neurons=0, encoders=None, voja=True, seed=seed)
+        nengo.Connection(landmark_input, out.slam.view_input, synapse=None)
+        nengo.Connection(landmark_inview, out.slam.no_landmark_in_view, synapse=None)
+        nengo.Connection(vel_input, out.slam.velocity_input, synapse=None)
+        nengo.Connection(init_state, out.slam.pathintegrator.input, synapse=None)
+        out.probe = nengo.Probe(out.slam.pathintegrator.output, synapse=0.05)
+        out.recall_probe = nengo.Probe(out.slam.assomemory.recall, synapse=0.05)
+        out.weights_probe = nengo.Probe(out.slam.assomemory.conn_out, "weights",
+                                        sample_every=weights_sample_every) if weights_sample_every else None
+    out.model, out.real_ssp, out.ssp_space, out.lm_space = model, real_ssp, ssp_space, lm_space
+    out.obj_locs, out.path, out.vels, out.vel_scaling_factor = obj_locs, path, vels, vel_scaling_factor
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# recorded trajectories in, result files out (the reference scripts' formats)
+# --------------------------------------------------------------------------------------------
+def stretch_trajectory(traj, original_dt=0.02, new_dt=0.001):
+    """Resample a recorded 2-D trajectory from ``original_dt`` to ``new_dt`` by linear interpolation
+    (``run_pathint.py:57-66``)."""
+    traj = np.asarray(traj, dtype=float)
+    n = traj.shape[0]
+    total = n * original_dt
+    m = int(total / new_dt)
+    t_old, t_new = np.linspace(0, total, n), np.linspace(0, total, m)
+    return np.stack([np.interp(t_new, t_old, traj[:, 0]), np.interp(t_new, t_old, traj[:, 1])], axis=1)
+
+
+def load_path(path_data, data_dt=0.001, dt=0.001, radius=1.0, max_rows=49999):
+    """``--path-data`` of the reference scripts (``run_pathint.py:77-89``): load an ``.npy`` trajectory, cut it
+    to ``max_rows``, resample if it was recorded at another step, rescale each axis to ±0.9·radius and
+    differentiate.  Returns ``(path, vels)``."""
+    path = np.load(path_data)[:max_rows, :].astype(float)
+    if data_dt != dt:
+        path = stretch_trajectory(path, original_dt=data_dt, new_dt=dt)
+    for i in range(path.shape[1]):
+        lo, hi = path[:, i].min(), path[:, i].max()
+        path[:, i] = 1.8 * radius * (path[:, i] - lo) / (hi - lo) - 0.9 * radius
+    vels = (1 / dt) * np.diff(path, axis=0, prepend=path[0:1])
+    return path, vels
+
+
+def save_pathint_results(filename, ssp_space, ts, path, real_ssp, pi_sim_out, elapsed_time, args=None,
+                         elapsed_thread_time=None):
+    """``np.savez`` with the field names of ``run_pathint.py:201-207`` so the reference's plotting scripts
+    (``plot_trials_2d.py``) read our runs.  Returns the decoded path estimate."""
+    pi_path, pi_sims, pi_error = pathint_metrics(ssp_space, pi_sim_out, real_ssp, path)
+    n = pi_sim_out.shape[0]
+    path, real_ssp = path[:n], real_ssp[:n]
+    np.savez(filename, ts=ts, path=path, real_ssp=real_ssp, pi_sim_out=pi_sim_out, pi_sims=pi_sims, pi_path=pi_path,
+             pi_error=pi_error, elapsed_time=elapsed_time,
+             elapsed_thread_time=elapsed_time if elapsed_thread_time is None else elapsed_thread_time,
+             args=np.array(repr(args)), sig_to_noise_ratio=np.array(np.nan))
+    return pi_path
+
+
+def save_slam_results(filename, ssp_space, ts, path, real_ssp, obj_locs, view_rad, slam_sim_out, landmark_ssps_est,
+                      landmark_loc_est, elapsed_time, args=None, elapsed_thread_time=None):
+    """Field names of ``run_slam.py:282-293``.  Returns the decoded path estimate."""
+    slam_path, slam_sims, slam_error = pathint_metrics(ssp_space, slam_sim_out, real_ssp, path)
+    n = slam_sim_out.shape[0]
+    path, real_ssp = path[:n], real_ssp[:n]
+    np.savez(filename, timesteps=np.arange(path.shape[0]) * (ts[1] - ts[0] if len(ts) > 1 else 0.001), ts=ts, path=path,
+             real_ssp=real_ssp, obj_locs=obj_locs, view_rad=view_rad, slam_sim_out=slam_sim_out, slam_sims=slam_sims,
+             slam_path=slam_path, slam_error=slam_error, landmark_ssps_est=landmark_ssps_est,
+             landmark_loc_est=landmark_loc_est, elapsed_time=elapsed_time,
+             elapsed_thread_time=elapsed_time if elapsed_thread_time is None else elapsed_thread_time,
+             args=np.array(repr(args)), sig_to_noise_ratio=np.array(np.nan))
+    return slam_path
+
+
 def get_activities(built_ens, neuron_type, x):
     """Rates of an ensemble for decoded-space points ``x`` (nengo.builder.ensemble.get_activities)."""
     proj = x @ built_ens.encoders.T / built_ens.radius

@@ -252,7 +252,8 @@ def load_reference():
     nets.PathIntegration, nets.CircularConvolution = pi.PathIntegration, bind.CircularConvolution
     nets.Product, nets.AssociativeMemory = bind.Product, am.AssociativeMemory
     slam = _load("sspslam.networks.slam", "sspslam/networks/slam.py")
-    return dict(utils=utils, ssp=ssp, pi=pi, bind=bind, am=am, slam=slam)
+    slam_view = _load("sspslam.networks.slam_view", "sspslam/networks/slam_view.py")
+    return dict(utils=utils, ssp=ssp, pi=pi, bind=bind, am=am, slam=slam, slam_view=slam_view)
 
 
 # --------------------------------------------------------------------------------------------
@@ -527,6 +528,24 @@ def main():
     g["unitary_x"] = xc
     g["unitary_out"] = np.stack([unit_fn(x) for x in xc])
     np.savez_compressed(os.path.join(OUT, "slam_nodes.npz"), **g)
+
+    # SLAMViewNetwork (slam_view.py): topology + input tables on the same synthetic path
+    sv = R["slam_view"]
+    m0 = _mark()
+    with Network(seed=0):
+        sv.SLAMViewNetwork(s55, lm_space, 0.2, 10, 500, 550, 100, tau_pi=0.05, update_thres=0.2,
+                           vel_scaling_factor=0.3, shift_rate=0.2, voja_learning_rate=1e-4,
+                           pes_learning_rate=5e-3, clean_up_method="grid", gc_n_neurons=0, encoders=None,
+                           voja=True, seed=0)
+    topo["slamview_d55_pi500_m550_lm10"] = census(m0)
+    g = {}
+    vf, scale, inview, lmf = sv.get_slamview_input_functions(s55, lm_space, vels, vec_to_lm, 0.2)
+    ts_v = ts[:1500]
+    g["scale"] = np.array(scale)
+    g["vel"] = np.stack([vf(t) for t in ts_v])
+    g["inview"] = np.array([inview(t) for t in ts_v])
+    g["view_ssp"] = np.stack([lmf(t) for t in ts_v]).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "slamview_inputs.npz"), **g)
 
     m0 = _mark()
     with Network(seed=0):

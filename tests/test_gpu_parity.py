@@ -217,6 +217,27 @@ def test_slam_f32_within_cosine_bar(Simulator):
     assert ce.max() < 1e-3, ce.max()
 
 
+def test_slamview_f64_matches_oracle(Simulator):
+    """SLAMViewNetwork (reference slam_view.py, run_slamview.py): trajectory, recall and learned decoders."""
+    s = H.make_ssp_space(2, 55)
+    path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
+    sm = H.make_slamview_model(s, path, vels, n_landmarks=10, pi_n_neurons=100, mem_n_neurons=300, view_rad=0.6,
+                               weights_sample_every=0.1)
+    model = build(sm.model)
+    ref = OracleSimulator(model)
+    ref.run_steps(400)
+    with Simulator(None, model=model, dtype="f64") as sim:
+        sim.run_steps(400)
+        np.testing.assert_allclose(sim.data[sm.probe], ref.probe_data(0), atol=1e-9, rtol=0)
+        np.testing.assert_allclose(sim.data[sm.recall_probe], ref.probe_data(1), atol=1e-9, rtol=0)
+        W = sim.data[sm.weights_probe]
+        assert np.abs(W[-1]).max() > 1e-6
+        np.testing.assert_allclose(W, ref.probe_data(2), atol=1e-12, rtol=1e-9)
+    with Simulator(None, model=model, dtype="f32") as sim:
+        sim.run_steps(300)
+        assert H.cosine_error(sim.data[sm.probe][20:], ref.probe_data(0)[20:300]).max() < 1e-3
+
+
 def test_slam_optin_plans_equal_default(Simulator):
     """flags 32 (single-workgroup neuron kernel emitting the spike list), 64 (LDS-staged programs) and 256
     (independent branches of a timestep forked over several streams inside the step graph) are alternative

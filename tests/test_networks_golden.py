@@ -190,6 +190,32 @@ def test_topology(s55):
     _check(census(m), ref["slam_d55_pi500_m550_c100_lm10"])
 
 
+def test_slamview_topology_and_inputs(golden, s55):
+    """SLAMViewNetwork / get_slamview_input_functions (reference slam_view.py) against the reference's own
+    constructor census and input tables."""
+    from sspslam_amd.networks import SLAMViewNetwork, get_slamview_input_functions
+    with open(os.path.join(os.path.dirname(__file__), "golden", "topology.json")) as f:
+        ref = json.load(f)
+    lm = SPSpace(10, 55, seed=0)
+    with nengo.Network(seed=0) as m:
+        SLAMViewNetwork(s55, lm, 0.2, 10, 500, 550, 100, tau_pi=0.05, update_thres=0.2, vel_scaling_factor=0.3,
+                        shift_rate=0.2, voja_learning_rate=1e-4, pes_learning_rate=5e-3, clean_up_method="grid",
+                        gc_n_neurons=0, encoders=None, voja=True, seed=0)
+    _check(census(m), ref["slamview_d55_pi500_m550_lm10"])
+    g = golden("slamview_inputs.npz")
+    gi = golden("slam_inputs.npz")
+    path, vels = gi["path"], gi["vels"]
+    obj = 0.9 * 2 * (Rd_sampling(10, 2, seed=0) - 0.5)
+    vec_to_lm = obj[None] - path[:, None]
+    vf, scale, inview, lmf = get_slamview_input_functions(s55, lm, vels, vec_to_lm, 0.2)
+    ts = np.arange(1, g["vel"].shape[0] + 1) * 0.001
+    np.testing.assert_allclose(scale, g["scale"], rtol=1e-13)
+    np.testing.assert_allclose(np.stack([vf(t) for t in ts]), g["vel"], atol=TOL)
+    np.testing.assert_array_equal(np.array([inview(t) for t in ts]), g["inview"])
+    np.testing.assert_allclose(np.stack([lmf(t) for t in ts]), g["view_ssp"], atol=1e-6)
+    assert g["inview"].min() == 0 and g["inview"].max() == 1          # the path passes landmarks
+
+
 def test_object_model_basics():
     with pytest.raises(nengo.NetworkContextError):
         nengo.Node(size_in=3)

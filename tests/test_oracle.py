@@ -168,3 +168,45 @@ def test_gate_and_cleanup_ops():
         want_g = 0.5 * (want_c - xin) if (t < 0.01 and want_c @ xin > 0.2) else np.zeros(7)
         np.testing.assert_allclose(G[i], want_g, atol=1e-15)
     assert np.abs(G[:9]).max() > 0 and np.abs(G[10:]).max() == 0
+
+
+def test_slamview_model_runs_on_the_oracle_and_io_helpers(tmp_path):
+    """SLAMViewNetwork (reference slam_view.py / run_slamview.py) lowers to the same operator set minus the
+    circular convolutions and steps on the oracle; recorded-trajectory loading and the result files use the
+    reference scripts' formats (run_pathint.py:57-89,201-207; run_slam.py:282-293)."""
+    from sspslam_amd import harness as H
+    from sspslam_amd.builder import build
+    s = H.make_ssp_space(2, 55)
+    d = s.ssp_dim
+    path, vels = H.make_random_path(10.0, limit=0.2, seed=0)
+    sm = H.make_slamview_model(s, path, vels, n_landmarks=5, pi_n_neurons=30, mem_n_neurons=60, view_rad=0.6,
+                               weights_sample_every=0.05)
+    model = build(sm.model)
+    kinds = {o["kind"] for o in model.ops}
+    assert {"cleanup", "gate", "pes", "voja", "neurons", "ensarray"} <= kinds
+    ref = OracleSimulator(model)
+    ref.run_steps(200)
+    out = ref.probe_data(0)
+    assert out.shape == (200, d) and np.isfinite(out).all() and np.abs(out).max() > 0.1
+    assert np.abs(ref.probe_data(2)[-1]).max() > 0          # PES moved the decoders
+
+    # recorded trajectory: 50 Hz -> 1 kHz, rescaled to +-0.9
+    rec = np.cumsum(np.random.RandomState(0).randn(300, 2), axis=0)
+    np.save(tmp_path / "rec.npy", rec)
+    p2, v2 = H.load_path(str(tmp_path / "rec.npy"), data_dt=0.02)
+    assert p2.shape == (6000, 2) and abs(p2.max() - 0.9) < 1e-12 and abs(p2.min() + 0.9) < 1e-12
+    np.testing.assert_allclose(v2[1:], np.diff(p2, axis=0) / 0.001)
+    st = H.stretch_trajectory(rec, 0.02, 0.001)
+    np.testing.assert_allclose(st[0], rec[0]); np.testing.assert_allclose(st[-1], rec[-1])
+
+    real = s.encode(path)
+    est = H.save_pathint_results(str(tmp_path / "pi.npz"), s, np.arange(1, 201) * 0.001, path, real, out, 1.5)
+    z = np.load(tmp_path / "pi.npz", allow_pickle=True)
+    assert {"ts", "path", "real_ssp", "pi_sim_out", "pi_sims", "pi_path", "pi_error", "elapsed_time",
+            "elapsed_thread_time", "args", "sig_to_noise_ratio"} <= set(z.files)
+    assert z["pi_path"].shape == (200, 2) and est.shape == (200, 2) and z["pi_error"].shape == (200,)
+    H.save_slam_results(str(tmp_path / "slam.npz"), s, np.arange(1, 201) * 0.001, path, real, sm.obj_locs, 0.6, out,
+                        np.zeros((5, d)), np.zeros((5, 2)), 1.5)
+    z = np.load(tmp_path / "slam.npz", allow_pickle=True)
+    assert {"timesteps", "slam_sim_out", "slam_sims", "slam_path", "slam_error", "landmark_ssps_est",
+            "landmark_loc_est", "obj_locs", "view_rad"} <= set(z.files)
