@@ -59,7 +59,9 @@ typedef struct ssn_buffer_desc {
  *  FILL     i0 dst  i1 len                                  f0 value
  *  TABLE    i0 dst  i1 width i2 table_id                                      (ssn_set_table)
  *  AXPY     i0 dst  i1 src   i2 len  i3 mode(0 inc,1 set)   f0 alpha
- *  MATVEC   i0 dst  i1 src   i2 rows i3 cols i4 W buf i5 mode                 W is rows x cols
+ *  MATVEC   i0 dst  i1 src   i2 rows i3 cols i4 W buf i5 mode i6 dft          W is rows x cols; dft != 0: W is
+ *           the real-DFT map of a circular-convolution network (1-4 transform_in A / B / conj A / conj B, 5 transform_out,
+ *           reference binding.py:23-74) - the f32 core may then run k_dft (mixed-radix FFT) instead of W
  *  LOWPASS  i0 dst  i1 src   i2 len                         f0 a  f1 gain     dst=a*dst+(1-a)*gain*src
  *  ENSARRAY i0 x    i1 K i2 n i3 din i4 dout i5 enc buf [K][din][n] i6 bias buf [K][n]
  *           i7 dec buf [K][dout][n] i8 dst_idx buf (int32 [K][dout]) i9 V buf i10 R buf
@@ -124,6 +126,7 @@ typedef struct ssn_model_desc {
                                               (k_ens_block): step it once per timestep (k_ensarray) instead,
                                          256 = generic plan: fork the independent branches of a timestep over several
                                               streams inside the step graph (data-hazard analysis in the planner),
+                                         512 = no FFT kernel for DFT-structured matvecs (always multiply by the matrix),
                                          64 = programs stage their signal ranges through LDS (experiment, measured
                                               5 % slower on SLAM config 3 than operating on global memory)          */
 } ssn_model_desc;

@@ -144,6 +144,27 @@ def _lowpass_coeff(tau, dt):
 
 
 # --------------------------------------------------------------------------------------------
+DFT_KINDS = {("A", False): 1, ("B", False): 2, ("A", True): 3, ("B", True): 4}
+
+
+def dft_structure(T):
+    """0, or the code of the real-DFT map a transform matrix is: 1-4 = ``transform_in(d, 'A'|'B', invert)``
+    (reference ``binding.py:23-54``), 5 = ``transform_out(d)`` (``:57-74``) - the three dense matrices of a
+    CircularConvolution network."""
+    from .networks.binding import transform_in, transform_out
+    T = np.asarray(T)
+    if T.ndim != 2:
+        return 0
+    r, c = T.shape
+    if c >= 8 and r == 4 * (c // 2 + 1):
+        for (align, inv), code in DFT_KINDS.items():
+            if np.allclose(T, transform_in(c, align, inv), rtol=0, atol=1e-12):
+                return code
+    if r >= 8 and c == 4 * (r // 2 + 1) and np.allclose(T, transform_out(r), rtol=0, atol=1e-12):
+        return 5
+    return 0
+
+
 class Builder:
     def __init__(self, network, dt=0.001, seed=None, n_eval_points=None, solver_backend="auto",
                  vco_shard=None, progress=None, probes=None, prune=False, staged=True):
@@ -541,11 +562,12 @@ class Builder:
         if cols != src.len or rows != dst.len:
             raise fe.BuildError(f"transform {T.shape} does not map {src.len} -> {dst.len}")
         b = self.model.add_buffer(np.ascontiguousarray(T), f"transform_{len(self.model.buffers)}")
+        dft = dft_structure(T)          # the matrix is kept (oracle, f64 mode); the f32 device path may use an FFT
         if c.synapse is None:
-            self.op("matvec", dst=dst, src=src, rows=rows, cols=cols, w=b, mode="inc")
+            self.op("matvec", dst=dst, src=src, rows=rows, cols=cols, w=b, mode="inc", dft=dft)
         else:
             w = self.alloc("W", rows)
-            self.op("matvec", dst=w, src=src, rows=rows, cols=cols, w=b, mode="set")
+            self.op("matvec", dst=w, src=src, rows=rows, cols=cols, w=b, mode="set", dft=dft)
             self._apply_synapse(c, w, dst, rows)
 
     def _register_rows(self, e, W, w_ref):

@@ -71,7 +71,7 @@ struct Buf {
   int64_t ldt = 0;
 };
 
-enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_NEURONS_COMPACT };
+enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_NEURONS_COMPACT, IT_DFT };
 
 }  // namespace
 
@@ -110,6 +110,7 @@ struct Sim final : ssn_sim {
     T scalar = 0;
     ssn::NeuronParams<T> np;
     int* list = nullptr; int* count = nullptr;     // spike list (k_neurons_compact -> k_spmv_partial)
+    ssn::DftArgs dft;
   };
 
   int device = 0;
@@ -135,6 +136,7 @@ struct Sim final : ssn_sim {
   std::vector<void*> fused_bufs;
   std::set<int> sparse_w;                     // decoder buffers multiplied with a LIF spike vector
   std::vector<std::pair<int64_t, std::pair<int*, int*>>> spike_lists;   // spike signal offset -> (list, count)
+  std::vector<std::pair<int, float2*>> dft_tables;                      // transform length -> twiddle table
   std::vector<ssn::BatchOp<T>> pre_ops, post_ops;
   std::vector<ssn_range> pre_to_core, core_to_post;
   std::vector<unsigned char> batched_mask;    // signals owned by a batched stage (for ssn_read_signal)
@@ -529,6 +531,37 @@ struct Sim final : ssn_sim {
     ens_chunking(a);
   }
 
+  // FFT plan of a DFT-structured matvec: radices (<= 32 each) and the twiddle table; N = 0 when d has a larger
+  // prime factor (97, 1801, ... : the matrix is used then).
+  int plan_dft(const ssn_op_desc& o, ssn::DftArgs* a) {
+    const int kind = (int)o.i[6];
+    const int d = kind == 5 ? (int)o.i[2] : (int)o.i[3];
+    *a = ssn::DftArgs{};
+    std::vector<int> rad;
+    int rest = d;
+    for (int p = 2; p <= 32 && rest > 1; ++p)
+      while (rest % p == 0) { rad.push_back(p); rest /= p; }
+    if (rest != 1 || rad.size() > 12 || d < 8 || (int64_t)d * 24 > 150 * 1024) return SSN_OK;
+    std::sort(rad.rbegin(), rad.rend());
+    float2* tw = nullptr;
+    for (auto& t : dft_tables) if (t.first == d) tw = t.second;
+    if (!tw) {
+      std::vector<float2> h((size_t)d);
+      for (int k = 0; k < d; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / (double)d;
+        h[(size_t)k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+      }
+      CHK(dmalloc(&tw, (int64_t)d * (int64_t)sizeof(float2)));
+      HIPCHK(hipMemcpy(tw, h.data(), (size_t)d * sizeof(float2), hipMemcpyHostToDevice));
+      scratch_bufs.push_back(tw);
+      dft_tables.push_back({d, tw});
+    }
+    a->src = (const float*)(sig + o.i[1]); a->dst = (float*)(sig + o.i[0]); a->tw = tw; a->N = d; a->kind = kind;
+    a->set = (int)o.i[5]; a->nr = (int)rad.size();
+    for (size_t i = 0; i < rad.size(); ++i) a->radix[i] = rad[i];
+    return SSN_OK;
+  }
+
   // Core stage == one recurrent ensemble array (the path integrator's VCO array): x assembled in the
   // kernel prologue, decoded rows / synapse update / hand-off / step counter in one barrier-free finish
   // kernel.  Returns false (and plans nothing) when the core does not have that shape.
@@ -906,6 +939,15 @@ struct Sim final : ssn_sim {
           push_micro(op, o.level, true); break;
         case SSN_OP_MATVEC: {
           const Buf& w = bufs[o.i[4]];
+          ssn::DftArgs da{};
+          if (o.i[6] && sizeof(T) == 4 && !(flags & 512) && plan_dft(o, &da) == SSN_OK && da.N) {
+            // the matrix is a real-DFT map of a circular-convolution network: mixed-radix FFT instead of a GEMV
+            flush();
+            Item it; it.type = IT_DFT; it.dft = da;
+            it.src = sig + o.i[1]; it.dst = sig + o.i[0]; it.rows = (int)o.i[2]; it.cols = (int)o.i[3];
+            items.push_back(it);
+            break;
+          }
           if (is_micro(o)) {
             op.kind = o.i[5] ? ssn::M_MATVEC_SET : ssn::M_MATVEC_INC;
             op.dst = o.i[0]; op.src = o.i[1]; op.len = o.i[2]; op.i0 = o.i[3]; op.i1 = w.ld; op.p0 = w.d;
@@ -1160,6 +1202,9 @@ struct Sim final : ssn_sim {
           pt(a, it.ens.partials, true); pt(a, it.ens.V, true); pt(a, it.ens.R, true);
           pt(a, it.ens.enc, false); pt(a, it.ens.bias, false); pt(a, it.ens.dec, false);
           break;
+        case IT_DFT:
+          sg(a, it.src - sig, it.cols, false); sg(a, it.dst - sig, it.rows, true); pt(a, it.dft.tw, false);
+          break;
         case IT_MATVEC: case IT_MATVEC_ORDERED:
           sg(a, it.src - sig, it.cols, false); pt(a, it.Wm, false);
           if (it.dst >= sig && it.dst < sig + n_sig) sg(a, it.dst - sig, it.rows, true); else pt(a, it.dst, true);
@@ -1226,6 +1271,7 @@ struct Sim final : ssn_sim {
       case IT_MATVEC: return ssn::launch_matvec<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set);
       case IT_MATVEC_ORDERED: return ssn::launch_matvec_ordered<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld);
       case IT_FINISH: return ssn::launch_ens_finish<T>(stream, it.fin);
+      case IT_DFT: return ssn::launch_dft<T>(stream, it.dft);
       case IT_SPMV: return ssn::launch_spmv_partial<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count);
       case IT_NEURONS_COMPACT: return ssn::launch_neurons_compact<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count);
       case IT_NEURONS: return ssn::launch_neurons<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar);

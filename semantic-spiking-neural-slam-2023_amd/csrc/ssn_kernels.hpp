@@ -411,6 +411,85 @@ hipError_t launch_ensarray(hipStream_t s, const EnsArgs<T>& a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_dft: bind / unbind transforms of the circular-convolution networks.  The reference multiplies by dense
+// real-DFT matrices (transform_in 4(d/2+1) x d, transform_out d x 4(d/2+1); 8.25 MB each at d = 1015, read
+// every timestep).  d is never a power of two (55 = 5*11, 1015 = 5*7*29, 3751 = 11*11*31), so this is a
+// mixed-radix Stockham autosort FFT with generic radix-r butterflies (r <= 32, O(r^2) each) on one workgroup:
+// data, scratch and the twiddle table live in LDS (24 B per point), one output point per thread per stage:
+//   y[q + s(r p + j)] = sum_k x[q + s(p + m k)] * W_N^{(j k N/r + p j N/n) mod N},  n -> n/r, s -> s r.
+// Forward kinds write the 4-slot layout [Re,Im,Re,Im] (A) / [Re,Im,Im,Re] (B) per half-spectrum bin, conjugated
+// for the inverted operand; the inverse kind recombines the four product slots (Re = s0 - s1, Im = s2 + s3),
+// completes the Hermitian spectrum and transforms back (1/d included).  f32 only: the f64 parity mode multiplies
+// by the matrix like the oracle.
+// ---------------------------------------------------------------------------------------------
+template <int DUMMY>
+__global__ __launch_bounds__(1024) void k_dft(DftArgs a) {
+  extern __shared__ __align__(16) unsigned char ssn_dft_dyn[];
+  const int N = a.N, H = N / 2 + 1, tid = threadIdx.x, nthr = blockDim.x;
+  float2* x = reinterpret_cast<float2*>(ssn_dft_dyn);
+  float2* y = x + N;
+  float2* tw = y + N;
+  for (int i = tid; i < N; i += nthr) {
+    tw[i] = a.tw[i];
+    if (a.kind != 5) x[i] = make_float2(a.src[i], 0.0f);
+    else {
+      const int w = i < H ? i : N - i;
+      const float* p = a.src + 4 * w;
+      float re = p[0] - p[1], im = p[2] + p[3];
+      if (w == 0 || 2 * w == N) im = 0.0f;            // purely real bins (their imaginary slots carry no signal)
+      // Z[i] = Y_w (i <= N/2) or conj(Y_w) (i > N/2); the inverse transform is conj(FFT(conj Z)): load conj Z
+      x[i] = make_float2(re, i < H ? -im : im);
+    }
+  }
+  __syncthreads();
+  int n = N, s = 1;
+  for (int st = 0; st < a.nr; ++st) {
+    const int r = a.radix[st], m = n / r, fn = N / n, fr = N / r;
+    for (int o = tid; o < N; o += nthr) {
+      const int q = o % s, u = o / s, j = u % r, p = u / r;
+      int idx = (int)(((long long)p * j * fn) % N);
+      const int step = (int)(((long long)j * fr) % N);
+      const float2* xi = x + q + s * p;
+      float2 acc = make_float2(0.0f, 0.0f);
+      for (int k = 0; k < r; ++k) {
+        const float2 v = xi[s * m * k], t = tw[idx];
+        acc.x = fmaf(v.x, t.x, fmaf(-v.y, t.y, acc.x));
+        acc.y = fmaf(v.x, t.y, fmaf(v.y, t.x, acc.y));
+        idx += step;
+        if (idx >= N) idx -= N;
+      }
+      y[o] = acc;
+    }
+    __syncthreads();
+    float2* t2 = x; x = y; y = t2;
+    n = m; s *= r;
+  }
+  if (a.kind != 5) {
+    const bool conj = a.kind >= 3, slotB = a.kind == 2 || a.kind == 4;
+    for (int w = tid; w < H; w += nthr) {
+      const float re = x[w].x, im = conj ? -x[w].y : x[w].y;
+      float* d = a.dst + 4 * w;
+      const float v2 = slotB ? im : re, v3 = slotB ? re : im;
+      if (a.set) { d[0] = re; d[1] = im; d[2] = v2; d[3] = v3; }
+      else { d[0] += re; d[1] += im; d[2] += v2; d[3] += v3; }
+    }
+  } else {
+    const float inv = 1.0f / (float)N;
+    for (int i = tid; i < N; i += nthr) {
+      const float v = x[i].x * inv;
+      if (a.set) a.dst[i] = v; else a.dst[i] += v;
+    }
+  }
+}
+
+template <typename T>
+hipError_t launch_dft(hipStream_t s, const DftArgs& a) {
+  const int threads = a.N >= 1024 ? 1024 : (a.N + 63) / 64 * 64;
+  hipLaunchKernelGGL((k_dft<0>), dim3(1), dim3(threads), (size_t)a.N * 3 * sizeof(float2), s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_program: one workgroup interprets a list of small vector operators back to back, with a
 // workgroup barrier only where the host scheduler found a dependency (level change).  This turns
 // the dozen tiny nengo operators between two big kernels into a single launch.
@@ -1050,6 +1129,7 @@ namespace ssn {
 
 #define SSN_INSTANTIATE(T)                                                                                   \
   template hipError_t launch_ens_block<T>(hipStream_t, const BlockArgs<T>&);                                 \
+  template hipError_t launch_dft<T>(hipStream_t, const DftArgs&);                                            \
   template bool ens_block_supported<T>(int, int, int, int*, int*, int*, int*);                                         \
   template hipError_t launch_ensarray<T>(hipStream_t, const EnsArgs<T>&);                                    \
   template hipError_t launch_dec_pack<T>(hipStream_t, const T*, T*, int, int, int, int, int, int);           \

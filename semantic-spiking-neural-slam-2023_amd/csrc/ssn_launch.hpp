@@ -113,6 +113,18 @@ struct BlockArgs {
   NeuronParams<T> np;
 };
 
+// k_dft: the real-DFT maps of a circular-convolution network (reference binding.py:23-74) as a mixed-radix FFT.
+struct DftArgs {
+  const float* src;      // d reals (kinds 1-4) or 4*(d/2+1) slot products (kind 5)
+  float* dst;
+  const float2* tw;      // exp(-2 pi i k / N), k = 0..N-1
+  int N;                 // transform length d
+  int kind;              // 1 A, 2 B, 3 A conj, 4 B conj (forward, 4 slots per half-spectrum bin); 5 inverse
+  int set;               // 1: dst = result, 0: dst += result
+  int nr;                // number of radices
+  int radix[12];         // product = N, each <= 32
+};
+
 enum MicroKind {
   M_FILL = 1, M_AXPY_INC, M_AXPY_SET, M_LOWPASS, M_TABLE, M_MATVEC_INC, M_MATVEC_SET, M_ENS_FINISH,
   M_GATE, M_ARGMAX_GATHER, M_PROBE, M_STEP_END, M_ROW_IN, M_ROW_OUT, M_REDUCE_SET, M_REDUCE_INC
@@ -173,6 +185,7 @@ template <typename T> hipError_t launch_ensarray(hipStream_t, const EnsArgs<T>&)
 template <typename T> hipError_t launch_dec_pack(hipStream_t, const T* src, T* dst, int K, int dout, int n, int n_pad, int DP, int unpack);
 template <typename T> hipError_t launch_state_unpack(hipStream_t, const T* src, T* out, int64_t n, int want_refractory);
 template <typename T> hipError_t launch_ens_finish(hipStream_t, const FinishArgs<T>&);
+template <typename T> hipError_t launch_dft(hipStream_t, const DftArgs&);   // (T only selects the translation unit)
 template <typename T> hipError_t launch_ens_block(hipStream_t, const BlockArgs<T>&);
 template <typename T> bool ens_block_supported(int din, int dout, int n, int* threads, int* tpb, int* npt, int* enc_lds);
 template <typename T> hipError_t launch_program(hipStream_t, const MicroOp<T>* ops, const ProgDesc* progs, int n_progs, const ProgSeg* segs,

@@ -80,7 +80,7 @@ def pack_model(model, dtype, device=0, steps_per_graph=0, block_steps=0, flags=0
             ii[:4] = [o["dst"], o["src"], o["len"], 1 if o["mode"] == "set" else 0]
             ff[0] = o["alpha"]
         elif k == "matvec":
-            ii[:6] = [o["dst"], o["src"], o["rows"], o["cols"], o["w"], 1 if o["mode"] == "set" else 0]
+            ii[:7] = [o["dst"], o["src"], o["rows"], o["cols"], o["w"], 1 if o["mode"] == "set" else 0, int(o.get("dft", 0) or 0)]
         elif k == "lowpass":
             ii[:3] = [o["dst"], o["src"], o["len"]]
             ff[:2] = [o["a"], o["gain"]]

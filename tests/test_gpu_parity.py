@@ -238,6 +238,46 @@ def test_slamview_f64_matches_oracle(Simulator):
         assert H.cosine_error(sim.data[sm.probe][20:], ref.probe_data(0)[20:300]).max() < 1e-3
 
 
+def test_dft_kernel_matches_the_transform_matrices(Simulator):
+    """k_dft (mixed-radix FFT for the circular-convolution transforms, f32 core) against the dense real-DFT
+    matrices it replaces (reference binding.py:23-74): in ONE run, the probed output of each transform equals
+    matrix @ probed input.  d = 25 (5*5, repeated radix), 55 (11*5), 217 (31*7); both operand layouts, with and
+    without involution; the inverse transform.  d = 97 (prime) falls back to the matrix."""
+    from sspslam_amd.networks import CircularConvolution
+    from sspslam_amd.builder import dft_structure
+    for d, inv_a, inv_b in ((25, False, True), (55, True, False), (217, False, False), (97, False, False)):
+        rng = np.random.RandomState(d)
+        fa, fb = rng.randn(d) / np.sqrt(d), rng.randn(d) / np.sqrt(d)
+        with nengo.Network(seed=1) as m:
+            ua = nengo.Node(lambda t, f=fa: f * np.cos(9 * t))
+            ub = nengo.Node(lambda t, f=fb: f * np.sin(7 * t) + f[::-1] * 0.5)
+            ea = nengo.Ensemble(60, d)
+            eb = nengo.Ensemble(60, d)
+            nengo.Connection(ua, ea, synapse=None)
+            nengo.Connection(ub, eb, synapse=None)
+            cc = CircularConvolution(12, d, invert_a=inv_a, invert_b=inv_b)
+            nengo.Connection(ea, cc.input_a, synapse=0.005)
+            nengo.Connection(eb, cc.input_b, synapse=0.005)
+            p_a, p_b = nengo.Probe(cc.input_a), nengo.Probe(cc.input_b)
+            p_fa, p_fb = nengo.Probe(cc.product.input_a), nengo.Probe(cc.product.input_b)
+            p_prod, p_out = nengo.Probe(cc.product.output), nengo.Probe(cc.output)
+            sink = nengo.Ensemble(30, d)                  # neurons downstream keep the inverse transform in the core
+            nengo.Connection(cc.output, sink, synapse=None)
+        model = build(m)
+        assert all(o["stage"] == 1 for o in model.ops if o["kind"] == "matvec" and o.get("dft"))
+        kinds = sorted(o.get("dft", 0) for o in model.ops if o["kind"] == "matvec" and o.get("dft"))
+        assert kinds == sorted([3 if inv_a else 1, 4 if inv_b else 2, 5]), kinds
+        assert dft_structure(cc.transform_out) == 5 and dft_structure(np.eye(8)) == 0
+        with Simulator(None, model=model, dtype="f32") as sim:
+            sim.run_steps(120)
+            a, b, fa_, fb_ = sim.data[p_a], sim.data[p_b], sim.data[p_fa], sim.data[p_fb]
+            prod, out = sim.data[p_prod], sim.data[p_out]
+        assert np.abs(a).max() > 0.01 and np.abs(prod).max() > 1e-4
+        np.testing.assert_allclose(fa_, a @ cc.transform_a.T, atol=2e-6 * np.sqrt(d))
+        np.testing.assert_allclose(fb_, b @ cc.transform_b.T, atol=2e-6 * np.sqrt(d))
+        np.testing.assert_allclose(out, prod @ cc.transform_out.T, atol=2e-6)
+
+
 def test_slam_optin_plans_equal_default(Simulator):
     """flags 32 (single-workgroup neuron kernel emitting the spike list), 64 (LDS-staged programs) and 256
     (independent branches of a timestep forked over several streams inside the step graph) are alternative
