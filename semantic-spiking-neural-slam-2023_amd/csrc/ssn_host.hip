@@ -110,6 +110,7 @@ struct Sim final : ssn_sim {
     T scalar = 0;
     ssn::NeuronParams<T> np;
     int* list = nullptr; int* count = nullptr;     // spike list (k_neurons_compact -> k_spmv_partial)
+    int seg = 0;                                   // > 0: segmented spike list (k_neurons), segments per spmv chunk
     ssn::DftArgs dft;
   };
 
@@ -136,6 +137,7 @@ struct Sim final : ssn_sim {
   std::vector<void*> fused_bufs;
   std::set<int> sparse_w;                     // decoder buffers multiplied with a LIF spike vector
   std::vector<std::pair<int64_t, std::pair<int*, int*>>> spike_lists;   // spike signal offset -> (list, count)
+  std::vector<int64_t> seg_spikes;                                       // spike signals whose list is segmented
   std::vector<std::pair<int, float2*>> dft_tables;                      // transform length -> twiddle table
   std::vector<ssn::BatchOp<T>> pre_ops, post_ops;
   std::vector<ssn_range> pre_to_core, core_to_post;
@@ -955,13 +957,19 @@ struct Sim final : ssn_sim {
           } else if (w.transposed) {
             // spike-sparse decoders: partial sums per spike-list chunk, reduced in the following program
             flush();
-            const int chunks = 32;
+            int chunks = 32;
             const int rows_pad = (int)w.ldt;
+            int seg = 0;
+            if (std::find(seg_spikes.begin(), seg_spikes.end(), o.i[1]) != seg_spikes.end()) {
+              const int n_seg = ((int)o.i[3] + 255) / 256;       // segments of 256 neurons, ~32 chunks
+              seg = std::max(1, (n_seg + 31) / 32);
+              chunks = (n_seg + seg - 1) / seg;
+            }
             T* partial = nullptr;
             CHK(dmalloc(&partial, (int64_t)chunks * rows_pad * (int64_t)sizeof(T)));
             scratch_bufs.push_back(partial);
             Item it; it.type = IT_SPMV; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.dst = partial;
-            it.rows = (int)o.i[2]; it.cols = (int)o.i[3]; it.ld = (int)w.ldt; it.n = chunks;
+            it.rows = (int)o.i[2]; it.cols = (int)o.i[3]; it.ld = (int)w.ldt; it.n = chunks; it.seg = seg;
             for (auto& sl : spike_lists) if (sl.first == o.i[1]) { it.list = sl.second.first; it.count = sl.second.second; }
             items.push_back(it);
             MOp r{};
@@ -1000,7 +1008,16 @@ struct Sim final : ssn_sim {
             const ssn_op_desc& q = m->ops[j];
             if (q.kind == SSN_OP_MATVEC && q.stage == 1 && q.i[1] == o.i[1] && q.i[3] == o.i[2] && bufs[q.i[4]].transposed) feeds_sparse = true;
           }
-          if (feeds_sparse && (flags & 32) && o.i[5] == SSN_LIF && o.i[2] <= 16384) {   // measured slower: opt-in
+          if (feeds_sparse && !(flags & 32) && !(flags & 1024)) {
+            // segmented spike list: every 256-neuron workgroup of k_neurons leaves its spikes as an ordered index list
+            const int n_seg = ((int)o.i[2] + 255) / 256;
+            CHK(dmalloc(&it.list, (int64_t)n_seg * 256 * 4));
+            CHK(dmalloc(&it.count, (int64_t)n_seg * 4 + 64));
+            HIPCHK(hipMemset(it.count, 0, (size_t)n_seg * 4 + 64));
+            scratch_bufs.push_back(it.list); scratch_bufs.push_back(it.count);
+            spike_lists.push_back({o.i[1], {it.list, it.count}});
+            seg_spikes.push_back(o.i[1]);
+          } else if (feeds_sparse && (flags & 32) && o.i[5] == SSN_LIF && o.i[2] <= 16384) {   // measured slower: opt-in
             it.type = IT_NEURONS_COMPACT;
             CHK(dmalloc(&it.list, (o.i[2] + 16) * 4));
             CHK(dmalloc(&it.count, 64));
@@ -1272,9 +1289,9 @@ struct Sim final : ssn_sim {
       case IT_MATVEC_ORDERED: return ssn::launch_matvec_ordered<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld);
       case IT_FINISH: return ssn::launch_ens_finish<T>(stream, it.fin);
       case IT_DFT: return ssn::launch_dft<T>(stream, it.dft);
-      case IT_SPMV: return ssn::launch_spmv_partial<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count);
+      case IT_SPMV: return ssn::launch_spmv_partial<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count, it.seg);
       case IT_NEURONS_COMPACT: return ssn::launch_neurons_compact<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count);
-      case IT_NEURONS: return ssn::launch_neurons<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar);
+      case IT_NEURONS: return ssn::launch_neurons<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count);
       case IT_PES: return ssn::launch_pes<T>(stream, it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar);
       case IT_VOJA: return ssn::launch_voja<T>(stream, it.Wm, it.src, it.aux0, it.aux1, it.aux2, it.rows, it.cols, it.ld, it.scalar);
     }

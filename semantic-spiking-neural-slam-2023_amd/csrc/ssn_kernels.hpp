@@ -721,13 +721,14 @@ hipError_t launch_matvec(hipStream_t s, const T* Wm, const T* src, T* dst, int r
 template <typename T>
 __global__ __launch_bounds__(256) void k_spmv_partial(const T* __restrict__ Wt, int ldt, const T* __restrict__ spikes,
                                                       int n, int rows, T* __restrict__ partial, int rows_pad, int chunks,
-                                                      const int* __restrict__ glist, const int* __restrict__ gcount) {
+                                                      const int* __restrict__ glist, const int* __restrict__ gcount, int seg) {
   extern __shared__ unsigned char smem[];
   __shared__ int counts[257];
   const int tid = threadIdx.x;
   const int* list = glist;                      // spike list produced by k_neurons_compact ...
-  int m;
-  if (glist) {
+  int m = 0;
+  if (seg > 0) {
+  } else if (glist) {
     m = gcount[0];
   } else {                                      // ... or compacted here (ascending order, blocked scan)
     int* llist = (int*)smem;
@@ -747,8 +748,27 @@ __global__ __launch_bounds__(256) void k_spmv_partial(const T* __restrict__ Wt, 
     list = llist;
   }
   const int c = blockIdx.y;
-  const int b = (int)((long long)m * c / chunks), e = (int)((long long)m * (c + 1) / chunks);
   const int r = blockIdx.x * 256 + tid;
+  if (seg > 0) {
+    // segmented spike list from k_neurons (256 neurons per segment): chunk c takes segments [c*seg, (c+1)*seg)
+    T acc = T(0);
+    const int n_seg = (n + 255) / 256;
+    if (r < rows)
+      for (int sgm = c * seg; sgm < min(n_seg, (c + 1) * seg); ++sgm) {
+        const int* sl = glist + sgm * 256;
+        const int e = gcount[sgm];
+        int i = 0;
+        for (; i + 4 <= e; i += 4) {
+          const int j0 = sl[i], j1 = sl[i + 1], j2 = sl[i + 2], j3 = sl[i + 3];
+          const T w0 = Wt[(size_t)j0 * ldt + r], w1 = Wt[(size_t)j1 * ldt + r], w2 = Wt[(size_t)j2 * ldt + r], w3 = Wt[(size_t)j3 * ldt + r];
+          acc += spikes[j0] * w0; acc += spikes[j1] * w1; acc += spikes[j2] * w2; acc += spikes[j3] * w3;
+        }
+        for (; i < e; ++i) { const int j = sl[i]; acc += spikes[j] * Wt[(size_t)j * ldt + r]; }
+      }
+    if (r < rows) partial[(size_t)c * rows_pad + r] = acc;
+    return;
+  }
+  const int b = (int)((long long)m * c / chunks), e = (int)((long long)m * (c + 1) / chunks);
   T acc = T(0);
   if (r < rows) {
     int i = b;
@@ -764,9 +784,9 @@ __global__ __launch_bounds__(256) void k_spmv_partial(const T* __restrict__ Wt, 
 
 template <typename T>
 hipError_t launch_spmv_partial(hipStream_t s, const T* Wt, int ldt, const T* spikes, int n, int rows, T* partial, int rows_pad, int chunks,
-                               const int* list, const int* count) {
+                               const int* list, const int* count, int seg) {
   hipLaunchKernelGGL((k_spmv_partial<T>), dim3((rows + 255) / 256, chunks), dim3(256), list ? (size_t)16 : (size_t)n * sizeof(int), s,
-                     Wt, ldt, spikes, n, rows, partial, rows_pad, chunks, list, count);
+                     Wt, ldt, spikes, n, rows, partial, rows_pad, chunks, list, count, seg);
   return hipGetLastError();
 }
 
@@ -853,18 +873,35 @@ hipError_t launch_transpose(hipStream_t s, const T* src, T* dst, int rows, int c
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_neurons(NeuronParams<T> np, const T* __restrict__ J, T* __restrict__ out,
-                                                 T* __restrict__ V, T* __restrict__ R, int n, T amp) {
+                                                 T* __restrict__ V, T* __restrict__ R, int n, T amp,
+                                                 int* __restrict__ seg_list, int* __restrict__ seg_cnt) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  T v = V[i], r = R[i];
-  const T a = neuron_step(np, J[i], v, r);
-  V[i] = v; R[i] = r;
-  out[i] = amp * a;
+  T a = T(0);
+  if (i < n) {
+    T v = V[i], r = R[i];
+    a = neuron_step(np, J[i], v, r);
+    V[i] = v; R[i] = r;
+    out[i] = amp * a;
+  }
+  if (seg_list) {
+    // this workgroup's spikes as an ascending index list (segment blockIdx.x of the ensemble's segmented spike
+    // list): the spike-sparse decoder product walks segments in order and never has to scan the spike vector
+    __shared__ int wcnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long mask = __ballot(a != T(0));
+    if (lane == 0) wcnt[wave] = __popcll(mask);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wcnt[w];
+    if (a != T(0)) seg_list[blockIdx.x * 256 + base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+    if (threadIdx.x == 0) seg_cnt[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+  }
 }
 
 template <typename T>
-hipError_t launch_neurons(hipStream_t s, const NeuronParams<T>& np, const T* J, T* out, T* V, T* R, int n, T amp) {
-  hipLaunchKernelGGL((k_neurons<T>), dim3((n + 255) / 256), dim3(256), 0, s, np, J, out, V, R, n, amp);
+hipError_t launch_neurons(hipStream_t s, const NeuronParams<T>& np, const T* J, T* out, T* V, T* R, int n, T amp,
+                          int* seg_list, int* seg_cnt) {
+  hipLaunchKernelGGL((k_neurons<T>), dim3((n + 255) / 256), dim3(256), 0, s, np, J, out, V, R, n, amp, seg_list, seg_cnt);
   return hipGetLastError();
 }
 
@@ -1139,10 +1176,10 @@ namespace ssn {
   template hipError_t launch_ens_finish<T>(hipStream_t, const FinishArgs<T>&);                               \
   template hipError_t launch_matvec<T>(hipStream_t, const T*, const T*, T*, int, int, int, int);            \
   template hipError_t launch_matvec_ordered<T>(hipStream_t, const T*, const T*, T*, int, int, int);         \
-  template hipError_t launch_spmv_partial<T>(hipStream_t, const T*, int, const T*, int, int, T*, int, int, const int*, const int*);  \
+  template hipError_t launch_spmv_partial<T>(hipStream_t, const T*, int, const T*, int, int, T*, int, int, const int*, const int*, int);  \
   template hipError_t launch_neurons_compact<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T, int*, int*);     \
   template hipError_t launch_transpose<T>(hipStream_t, const T*, T*, int, int, int, int);                   \
-  template hipError_t launch_neurons<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T); \
+  template hipError_t launch_neurons<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T, int*, int*); \
   template hipError_t launch_pes<T>(hipStream_t, T*, const T*, const T*, int, int, int, T);                 \
   template hipError_t launch_voja<T>(hipStream_t, T*, const T*, const T*, const T*, const T*, int, int, int, T); \
   template hipError_t launch_batch_op<T>(hipStream_t, const BatchOp<T>&);                                   \
