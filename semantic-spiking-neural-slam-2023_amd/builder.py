@@ -913,7 +913,9 @@ def schedule_ops(ops, model):
 
     Kahn's algorithm in rounds.  A round takes every ready cheap vector op ("micro") at once - they
     were all ready together, so they touch disjoint data and need no barrier between them - or,
-    when none is ready, the single oldest big op.  ``level`` is the round number: the device-side
+    when none is ready, every ready big op (oldest first: independent branches of the graph - the four
+    dense ensembles of a SLAM network, say - advance side by side, so their small follow-up operators
+    become ready together and share one launch).  ``level`` is the round number: the device-side
     program executor puts a workgroup barrier between micro ops of different level, and runs of
     consecutive micro ops become one launch.
     """
@@ -940,7 +942,7 @@ def schedule_ops(ops, model):
     out, level = [], 0
     while ready:
         micro = [i for i in ready if is_micro(ops[i])]
-        pick = sorted(micro, key=lambda i: ops[i]["seq"]) if micro else [min(ready, key=lambda i: ops[i]["seq"])]
+        pick = sorted(micro if micro else ready, key=lambda i: ops[i]["seq"])
         for i in pick:
             ready.remove(i)
         for i in pick:
