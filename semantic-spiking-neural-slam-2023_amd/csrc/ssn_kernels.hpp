@@ -693,37 +693,65 @@ hipError_t program_set_max_lds(int bytes) {
 // path integrator outside loop closures) the wave skips W entirely - exact, and it saves the
 // whole matrix read.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool XLDS>
 __global__ __launch_bounds__(256) void k_matvec(const T* __restrict__ Wm, const T* __restrict__ sig_src,
                                                 T* __restrict__ sig_dst, int rows, int cols, int ld, int set) {
+  // y = W x, one wave per FOUR rows (16 rows per workgroup): the source vector is staged in LDS once per
+  // workgroup (XLDS) and each lane keeps four independent 16-byte row loads in flight per trip.  Per row the
+  // lane-strided accumulation and the wave reduction are the same sequence as a one-row-per-wave kernel.
   using vec = typename VecT<T>::type;
   constexpr int W = VecT<T>::W;
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  constexpr int RW = 4;
+  extern __shared__ __align__(16) unsigned char ssn_mv_dyn[];
+  T* xs = reinterpret_cast<T*>(ssn_mv_dyn);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int nz = 0;
-  for (int c = lane; c < cols; c += 64) nz |= (sig_src[c] != T(0));
-  if (!__any(nz)) {
-    if (set && lane == 0) sig_dst[row] = T(0);
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const T v = sig_src[c];
+    if (XLDS) xs[c] = v;
+    nz |= (v != T(0));
+  }
+  nz = __syncthreads_or(nz);
+  const int r0 = (blockIdx.x * 4 + wave) * RW;
+  if (r0 >= rows) return;
+  if (!nz) {                                   // all-zero input (correction / init paths are zero most of the time)
+    if (set && lane < RW && r0 + lane < rows) sig_dst[r0 + lane] = T(0);
     return;
   }
-  const T* wr = Wm + (size_t)row * ld;
-  T s = T(0);
+  const T* __restrict__ x = XLDS ? xs : sig_src;
+  const T* wr[RW];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) wr[q] = Wm + (size_t)min(r0 + q, rows - 1) * ld;
+  T s[RW];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) s[q] = T(0);
   const int n_vec = cols / W;
   for (int v = lane; v < n_vec; v += 64) {
-    T w[W];
-    *(vec*)w = *(const vec*)(wr + (size_t)v * W);
+    T w[RW][W], xv[W];
 #pragma unroll
-    for (int j = 0; j < W; ++j) s += w[j] * sig_src[v * W + j];
+    for (int q = 0; q < RW; ++q) *(vec*)w[q] = *(const vec*)(wr[q] + (size_t)v * W);
+    *(vec*)xv = *(const vec*)(x + (size_t)v * W);
+#pragma unroll
+    for (int q = 0; q < RW; ++q)
+#pragma unroll
+      for (int j = 0; j < W; ++j) s[q] += w[q][j] * xv[j];
   }
-  for (int c = n_vec * W + lane; c < cols; c += 64) s += wr[c] * sig_src[c];
-  s = wave_sum(s);
-  if (lane == 0) { if (set) sig_dst[row] = s; else sig_dst[row] += s; }
+  for (int c = n_vec * W + lane; c < cols; c += 64)
+#pragma unroll
+    for (int q = 0; q < RW; ++q) s[q] += wr[q][c] * x[c];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) {
+    const T t = wave_sum(s[q]);
+    if (lane == 0 && r0 + q < rows) { if (set) sig_dst[r0 + q] = t; else sig_dst[r0 + q] += t; }
+  }
 }
 
 template <typename T>
 hipError_t launch_matvec(hipStream_t s, const T* Wm, const T* src, T* dst, int rows, int cols, int ld, int set) {
-  hipLaunchKernelGGL((k_matvec<T>), dim3((rows + 3) / 4), dim3(256), 0, s, Wm, src, dst, rows, cols, ld, set);
+  const size_t xb = (size_t)cols * sizeof(T);
+  const dim3 grid((rows + 15) / 16), block(256);
+  if (xb <= 48 * 1024) hipLaunchKernelGGL((k_matvec<T, true>), grid, block, xb, s, Wm, src, dst, rows, cols, ld, set);
+  else hipLaunchKernelGGL((k_matvec<T, false>), grid, block, 0, s, Wm, src, dst, rows, cols, ld, set);
   return hipGetLastError();
 }
 
