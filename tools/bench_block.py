@@ -21,7 +21,7 @@ s = H.make_ssp_space(2, d)
 path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
 pm = H.make_pathint_model(s, path, vels, n)
 t0 = time.time()
-bm = build(pm.model, n_eval_points=m_eval)
+bm = build(pm.model, n_eval_points=m_eval or None)
 print("build %.1fs" % (time.time() - t0), bm.stats, flush=True)
 base = None
 for v in variants:
