@@ -50,10 +50,27 @@ __device__ inline float row_sum_dpp(float v) {
 #undef SSN_DPP_ADD
   return v;
 }
+// N independent wave sums, stage by stage (result of each in lane 63)
+template <int N>
+__device__ inline void wave_sum_dpp_n(float* v) {
+#define SSN_DPP_STAGE(ctrl, rmask)                                                                            \
+  _Pragma("unroll") for (int r = 0; r < N; ++r) {                                                              \
+    const int x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[r]), ctrl, rmask, 0xF, false);      \
+    v[r] += __builtin_bit_cast(float, x);                                                                      \
+  }
+  SSN_DPP_STAGE(0xB1, 0xF) SSN_DPP_STAGE(0x4E, 0xF) SSN_DPP_STAGE(0x141, 0xF) SSN_DPP_STAGE(0x140, 0xF)
+  SSN_DPP_STAGE(0x142, 0xA) SSN_DPP_STAGE(0x143, 0xC)
+#undef SSN_DPP_STAGE
+}
 __device__ inline double wave_sum_dpp(double v) {     // parity/test instantiation: plain shuffles, result in every lane
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+template <int N>
+__device__ inline void wave_sum_dpp_n(double* v) {
+#pragma unroll
+  for (int r = 0; r < N; ++r) v[r] = wave_sum_dpp(v[r]);
 }
 
 // Branch-free f32 LIF step on the packed state word (s >= 0: voltage; s < 0: minus the remaining refractory
@@ -211,6 +228,11 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
 #pragma unroll
   for (int r = 0; r < DOUT; ++r) tot[r] = T(0);
 
+  G en[DIN];                                 // ENC_LDS: encoders of the group about to be processed
+  if constexpr (ENC_LDS) {
+#pragma unroll
+    for (int d = 0; d < DIN; ++d) en[d] = *reinterpret_cast<const G*>(e_lds + d * cap + tid * PK);
+  }
   for (int j0 = 0; j0 < a.B; j0 += CH) {
     const int cn = min(CH, a.B - j0);
     __syncthreads();                         // previous chunk: every wave is past its last xs read / os write
@@ -241,14 +263,26 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
       G accg[DOUT];
 #pragma unroll
       for (int r = 0; r < DOUT; ++r) accg[r] = G(0);
+      // ENC_LDS: a thread reads back only the entries it wrote itself (no barrier needed); the next group's
+      // encoders are requested one group ahead so the LDS latency hides under this group's arithmetic (with two
+      // waves per SIMD an exposed ds_read stalls the SIMD)
+      G nx[DIN];
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
+        if constexpr (ENC_LDS) {          // (the last group requests group 0 again: the next timestep's first operands)
+          const int gn = g + 1 < NG ? g + 1 : 0;
+#pragma unroll
+          for (int d = 0; d < DIN; ++d) nx[d] = *reinterpret_cast<const G*>(e_lds + d * cap + (gn * nthr + tid) * PK);
+        }
         G J = b[g];
 #pragma unroll
         for (int d = 0; d < DIN; ++d) {
-          // ENC_LDS: a thread reads back only the entries it wrote itself - no barrier needed
-          if constexpr (ENC_LDS) J += *reinterpret_cast<const G*>(e_lds + d * cap + (g * nthr + tid) * PK) * x[d];
+          if constexpr (ENC_LDS) J += en[d] * x[d];
           else J += e[g][d] * x[d];
+        }
+        if constexpr (ENC_LDS) {
+#pragma unroll
+          for (int d = 0; d < DIN; ++d) en[d] = nx[d];
         }
         G spk;
         if constexpr (F32) spk = lif_packed_step_f32x2(J, s[g], lc);
@@ -283,10 +317,19 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
         if constexpr (F32) acc[r] = accg[r].x + accg[r].y; else acc[r] = accg[r];
       }
       const int par = jj & 1;
+#if defined(SSN_BLOCK_EXPERIMENT) && SSN_BLOCK_EXPERIMENT == 1      /* timing bisection only: no reduction (wrong results) */
 #pragma unroll
-      for (int r = 0; r < DOUT; ++r) {
-        const T w = wave_sum_dpp(acc[r]);
-        if (lane == 63) red[par][r * 16 + wave] = w;
+      for (int r = 0; r < DOUT; ++r) tot[r] = acc[r] * T(1e-30);
+#else
+      // the DOUT wave reductions are independent: all sums first (their DPP stages interleave and fill each
+      // other's wait states), then one predicated store block
+      T wsum[DOUT];
+#pragma unroll
+      for (int r = 0; r < DOUT; ++r) wsum[r] = acc[r];
+      wave_sum_dpp_n<DOUT>(wsum);
+      if (lane == 63) {
+#pragma unroll
+        for (int r = 0; r < DOUT; ++r) red[par][r * 16 + wave] = wsum[r];
       }
       __syncthreads();
       if constexpr (sizeof(T) == 4) {
@@ -311,6 +354,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
           tot[r] = t;
         }
       }
+#endif
       if (CLUSTER && a.P > 1) {
         // ---- cluster exchange: publish this workgroup's partial sums as 8-byte {payload, tag = step} granules
         //      (one atomic store each: data and flag arrive together), collect the P partials of the step, add
