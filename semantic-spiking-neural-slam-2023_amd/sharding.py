@@ -52,7 +52,7 @@ class _BlockFeed:
 class ShardedPathIntegration:
     def __init__(self, pm, rank, world, dt=0.001, dtype="f32", device=0, n_eval_points=None, block=1000,
                  sim_factory=None, dist=None, gather_device=None, async_readout=True, block_steps=0,
-                 device_exchange=None, defer_readout=16):
+                 device_exchange=None, defer_readout=None):
         """``pm``: object from ``harness.make_pathint_model`` (model, pathintegrator, probe)."""
         if dist is None:
             import torch.distributed as dist
@@ -73,6 +73,11 @@ class ShardedPathIntegration:
         # 256 CUs hold a k_ens_block workgroup for the whole block - so read-out kernels launched meanwhile would
         # crawl on the few free CUs.  Gathered blocks (6 MB each at d = 1015) are therefore kept in HBM and replayed
         # through the read-out `defer_readout` blocks at a time, or when flush() / probe_data() asks for them.
+        # Default: defer (16 blocks at a time) when this rank's VCOs occupy most of the GPU (> 192 of 256 CUs),
+        # otherwise hand each block to the worker thread at once - the read-out then overlaps the next block
+        # on the idle CUs.
+        if defer_readout is None:
+            defer_readout = 16 if (self.hi - self.lo) > 192 else 0
         self.defer_readout = int(defer_readout)
         self._pending = []
         # --- this rank's VCO shard: probe = local slice of the oscillator output node ----------------
@@ -209,9 +214,16 @@ class ShardedPathIntegration:
             self.sim.run_steps(n, collect=False)
             full = self._gather_device(n)
             if self.readout is not None:
-                self._pending.append((full, self.n_steps, n))
-                if len(self._pending) >= max(1, self.defer_readout):
-                    self._drain_pending()
+                if self.defer_readout > 0:
+                    self._pending.append((full, self.n_steps, n))
+                    if len(self._pending) >= self.defer_readout:
+                        self._drain_pending()
+                elif self._jobs is not None:
+                    if self._error is not None:
+                        self.flush()
+                    self._jobs.put((full, self.n_steps, n))
+                else:
+                    self._replay(full, self.n_steps, n)
             self.n_steps += n
             return
         self.sim.run_steps(n, collect=True)
