@@ -1060,6 +1060,41 @@ __global__ __launch_bounds__(64) void kb_lowpass(BatchOp<T> o) {
   for (; t < o.B; ++t) { y = o.a * y + o.b * u[(size_t)t * o.n_sig]; out[(size_t)t * o.n_sig] = y; }
 }
 
+// f32 scan along time, time split into C chunks per element (the f64 parity mode keeps the sequential recurrence
+// of kb_lowpass): thread (element i, chunk c) first runs its chunk from a zero state to get the chunk's own
+// contribution L_c, the chunk carries  Y_c = a^len_c * Y_{c-1} + L_c  are chained through LDS, then every thread
+// re-runs its chunk from the right carry and writes the outputs.  2 * B / C dependent steps instead of B.
+template <int C>
+__global__ __launch_bounds__(64 * C) void kb_lowpass_chunked(BatchOp<float> o) {
+  __shared__ float sl[C][64];
+  __shared__ float sp[C][64];
+  const int e = threadIdx.x & 63, c = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + e;
+  const int per = (o.B + C - 1) / C;
+  const int t0 = min(o.B, c * per), t1 = min(o.B, t0 + per);
+  const bool ok = i < o.len;
+  const float* u = o.bsig + (size_t)(1 - o.src_prev) * o.n_sig + o.src + (ok ? i : 0);
+  float y = 0.0f, pw = 1.0f;
+  if (ok)
+    for (int t = t0; t < t1; ++t) { y = o.a * y + o.b * u[(size_t)t * o.n_sig]; pw *= o.a; }
+  sl[c][e] = y; sp[c][e] = pw;
+  __syncthreads();
+  if (!ok) return;
+  float carry = o.bsig[o.dst + i];                            // row 0: state before the block
+  for (int q = 0; q < c; ++q) carry = sp[q][e] * carry + sl[q][e];
+  float* out = o.bsig + (size_t)o.n_sig + o.dst + i;
+  y = carry;
+  int t = t0;
+  for (; t + 8 <= t1; t += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = u[(size_t)(t + j) * o.n_sig];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { y = o.a * y + o.b * v[j]; out[(size_t)(t + j) * o.n_sig] = y; }
+  }
+  for (; t < t1; ++t) { y = o.a * y + o.b * u[(size_t)t * o.n_sig]; out[(size_t)t * o.n_sig] = y; }
+}
+
 // C[t][r] (+)= sum_c A[t][c] * W[r][c]   (A = block rows of the source signal, W row-major [rows][ld])
 // 32 x 32 output tile per 256-thread workgroup, K staged through LDS in slabs of 32.
 template <typename T>
@@ -1161,6 +1196,12 @@ template <typename T>
 hipError_t launch_batch_op(hipStream_t s, const BatchOp<T>& o) {
   if (o.B <= 0 || o.len <= 0) return hipSuccess;
   if (o.kind == M_LOWPASS) {
+    if constexpr (sizeof(T) == 4) {
+      if (o.B >= 256) {
+        hipLaunchKernelGGL((kb_lowpass_chunked<8>), dim3((unsigned)((o.len + 63) / 64)), dim3(512), 0, s, o);
+        return hipGetLastError();
+      }
+    }
     hipLaunchKernelGGL((kb_lowpass<T>), dim3((unsigned)((o.len + 63) / 64)), dim3(64), 0, s, o);
   } else if ((o.kind == M_MATVEC_INC || o.kind == M_MATVEC_SET) && sizeof(T) == 4 && o.cols >= 64 && o.len >= 32 && o.B >= 32) {
     if constexpr (sizeof(T) == 4)

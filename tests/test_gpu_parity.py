@@ -318,6 +318,12 @@ def test_feedforward_model_runs_fully_batched(Simulator):
         for i, p in enumerate((p1, p2, p3)):
             np.testing.assert_allclose(sim.data[p], ref.probe_data(i), atol=1e-12, rtol=0)
         assert sim.data[p3].shape == (100, 5)
+    # f32: MFMA GEMM and the chunked scan (blocks of >= 256 timesteps) against the same oracle run
+    ref.run_steps(400)
+    with Simulator(None, model=model, dtype="f32", block_steps=512) as sim:
+        sim.run_steps(700)
+        for i, p in enumerate((p1, p2, p3)):
+            np.testing.assert_allclose(sim.data[p], ref.probe_data(i), atol=2e-5, rtol=0)
 
 
 def test_sharded_runner_on_hip_matches_unsharded(Simulator):
