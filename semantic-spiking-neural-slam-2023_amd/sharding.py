@@ -52,7 +52,7 @@ class _BlockFeed:
 class ShardedPathIntegration:
     def __init__(self, pm, rank, world, dt=0.001, dtype="f32", device=0, n_eval_points=None, block=1000,
                  sim_factory=None, dist=None, gather_device=None, async_readout=True, block_steps=0,
-                 device_exchange=None, defer_readout=None):
+                 device_exchange=None, defer_readout=None, gather_every=4):
         """``pm``: object from ``harness.make_pathint_model`` (model, pathintegrator, probe)."""
         if dist is None:
             import torch.distributed as dist
@@ -80,6 +80,11 @@ class ShardedPathIntegration:
             defer_readout = 16 if (self.hi - self.lo) > 192 else 0
         self.defer_readout = int(defer_readout)
         self._pending = []
+        # Device path: the oscillator samples stay in the simulator's probe storage, so the all-gather (and its
+        # fixed host + launch cost, ~0.3 ms against a 2.7 ms block) is issued once per `gather_every` blocks.
+        # flush() gathers the remainder and is therefore a COLLECTIVE on this path: call it on every rank.
+        self.gather_every = max(1, int(gather_every))
+        self._ungathered = 0
         # --- this rank's VCO shard: probe = local slice of the oscillator output node ----------------
         with pm.model:
             width = 3 * (self.hi - self.lo)
@@ -184,8 +189,18 @@ class ShardedPathIntegration:
         for job in pending:
             self._replay(*job)
 
+    def _drain_jobs(self):
+        if self._jobs is not None:
+            self._jobs.join()
+            if self._error is not None:
+                err, self._error = self._error, None
+                raise err
+
     def flush(self):
-        """Wait until the read-out has consumed every block handed to it."""
+        """Wait until the read-out has consumed every block handed to it.  On the device path this first gathers the
+        timesteps not exchanged yet - a collective: every rank must call it."""
+        if self._ungathered:
+            self._exchange_pending()
         self._drain_pending()
         if self._jobs is not None:
             self._jobs.join()
@@ -212,19 +227,10 @@ class ShardedPathIntegration:
         n = self.block if n is None else int(n)
         if self._device_exchange():
             self.sim.run_steps(n, collect=False)
-            full = self._gather_device(n)
-            if self.readout is not None:
-                if self.defer_readout > 0:
-                    self._pending.append((full, self.n_steps, n))
-                    if len(self._pending) >= self.defer_readout:
-                        self._drain_pending()
-                elif self._jobs is not None:
-                    if self._error is not None:
-                        self.flush()
-                    self._jobs.put((full, self.n_steps, n))
-                else:
-                    self._replay(full, self.n_steps, n)
+            self._ungathered += n
             self.n_steps += n
+            if self._ungathered >= self.gather_every * self.block:
+                self._exchange_pending()
             return
         self.sim.run_steps(n, collect=True)
         if self.osc_probe is not None:
@@ -241,6 +247,27 @@ class ShardedPathIntegration:
             else:
                 self._replay(full, self.n_steps, n)
         self.n_steps += n
+
+    def _exchange_pending(self):
+        """Device path: gather every timestep stepped since the last exchange and hand it to the read-out."""
+        n = self._ungathered
+        if n == 0:
+            return
+        self._ungathered = 0
+        first = self.n_steps - n
+        full = self._gather_device(n)
+        if self.readout is None:
+            return
+        if self.defer_readout > 0:
+            self._pending.append((full, first, n))
+            if len(self._pending) * self.gather_every >= self.defer_readout:
+                self._drain_pending()
+        elif self._jobs is not None:
+            if self._error is not None:
+                self._drain_jobs()
+            self._jobs.put((full, first, n))
+        else:
+            self._replay(full, first, n)
 
     def run_steps(self, n):
         done = 0

@@ -355,10 +355,12 @@ def test_sharded_runner_device_exchange(Simulator):
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1)
         created = True
     try:
-        for dtype, tol, defer in (("f64", 1e-9, None), ("f64", 1e-9, 2), ("f32", None, None)):
+        for dtype, tol, defer, every in (("f64", 1e-9, None, 4), ("f64", 1e-9, 2, 1), ("f32", None, None, 2)):
             pm2 = small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2)
-            # read-out replayed block by block on the worker thread (default for small shards) or deferred
-            r = ShardedPathIntegration(pm2, 0, 1, dtype=dtype, block=128, device_exchange=True, defer_readout=defer)
+            # read-out replayed on the worker thread (default for small shards) or deferred; exchange every
+            # `every` blocks (the remainder is gathered by flush() / probe_data())
+            r = ShardedPathIntegration(pm2, 0, 1, dtype=dtype, block=128, device_exchange=True, defer_readout=defer,
+                                       gather_every=every)
             r.prepare(300)
             r.run_steps(300)
             got = r.probe_data()
