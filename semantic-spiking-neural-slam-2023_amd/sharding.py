@@ -165,8 +165,9 @@ class ShardedPathIntegration:
         out = torch.empty((self.world, n, 3 * self.per), dtype=tdt, device=dev)
         if self.dist.is_initialized():
             self.dist.all_gather_into_tensor(out, send)
-        else:                                          # single process (tests): nothing to exchange
-            out[0] = send
+        else:                                          # no process group (tests): only this rank's slot is filled
+            out.zero_()
+            out[self.rank] = send
         full = out.permute(1, 0, 2).reshape(n, self.world * 3 * self.per)[:, :3 * self.K].contiguous()
         torch.cuda.current_stream().synchronize()      # the read-out simulator runs on its own HIP stream
         return full

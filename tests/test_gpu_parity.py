@@ -372,6 +372,19 @@ def test_sharded_runner_device_exchange(Simulator):
     finally:
         if created:
             dist.destroy_process_group()
+    # a last rank with fewer VCOs than the others (28 VCOs over 3 ranks: 10, 10, 8): its samples are padded to the
+    # common width before the all-gather; without a process group its slot of the gathered block is checked alone
+    pm3 = small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2)
+    r = ShardedPathIntegration(pm3, 2, 3, dtype="f64", block=64, device_exchange=True)
+    assert (r.lo, r.hi, r.per) == (20, 28, 10) and r.readout is None
+    r.prepare(64)
+    r.sim.run_steps(64, collect=False)
+    full = r._gather_device(64).cpu().numpy()
+    own = r.sim.data[r.osc_probe]
+    assert full.shape == (64, 3 * 28) and np.abs(own).max() > 0
+    np.testing.assert_array_equal(full[:, :60], 0.0)                   # the other ranks' slots (nobody filled them)
+    np.testing.assert_array_equal(full[:, 60:84], own[:, :24])
+    r.close()
 
 
 def test_fused_recurrent_core_equals_generic_path(Simulator):
