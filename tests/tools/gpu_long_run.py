@@ -16,8 +16,8 @@ bm = build(pm.model, n_eval_points=4000 if n >= 2000 else None)
 steps = int(T / 0.001)
 real = s.encode(path[:steps])
 outs = {}
-for name, flags in (("block", 0), ("step", 128)):
-    sim = Simulator(None, model=bm, dtype="f32", flags=flags)
+for name, flags, dtype in (("block", 0, "f32"), ("step", 128, "f32"), ("f64", 0, "f64")):
+    sim = Simulator(None, model=bm, dtype=dtype, flags=flags)
     t0 = time.time(); sim.run_steps(steps); el = time.time() - t0
     out = sim.data[pm.probe]
     sims = np.sum(out * real, axis=1) / np.maximum(np.linalg.norm(out, axis=1), 1e-12)
@@ -28,3 +28,6 @@ for name, flags in (("block", 0), ("step", 128)):
     sim.close()
 ce = H.cosine_error(outs["block"][0][20:], outs["step"][0][20:])
 print("block vs step kernel cosine error: first 1 s max %.2e, whole run max %.2e, mean %.2e" % (ce[:980].max(), ce.max(), ce.mean()))
+ce = H.cosine_error(outs["block"][0][20:], outs["f64"][0][20:])
+print("f32 block kernel vs f64 parity mode (equal to the NumPy oracle to rounding) cosine error: first 1 s max %.2e, whole run max %.2e, mean %.2e"
+      % (ce[:980].max(), ce.max(), ce.mean()))
