@@ -207,14 +207,23 @@ def test_slam_f64_matches_oracle(Simulator):
 
 
 def test_slam_f32_within_cosine_bar(Simulator):
-    sm = _small_slam(weights_every=None)
+    """f32 fast mode: trajectory and map-recall vectors (run_slam.py:263-268) within 1e-3 cosine of the oracle."""
+    import sspslam_amd.frontend as fe
+    sm = _small_slam(weights_every=0.1)
     model = build(sm.model)
     ref = OracleSimulator(model)
     ref.run_steps(300)
+    mem = sm.slam.assomemory.memory
     with Simulator(None, model=model, dtype="f32") as sim:
         sim.run_steps(300)
         ce = H.cosine_error(sim.data[sm.probe][20:], ref.probe_data(0)[20:])
+        W_gpu = sim.data[sm.weights_probe]
     assert ce.max() < 1e-3, ce.max()
+    rec_g, _ = H.map_recall(sm.ssp_space, sm.lm_space, model.params[mem], fe.LIF(), W_gpu[-1])
+    rec_r, _ = H.map_recall(sm.ssp_space, sm.lm_space, model.params[mem], fe.LIF(), ref.probe_data(1)[-1])
+    seen = np.linalg.norm(rec_r, axis=1) > 1e-6            # landmarks the memory has learned something about
+    assert seen.any()
+    assert H.cosine_error(rec_g[seen], rec_r[seen]).max() < 1e-3
 
 
 def test_slamview_f64_matches_oracle(Simulator):
