@@ -543,7 +543,7 @@ struct Sim final : ssn_sim {
     int rest = d;
     for (int p = 2; p <= 32 && rest > 1; ++p)
       while (rest % p == 0) { rad.push_back(p); rest /= p; }
-    if (rest != 1 || rad.size() > 12 || d < 8 || (int64_t)d * 24 > 150 * 1024) return SSN_OK;
+    if (rest != 1 || rad.size() > 12 || d < 8 || d > 6400) return SSN_OK;      // (6400: LDS 24 B per point, 32-bit index products)
     std::sort(rad.rbegin(), rad.rend());
     float2* tw = nullptr;
     for (auto& t : dft_tables) if (t.first == d) tw = t.second;
@@ -962,7 +962,7 @@ struct Sim final : ssn_sim {
             int seg = 0;
             if (std::find(seg_spikes.begin(), seg_spikes.end(), o.i[1]) != seg_spikes.end()) {
               const int n_seg = ((int)o.i[3] + 255) / 256;       // segments of 256 neurons, ~32 chunks
-              seg = std::max(1, (n_seg + 31) / 32);
+              seg = std::max(1, (n_seg + 63) / 64);
               chunks = (n_seg + seg - 1) / seg;
             }
             T* partial = nullptr;

@@ -444,15 +444,17 @@ __global__ __launch_bounds__(1024) void k_dft(DftArgs a) {
   __syncthreads();
   int n = N, s = 1;
   for (int st = 0; st < a.nr; ++st) {
-    const int r = a.radix[st], m = n / r, fn = N / n, fr = N / r;
+    const unsigned r = (unsigned)a.radix[st], m = (unsigned)n / r, fn = (unsigned)(N / n), fr = (unsigned)N / r;
     for (int o = tid; o < N; o += nthr) {
-      const int q = o % s, u = o / s, j = u % r, p = u / r;
-      int idx = (int)(((long long)p * j * fn) % N);
-      const int step = (int)(((long long)j * fr) % N);
+      // (all products below stay under 2^32: p j fn <= N * 32 * N / n... with N <= 6400, see plan_dft)
+      const unsigned uo = (unsigned)o, us = (unsigned)s;
+      const unsigned q = uo % us, u = uo / us, j = u % r, p = u / r;
+      int idx = (int)((p * j * fn) % (unsigned)N);
+      const int step = (int)((j * fr) % (unsigned)N);
       const float2* xi = x + q + s * p;
       float2 acc = make_float2(0.0f, 0.0f);
-      for (int k = 0; k < r; ++k) {
-        const float2 v = xi[s * m * k], t = tw[idx];
+      for (int k = 0; k < (int)r; ++k) {
+        const float2 v = xi[(unsigned)s * m * (unsigned)k], t = tw[idx];
         acc.x = fmaf(v.x, t.x, fmaf(-v.y, t.y, acc.x));
         acc.y = fmaf(v.x, t.y, fmaf(v.y, t.x, acc.y));
         idx += step;
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(1024) void k_dft(DftArgs a) {
     }
     __syncthreads();
     float2* t2 = x; x = y; y = t2;
-    n = m; s *= r;
+    n = (int)m; s *= (int)r;
   }
   if (a.kind != 5) {
     const bool conj = a.kind >= 3, slotB = a.kind == 2 || a.kind == 4;
@@ -555,8 +557,9 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
         int row = -1;
         if (rel >= 0 && rel < t->n_idx) row = t->idx[rel];
         const T* rows = (const T*)t->rows;
-        for (long long i = tid; i < op.len; i += 1024)
-          sig[op.dst + i] = (row >= 0 && row < t->n_rows) ? rows[(size_t)row * t->width + i] : T(0);
+        const bool have = row >= 0 && row < t->n_rows;
+        vec4_loop<T>(tid, op.len, [&](long long i) { return have ? rows[(size_t)row * t->width + i] : T(0); },
+                     [&](long long i, T v) { sig[op.dst + i] = v; });
         break;
       }
       case M_MATVEC_INC:
@@ -600,9 +603,13 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
         T best = T(-INFINITY);
         int bi = 0x7fffffff;
         const T* sims = (const T*)op.p1;
-        for (int i = tid; i < (int)op.i0; i += 1024) {
-          const T v = sims[i];
-          if (v > best) { best = v; bi = i; }     // first maximum within a thread (ascending i)
+        for (int i0 = tid; i0 < (int)op.i0; i0 += 4096) {       // four reads in flight, examined in ascending order
+          T v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int i = i0 + u * 1024; v[u] = i < (int)op.i0 ? sims[i] : T(-INFINITY); }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (v[u] > best) { best = v[u]; bi = i0 + u * 1024; }     // first maximum within a thread (ascending i)
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -617,7 +624,7 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
           if (sred[w] > best || (sred[w] == best && sidx[w] < bi)) { best = sred[w]; bi = sidx[w]; }
         if (bi == 0x7fffffff) bi = 0;
         const T* tab = (const T*)op.p0;
-        for (long long i = tid; i < op.len; i += 1024) sig[op.dst + i] = tab[(size_t)bi * op.i1 + i];
+        vec4_loop<T>(tid, op.len, [&](long long i) { return tab[(size_t)bi * op.i1 + i]; }, [&](long long i, T v) { sig[op.dst + i] = v; });
         __syncthreads();
         break;
       }
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
           const long long slot = s1 / ps->every - 1 - ps->base_slot;
           if (slot >= 0 && slot < ps->capacity) {
             T* out = (T*)ps->data + (size_t)slot * op.len;
-            for (long long i = tid; i < op.len; i += 1024) out[i] = sig[op.src + i];
+            vec4_loop<T>(tid, op.len, [&](long long i) { return sig[op.src + i]; }, [&](long long i, T v) { out[i] = v; });
           } else if (tid == 0) {
             ctx->probe_overflow = 1;
           }
@@ -649,9 +656,18 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
       case M_REDUCE_SET:
       case M_REDUCE_INC: {   // p0 = partial [i0 chunks][i1 rows_pad]: dst[r] (+)= sum_c partial[c][r], fixed order
         const T* part = (const T*)op.p0;
+        const int nc = (int)op.i0;
         for (long long r = tid; r < op.len; r += 1024) {
           T s = T(0);
-          for (int c = 0; c < (int)op.i0; ++c) s += part[(size_t)c * op.i1 + r];
+          int c = 0;
+          for (; c + 8 <= nc; c += 8) {            // eight chunk reads in flight, added in chunk order
+            T v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(c + q) * op.i1 + r];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+          }
+          for (; c < nc; ++c) s += part[(size_t)c * op.i1 + r];
           if (op.kind == M_REDUCE_INC) sig[op.dst + r] += s; else sig[op.dst + r] = s;
         }
         break;
@@ -803,10 +819,14 @@ __global__ __launch_bounds__(256) void k_spmv_partial(const T* __restrict__ Wt, 
         const int* sl = glist + sgm * 256;
         const int e = gcount[sgm];
         int i = 0;
-        for (; i + 4 <= e; i += 4) {
-          const int j0 = sl[i], j1 = sl[i + 1], j2 = sl[i + 2], j3 = sl[i + 3];
-          const T w0 = Wt[(size_t)j0 * ldt + r], w1 = Wt[(size_t)j1 * ldt + r], w2 = Wt[(size_t)j2 * ldt + r], w3 = Wt[(size_t)j3 * ldt + r];
-          acc += spikes[j0] * w0; acc += spikes[j1] * w1; acc += spikes[j2] * w2; acc += spikes[j3] * w3;
+        for (; i + 8 <= e; i += 8) {           // eight independent row reads in flight per lane
+          int j[8]; T w[8], sv[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) j[q] = sl[i + q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { w[q] = Wt[(size_t)j[q] * ldt + r]; sv[q] = spikes[j[q]]; }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc += sv[q] * w[q];
         }
         for (; i < e; ++i) { const int j = sl[i]; acc += spikes[j] * Wt[(size_t)j * ldt + r]; }
       }
