@@ -1095,8 +1095,17 @@ __global__ __launch_bounds__(64 * C) void kb_lowpass_chunked(BatchOp<float> o) {
   const bool ok = i < o.len;
   const float* u = o.bsig + (size_t)(1 - o.src_prev) * o.n_sig + o.src + (ok ? i : 0);
   float y = 0.0f, pw = 1.0f;
-  if (ok)
-    for (int t = t0; t < t1; ++t) { y = o.a * y + o.b * u[(size_t)t * o.n_sig]; pw *= o.a; }
+  if (ok) {
+    int t = t0;
+    for (; t + 8 <= t1; t += 8) {           // eight row reads in flight
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = u[(size_t)(t + j) * o.n_sig];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { y = o.a * y + o.b * v[j]; pw *= o.a; }
+    }
+    for (; t < t1; ++t) { y = o.a * y + o.b * u[(size_t)t * o.n_sig]; pw *= o.a; }
+  }
   sl[c][e] = y; sp[c][e] = pw;
   __syncthreads();
   if (!ok) return;
