@@ -126,6 +126,8 @@ typedef struct ssn_model_desc {
                                               (k_ens_block): step it once per timestep (k_ensarray) instead,
                                          256 = generic plan: fork the independent branches of a timestep over several
                                               streams inside the step graph (data-hazard analysis in the planner),
+                                         2048 = chunk reduction fused into k_spmv_partial (last workgroup per row block; experiment,
+                                              measured 20 % slower on SLAM config 3: device-scope fences),
                                          1024 = k_spmv_partial rebuilds the spike list itself (no segmented list from k_neurons),
                                          512 = no FFT kernel for DFT-structured matvecs (always multiply by the matrix),
                                          64 = programs stage their signal ranges through LDS (experiment, measured

@@ -111,6 +111,7 @@ struct Sim final : ssn_sim {
     ssn::NeuronParams<T> np;
     int* list = nullptr; int* count = nullptr;     // spike list (k_neurons_compact -> k_spmv_partial)
     int seg = 0;                                   // > 0: segmented spike list (k_neurons), segments per spmv chunk
+    T* out = nullptr; unsigned int* tickets = nullptr;   // spmv with the chunk reduction fused in (writes the signal itself)
     ssn::DftArgs dft;
   };
 
@@ -971,10 +972,22 @@ struct Sim final : ssn_sim {
             Item it; it.type = IT_SPMV; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.dst = partial;
             it.rows = (int)o.i[2]; it.cols = (int)o.i[3]; it.ld = (int)w.ldt; it.n = chunks; it.seg = seg;
             for (auto& sl : spike_lists) if (sl.first == o.i[1]) { it.list = sl.second.first; it.count = sl.second.second; }
-            items.push_back(it);
-            MOp r{};
-            r.kind = o.i[5] ? ssn::M_REDUCE_SET : ssn::M_REDUCE_INC; r.dst = o.i[0]; r.len = o.i[2]; r.i0 = chunks; r.i1 = rows_pad; r.p0 = partial;
-            push_micro(r, o.level, true);
+            if (seg > 0 && (flags & 2048) && (o.i[2] + 255) / 256 <= 64) {
+              // opt-in experiment: the last workgroup of each row block adds the chunk sums itself (no reduce program
+              // behind the product).  Measured SLOWER on SLAM config 3 (446 vs 372 us per timestep, 37 vs 42 launches):
+              // the device-scope fences every workgroup needs cost more than the five launches they save.
+              CHK(dmalloc(&it.tickets, 64 * 4));
+              HIPCHK(hipMemset(it.tickets, 0, 64 * 4));
+              scratch_bufs.push_back(it.tickets);
+              it.out = sig + o.i[0]; it.set = (int)o.i[5];
+              items.push_back(it);
+              force_barrier = true;
+            } else {
+              items.push_back(it);
+              MOp r{};
+              r.kind = o.i[5] ? ssn::M_REDUCE_SET : ssn::M_REDUCE_INC; r.dst = o.i[0]; r.len = o.i[2]; r.i0 = chunks; r.i1 = rows_pad; r.p0 = partial;
+              push_micro(r, o.level, true);
+            }
           } else {
             flush();
             Item it; it.type = IT_MATVEC; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.dst = sig + o.i[0];
@@ -1228,6 +1241,7 @@ struct Sim final : ssn_sim {
           break;
         case IT_SPMV:
           sg(a, it.src - sig, it.cols, false); pt(a, it.Wm, false); pt(a, it.list, false); pt(a, it.count, false); pt(a, it.dst, true);
+          if (it.out) sg(a, it.out - sig, it.rows, true);
           break;
         case IT_NEURONS: case IT_NEURONS_COMPACT:
           sg(a, it.src - sig, it.n, false); sg(a, it.dst - sig, it.n, true); pt(a, it.V, true); pt(a, it.R, true);
@@ -1289,7 +1303,8 @@ struct Sim final : ssn_sim {
       case IT_MATVEC_ORDERED: return ssn::launch_matvec_ordered<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld);
       case IT_FINISH: return ssn::launch_ens_finish<T>(stream, it.fin);
       case IT_DFT: return ssn::launch_dft<T>(stream, it.dft);
-      case IT_SPMV: return ssn::launch_spmv_partial<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count, it.seg);
+      case IT_SPMV: return ssn::launch_spmv_partial<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count, it.seg,
+                                                       it.out, it.set, it.tickets);
       case IT_NEURONS_COMPACT: return ssn::launch_neurons_compact<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count);
       case IT_NEURONS: return ssn::launch_neurons<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count);
       case IT_PES: return ssn::launch_pes<T>(stream, it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar);

@@ -782,7 +782,8 @@ hipError_t launch_matvec(hipStream_t s, const T* Wm, const T* src, T* dst, int r
 template <typename T>
 __global__ __launch_bounds__(256) void k_spmv_partial(const T* __restrict__ Wt, int ldt, const T* __restrict__ spikes,
                                                       int n, int rows, T* __restrict__ partial, int rows_pad, int chunks,
-                                                      const int* __restrict__ glist, const int* __restrict__ gcount, int seg) {
+                                                      const int* __restrict__ glist, const int* __restrict__ gcount, int seg,
+                                                      T* __restrict__ out, int out_set, unsigned int* __restrict__ tickets) {
   extern __shared__ unsigned char smem[];
   __shared__ int counts[257];
   const int tid = threadIdx.x;
@@ -831,6 +832,35 @@ __global__ __launch_bounds__(256) void k_spmv_partial(const T* __restrict__ Wt, 
         for (; i < e; ++i) { const int j = sl[i]; acc += spikes[j] * Wt[(size_t)j * ldt + r]; }
       }
     if (r < rows) partial[(size_t)c * rows_pad + r] = acc;
+    if (out) {
+      // fused chunk reduction: the last workgroup of a row block to arrive adds the chunk sums in chunk order
+      // (same order as the M_REDUCE_* micro-operator it replaces - and one kernel launch less per product)
+      __shared__ int s_last;
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned int t = atomicAdd(&tickets[blockIdx.x], 1u);
+        s_last = t == (unsigned int)chunks - 1u;
+        if (s_last) tickets[blockIdx.x] = 0u;         // ready for the next launch (stream-ordered)
+      }
+      __syncthreads();
+      if (s_last) {
+        __threadfence();
+        if (r < rows) {
+          T sum = T(0);
+          int q = 0;
+          for (; q + 8 <= chunks; q += 8) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(partial + (size_t)(q + u) * rows_pad + r);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+          }
+          for (; q < chunks; ++q) sum += __builtin_nontemporal_load(partial + (size_t)q * rows_pad + r);
+          if (out_set) out[r] = sum; else out[r] += sum;
+        }
+      }
+    }
     return;
   }
   const int b = (int)((long long)m * c / chunks), e = (int)((long long)m * (c + 1) / chunks);
@@ -849,9 +879,9 @@ __global__ __launch_bounds__(256) void k_spmv_partial(const T* __restrict__ Wt, 
 
 template <typename T>
 hipError_t launch_spmv_partial(hipStream_t s, const T* Wt, int ldt, const T* spikes, int n, int rows, T* partial, int rows_pad, int chunks,
-                               const int* list, const int* count, int seg) {
+                               const int* list, const int* count, int seg, T* out, int out_set, unsigned int* tickets) {
   hipLaunchKernelGGL((k_spmv_partial<T>), dim3((rows + 255) / 256, chunks), dim3(256), list ? (size_t)16 : (size_t)n * sizeof(int), s,
-                     Wt, ldt, spikes, n, rows, partial, rows_pad, chunks, list, count, seg);
+                     Wt, ldt, spikes, n, rows, partial, rows_pad, chunks, list, count, seg, out, out_set, tickets);
   return hipGetLastError();
 }
 
@@ -1291,7 +1321,7 @@ namespace ssn {
   template hipError_t launch_ens_finish<T>(hipStream_t, const FinishArgs<T>&);                               \
   template hipError_t launch_matvec<T>(hipStream_t, const T*, const T*, T*, int, int, int, int);            \
   template hipError_t launch_matvec_ordered<T>(hipStream_t, const T*, const T*, T*, int, int, int);         \
-  template hipError_t launch_spmv_partial<T>(hipStream_t, const T*, int, const T*, int, int, T*, int, int, const int*, const int*, int);  \
+  template hipError_t launch_spmv_partial<T>(hipStream_t, const T*, int, const T*, int, int, T*, int, int, const int*, const int*, int, T*, int, unsigned int*);  \
   template hipError_t launch_neurons_compact<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T, int*, int*);     \
   template hipError_t launch_transpose<T>(hipStream_t, const T*, T*, int, int, int, int);                   \
   template hipError_t launch_neurons<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T, int*, int*); \

@@ -195,7 +195,8 @@ template <typename T> hipError_t launch_matvec(hipStream_t, const T* W, const T*
 template <typename T> hipError_t launch_matvec_ordered(hipStream_t, const T* Wt, const T* x, T* y, int rows, int cols, int ldt);
 template <typename T> hipError_t launch_transpose(hipStream_t, const T* src, T* dst, int rows, int cols, int ld, int ldt);
 template <typename T> hipError_t launch_spmv_partial(hipStream_t, const T* Wt, int ldt, const T* spikes, int n, int rows, T* partial,
-                                                     int rows_pad, int chunks, const int* list, const int* count, int seg);
+                                                     int rows_pad, int chunks, const int* list, const int* count, int seg,
+                                                     T* out, int out_set, unsigned int* tickets);
 template <typename T> hipError_t launch_neurons_compact(hipStream_t, const NeuronParams<T>&, const T* J, T* out, T* V, T* R, int n, T amp,
                                                         int* list, int* count);
 template <typename T> hipError_t launch_neurons(hipStream_t, const NeuronParams<T>&, const T* J, T* out, T* V, T* R, int n, T amp,
