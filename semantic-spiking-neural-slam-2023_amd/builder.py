@@ -942,7 +942,9 @@ def schedule_ops(ops, model):
     out, level = [], 0
     while ready:
         micro = [i for i in ready if is_micro(ops[i])]
-        pick = sorted(micro if micro else ready, key=lambda i: ops[i]["seq"])
+        # big ops of a round: grouped by kind (then oldest first) so that the device can batch neighbours of one kind
+        pick = (sorted(micro, key=lambda i: ops[i]["seq"]) if micro else
+                sorted(ready, key=lambda i: (ops[i]["kind"], 1 if ops[i].get("dft") else 0, ops[i]["seq"])))
         for i in pick:
             ready.remove(i)
         for i in pick:

@@ -112,6 +112,8 @@ struct Sim final : ssn_sim {
     int* list = nullptr; int* count = nullptr;     // spike list (k_neurons_compact -> k_spmv_partial)
     int seg = 0;                                   // > 0: segmented spike list (k_neurons), segments per spmv chunk
     T* out = nullptr; unsigned int* tickets = nullptr;   // spmv with the chunk reduction fused in (writes the signal itself)
+    int batch = 1;                                 // this item and the next batch-1 items (same kind, independent) share one launch
+    bool merged = false;                           // launched by the item that leads its batch
     ssn::DftArgs dft;
   };
 
@@ -1177,6 +1179,7 @@ struct Sim final : ssn_sim {
     core_empty = bsig && n_core_ops == 0 && !core_probe;
     if (core_empty) launches_per_step = 0;
     if (!fused) analyse_dependencies(programs, item_prog);
+    if (!fused && !(flags & (256 | 4096))) merge_adjacent_items();
     if (getenv("SSN_DEBUG_PLAN")) {
       int pj = 0;
       for (size_t i = 0; i < items.size(); ++i) {
@@ -1190,6 +1193,30 @@ struct Sim final : ssn_sim {
       }
     }
     return SSN_OK;
+  }
+
+  // Adjacent items of one kind with no data hazard between them share a launch (blockIdx.y selects the item).
+  void merge_adjacent_items() {
+    const int n = (int)items.size();
+    auto xlds = [&](const Item& it) { return (size_t)it.cols * sizeof(T) <= 48 * 1024; };
+    for (int i = 0; i < n; ++i) {
+      Item& lead = items[(size_t)i];
+      if (lead.merged || !(lead.type == IT_MATVEC || lead.type == IT_NEURONS || lead.type == IT_DFT)) continue;
+      int k = 1;
+      while (i + k < n && k < ssn::MAX_BATCH && items[(size_t)(i + k)].type == lead.type) {
+        const Item& nx = items[(size_t)(i + k)];
+        if (lead.type == IT_MATVEC && xlds(nx) != xlds(lead)) break;
+        bool indep = true;
+        for (int d : item_deps[(size_t)(i + k)]) if (d >= i && d < i + k) indep = false;
+        if (!indep) break;
+        ++k;
+      }
+      lead.batch = k;
+      for (int q = 1; q < k; ++q) items[(size_t)(i + q)].merged = true;
+    }
+    int launches = 0;
+    for (auto& it : items) launches += it.merged ? 0 : 1;
+    if (!core_empty) launches_per_step = launches - (can_fuse ? 1 : 0);
   }
 
   // Read / write sets of every item of the generic plan -> item_deps (RAW, WAR and WAW hazards on earlier items).
@@ -1290,6 +1317,8 @@ struct Sim final : ssn_sim {
 
   // ---- launching --------------------------------------------------------------------------
   hipError_t launch_item(const Item& it, hipEvent_t e0, hipEvent_t e1) {
+    if (it.merged) return hipSuccess;               // its batch leader launched it
+    const Item* g = &it;                            // (batch members are adjacent in `items`)
     switch (it.type) {
       case IT_PROGRAM: return ssn::launch_program<T>(stream, d_mops, d_progs + it.op_begin, 1, d_segs, prog_lds[it.op_begin], sig, d_ctx);
       case IT_ENS: {
@@ -1299,14 +1328,27 @@ struct Sim final : ssn_sim {
         if (e1) return hipEventRecord(e1, stream);
         return hipSuccess;
       }
-      case IT_MATVEC: return ssn::launch_matvec<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set);
+      case IT_MATVEC: {
+        ssn::MatvecBatch<T> b{};
+        for (int q = 0; q < it.batch; ++q) b.a[q] = ssn::MatvecArgs<T>{g[q].Wm, g[q].src, g[q].dst, g[q].rows, g[q].cols, g[q].ld, g[q].set};
+        return ssn::launch_matvec<T>(stream, b, it.batch);
+      }
       case IT_MATVEC_ORDERED: return ssn::launch_matvec_ordered<T>(stream, it.Wm, it.src, it.dst, it.rows, it.cols, it.ld);
       case IT_FINISH: return ssn::launch_ens_finish<T>(stream, it.fin);
-      case IT_DFT: return ssn::launch_dft<T>(stream, it.dft);
+      case IT_DFT: {
+        ssn::DftBatch b{};
+        for (int q = 0; q < it.batch; ++q) b.a[q] = g[q].dft;
+        return ssn::launch_dft<T>(stream, b, it.batch);
+      }
       case IT_SPMV: return ssn::launch_spmv_partial<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count, it.seg,
                                                        it.out, it.set, it.tickets);
       case IT_NEURONS_COMPACT: return ssn::launch_neurons_compact<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count);
-      case IT_NEURONS: return ssn::launch_neurons<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count);
+      case IT_NEURONS: {
+        ssn::NeuronsBatch<T> b{};
+        for (int q = 0; q < it.batch; ++q)
+          b.a[q] = ssn::NeuronsArgs<T>{g[q].np, g[q].src, g[q].dst, g[q].V, g[q].R, g[q].n, g[q].scalar, g[q].list, g[q].count};
+        return ssn::launch_neurons<T>(stream, b, it.batch);
+      }
       case IT_PES: return ssn::launch_pes<T>(stream, it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar);
       case IT_VOJA: return ssn::launch_voja<T>(stream, it.Wm, it.src, it.aux0, it.aux1, it.aux2, it.rows, it.cols, it.ld, it.scalar);
     }

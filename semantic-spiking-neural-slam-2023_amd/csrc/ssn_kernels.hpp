@@ -423,7 +423,8 @@ hipError_t launch_ensarray(hipStream_t s, const EnsArgs<T>& a) {
 // by the matrix like the oracle.
 // ---------------------------------------------------------------------------------------------
 template <int DUMMY>
-__global__ __launch_bounds__(1024) void k_dft(DftArgs a) {
+__global__ __launch_bounds__(1024) void k_dft(DftBatch batch) {
+  const DftArgs a = batch.a[blockIdx.x];
   extern __shared__ __align__(16) unsigned char ssn_dft_dyn[];
   const int N = a.N, H = N / 2 + 1, tid = threadIdx.x, nthr = blockDim.x;
   float2* x = reinterpret_cast<float2*>(ssn_dft_dyn);
@@ -485,9 +486,11 @@ __global__ __launch_bounds__(1024) void k_dft(DftArgs a) {
 }
 
 template <typename T>
-hipError_t launch_dft(hipStream_t s, const DftArgs& a) {
-  const int threads = a.N >= 1024 ? 1024 : (a.N + 63) / 64 * 64;
-  hipLaunchKernelGGL((k_dft<0>), dim3(1), dim3(threads), (size_t)a.N * 3 * sizeof(float2), s, a);
+hipError_t launch_dft(hipStream_t s, const DftBatch& b, int count) {
+  int N = 0;
+  for (int i = 0; i < count; ++i) N = std::max(N, b.a[i].N);
+  const int threads = N >= 1024 ? 1024 : (N + 63) / 64 * 64;
+  hipLaunchKernelGGL((k_dft<0>), dim3(count), dim3(threads), (size_t)N * 3 * sizeof(float2), s, b);
   return hipGetLastError();
 }
 
@@ -710,8 +713,13 @@ hipError_t program_set_max_lds(int bytes) {
 // whole matrix read.
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool XLDS>
-__global__ __launch_bounds__(256) void k_matvec(const T* __restrict__ Wm, const T* __restrict__ sig_src,
-                                                T* __restrict__ sig_dst, int rows, int cols, int ld, int set) {
+__global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
+  const MatvecArgs<T> ma = batch.a[blockIdx.y];
+  const T* __restrict__ Wm = ma.Wm;
+  const T* __restrict__ sig_src = ma.src;
+  T* __restrict__ sig_dst = ma.dst;
+  const int rows = ma.rows, cols = ma.cols, ld = ma.ld, set = ma.set;
+  if ((int)blockIdx.x * 16 >= rows) return;      // (grid.x is sized for the tallest matrix of the batch)
   // y = W x, one wave per FOUR rows (16 rows per workgroup): the source vector is staged in LDS once per
   // workgroup (XLDS) and each lane keeps four independent 16-byte row loads in flight per trip.  Per row the
   // lane-strided accumulation and the wave reduction are the same sequence as a one-row-per-wave kernel.
@@ -763,11 +771,13 @@ __global__ __launch_bounds__(256) void k_matvec(const T* __restrict__ Wm, const 
 }
 
 template <typename T>
-hipError_t launch_matvec(hipStream_t s, const T* Wm, const T* src, T* dst, int rows, int cols, int ld, int set) {
+hipError_t launch_matvec(hipStream_t s, const MatvecBatch<T>& b, int count) {
+  int rows = 0, cols = 0;
+  for (int i = 0; i < count; ++i) { rows = std::max(rows, b.a[i].rows); cols = std::max(cols, b.a[i].cols); }
   const size_t xb = (size_t)cols * sizeof(T);
-  const dim3 grid((rows + 15) / 16), block(256);
-  if (xb <= 48 * 1024) hipLaunchKernelGGL((k_matvec<T, true>), grid, block, xb, s, Wm, src, dst, rows, cols, ld, set);
-  else hipLaunchKernelGGL((k_matvec<T, false>), grid, block, 0, s, Wm, src, dst, rows, cols, ld, set);
+  const dim3 grid((rows + 15) / 16, count), block(256);
+  if (xb <= 48 * 1024) hipLaunchKernelGGL((k_matvec<T, true>), grid, block, xb, s, b);
+  else hipLaunchKernelGGL((k_matvec<T, false>), grid, block, 0, s, b);
   return hipGetLastError();
 }
 
@@ -967,9 +977,18 @@ hipError_t launch_transpose(hipStream_t s, const T* src, T* dst, int rows, int c
 
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_neurons(NeuronParams<T> np, const T* __restrict__ J, T* __restrict__ out,
-                                                 T* __restrict__ V, T* __restrict__ R, int n, T amp,
-                                                 int* __restrict__ seg_list, int* __restrict__ seg_cnt) {
+__global__ __launch_bounds__(256) void k_neurons(NeuronsBatch<T> batch) {
+  const NeuronsArgs<T> na = batch.a[blockIdx.y];
+  const NeuronParams<T> np = na.np;
+  const T* __restrict__ J = na.J;
+  T* __restrict__ out = na.out;
+  T* __restrict__ V = na.V;
+  T* __restrict__ R = na.R;
+  const int n = na.n;
+  const T amp = na.amp;
+  int* __restrict__ seg_list = na.seg_list;
+  int* __restrict__ seg_cnt = na.seg_cnt;
+  if ((int)blockIdx.x * 256 >= n) return;        // (grid.x is sized for the largest population of the batch)
   const int i = blockIdx.x * 256 + threadIdx.x;
   T a = T(0);
   if (i < n) {
@@ -994,9 +1013,10 @@ __global__ __launch_bounds__(256) void k_neurons(NeuronParams<T> np, const T* __
 }
 
 template <typename T>
-hipError_t launch_neurons(hipStream_t s, const NeuronParams<T>& np, const T* J, T* out, T* V, T* R, int n, T amp,
-                          int* seg_list, int* seg_cnt) {
-  hipLaunchKernelGGL((k_neurons<T>), dim3((n + 255) / 256), dim3(256), 0, s, np, J, out, V, R, n, amp, seg_list, seg_cnt);
+hipError_t launch_neurons(hipStream_t s, const NeuronsBatch<T>& b, int count) {
+  int n = 0;
+  for (int i = 0; i < count; ++i) n = std::max(n, b.a[i].n);
+  hipLaunchKernelGGL((k_neurons<T>), dim3((n + 255) / 256, count), dim3(256), 0, s, b);
   return hipGetLastError();
 }
 
@@ -1311,7 +1331,7 @@ namespace ssn {
 
 #define SSN_INSTANTIATE(T)                                                                                   \
   template hipError_t launch_ens_block<T>(hipStream_t, const BlockArgs<T>&);                                 \
-  template hipError_t launch_dft<T>(hipStream_t, const DftArgs&);                                            \
+  template hipError_t launch_dft<T>(hipStream_t, const DftBatch&, int);                                            \
   template bool ens_block_supported<T>(int, int, int, int*, int*, int*, int*);                                         \
   template hipError_t launch_ensarray<T>(hipStream_t, const EnsArgs<T>&);                                    \
   template hipError_t launch_dec_pack<T>(hipStream_t, const T*, T*, int, int, int, int, int, int);           \
@@ -1319,12 +1339,12 @@ namespace ssn {
   template hipError_t launch_program<T>(hipStream_t, const MicroOp<T>*, const ProgDesc*, int, const ProgSeg*, int, T*, StepCtx*); \
   template hipError_t program_set_max_lds<T>(int);                                                          \
   template hipError_t launch_ens_finish<T>(hipStream_t, const FinishArgs<T>&);                               \
-  template hipError_t launch_matvec<T>(hipStream_t, const T*, const T*, T*, int, int, int, int);            \
+  template hipError_t launch_matvec<T>(hipStream_t, const MatvecBatch<T>&, int);            \
   template hipError_t launch_matvec_ordered<T>(hipStream_t, const T*, const T*, T*, int, int, int);         \
   template hipError_t launch_spmv_partial<T>(hipStream_t, const T*, int, const T*, int, int, T*, int, int, const int*, const int*, int, T*, int, unsigned int*);  \
   template hipError_t launch_neurons_compact<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T, int*, int*);     \
   template hipError_t launch_transpose<T>(hipStream_t, const T*, T*, int, int, int, int);                   \
-  template hipError_t launch_neurons<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T, int*, int*); \
+  template hipError_t launch_neurons<T>(hipStream_t, const NeuronsBatch<T>&, int); \
   template hipError_t launch_pes<T>(hipStream_t, T*, const T*, const T*, int, int, int, T);                 \
   template hipError_t launch_voja<T>(hipStream_t, T*, const T*, const T*, const T*, const T*, int, int, int, T); \
   template hipError_t launch_batch_op<T>(hipStream_t, const BatchOp<T>&);                                   \

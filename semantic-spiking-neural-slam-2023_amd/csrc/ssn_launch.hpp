@@ -125,6 +125,15 @@ struct DftArgs {
   int radix[12];         // product = N, each <= 32
 };
 
+// Independent operators of one kind that the scheduler placed next to each other share one launch
+// (blockIdx.y selects the operator): every launch costs ~4-5 us on this GPU whatever its size.
+constexpr int MAX_BATCH = 4;
+template <typename T> struct MatvecArgs { const T* Wm; const T* src; T* dst; int rows, cols, ld, set; };
+template <typename T> struct MatvecBatch { MatvecArgs<T> a[MAX_BATCH]; };
+template <typename T> struct NeuronsArgs { NeuronParams<T> np; const T* J; T* out; T* V; T* R; int n; T amp; int* seg_list; int* seg_cnt; };
+template <typename T> struct NeuronsBatch { NeuronsArgs<T> a[MAX_BATCH]; };
+struct DftBatch { DftArgs a[MAX_BATCH]; };
+
 enum MicroKind {
   M_FILL = 1, M_AXPY_INC, M_AXPY_SET, M_LOWPASS, M_TABLE, M_MATVEC_INC, M_MATVEC_SET, M_ENS_FINISH,
   M_GATE, M_ARGMAX_GATHER, M_PROBE, M_STEP_END, M_ROW_IN, M_ROW_OUT, M_REDUCE_SET, M_REDUCE_INC
@@ -185,13 +194,13 @@ template <typename T> hipError_t launch_ensarray(hipStream_t, const EnsArgs<T>&)
 template <typename T> hipError_t launch_dec_pack(hipStream_t, const T* src, T* dst, int K, int dout, int n, int n_pad, int DP, int unpack);
 template <typename T> hipError_t launch_state_unpack(hipStream_t, const T* src, T* out, int64_t n, int want_refractory);
 template <typename T> hipError_t launch_ens_finish(hipStream_t, const FinishArgs<T>&);
-template <typename T> hipError_t launch_dft(hipStream_t, const DftArgs&);   // (T only selects the translation unit)
+template <typename T> hipError_t launch_dft(hipStream_t, const DftBatch&, int count);   // (T only selects the translation unit)
 template <typename T> hipError_t launch_ens_block(hipStream_t, const BlockArgs<T>&);
 template <typename T> bool ens_block_supported(int din, int dout, int n, int* threads, int* tpb, int* npt, int* enc_lds);
 template <typename T> hipError_t launch_program(hipStream_t, const MicroOp<T>* ops, const ProgDesc* progs, int n_progs, const ProgSeg* segs,
                                                int lds_bytes, T* sig, StepCtx* ctx);
 template <typename T> hipError_t program_set_max_lds(int bytes);
-template <typename T> hipError_t launch_matvec(hipStream_t, const T* W, const T* src, T* dst, int rows, int cols, int ld, int set);
+template <typename T> hipError_t launch_matvec(hipStream_t, const MatvecBatch<T>&, int count);
 template <typename T> hipError_t launch_matvec_ordered(hipStream_t, const T* Wt, const T* x, T* y, int rows, int cols, int ldt);
 template <typename T> hipError_t launch_transpose(hipStream_t, const T* src, T* dst, int rows, int cols, int ld, int ldt);
 template <typename T> hipError_t launch_spmv_partial(hipStream_t, const T* Wt, int ldt, const T* spikes, int n, int rows, T* partial,
@@ -199,8 +208,7 @@ template <typename T> hipError_t launch_spmv_partial(hipStream_t, const T* Wt, i
                                                      T* out, int out_set, unsigned int* tickets);
 template <typename T> hipError_t launch_neurons_compact(hipStream_t, const NeuronParams<T>&, const T* J, T* out, T* V, T* R, int n, T amp,
                                                         int* list, int* count);
-template <typename T> hipError_t launch_neurons(hipStream_t, const NeuronParams<T>&, const T* J, T* out, T* V, T* R, int n, T amp,
-                                                int* seg_list, int* seg_cnt);
+template <typename T> hipError_t launch_neurons(hipStream_t, const NeuronsBatch<T>&, int count);
 template <typename T> hipError_t launch_pes(hipStream_t, T* W, const T* err, const T* act, int rows, int cols, int ld, T kappa);
 template <typename T> hipError_t launch_voja(hipStream_t, T* E, const T* spk, const T* key, const T* learn, const T* scale,
                                             int rows, int cols, int ld, T lr_dt);
