@@ -126,6 +126,8 @@ typedef struct ssn_model_desc {
                                               (k_ens_block): step it once per timestep (k_ensarray) instead,
                                          256 = generic plan: fork the independent branches of a timestep over several
                                               streams inside the step graph (data-hazard analysis in the planner),
+                                         8192 = ensemble arrays always leave partial sums for a finish operator (no direct write
+                                              when one workgroup covers an ensemble),
                                          4096 = one launch per operator (adjacent independent operators of one kind are not batched),
                                          2048 = chunk reduction fused into k_spmv_partial (last workgroup per row block; experiment,
                                               measured 20 % slower on SLAM config 3: device-scope fences),

@@ -1006,11 +1006,19 @@ struct Sim final : ssn_sim {
           CHK(dmalloc(&a.partials, (int64_t)a.K * a.P * a.dout * (int64_t)sizeof(T)));
           const int64_t units = (int64_t)a.K * a.n;
           if (units > best_units) { best_units = units; best_item = (int)items.size(); }
+          host_idx.push_back({bufs[o.i[8]].d, {(const int32_t*)m->buffers[o.i[8]].data, (int64_t)a.K * a.dout}});
+          if (a.P == 1 && !(flags & 8192)) {
+            // one workgroup covers a whole ensemble (the 8128 product ensembles of 50 neurons): it writes the decoded
+            // rows itself, no finish operator (and no program launch) behind the kernel
+            a.direct = 1; a.didx = (const int*)bufs[o.i[8]].d; a.sig_w = sig;
+            items.push_back(it);
+            force_barrier = true;
+            break;
+          }
           items.push_back(it);
           MOp f{};
           f.kind = ssn::M_ENS_FINISH; f.len = (int64_t)a.K * a.dout; f.i0 = a.P; f.i1 = a.dout;
           f.p0 = a.partials; f.p1 = bufs[o.i[8]].d;
-          host_idx.push_back({bufs[o.i[8]].d, {(const int32_t*)m->buffers[o.i[8]].data, (int64_t)a.K * a.dout}});
           push_micro(f, o.level, true);
           break;
         }
@@ -1255,6 +1263,10 @@ struct Sim final : ssn_sim {
           break;
         }
         case IT_ENS:
+          if (it.ens.direct)
+            for (auto& h : host_idx)
+              if (h.first == (const void*)it.ens.didx)
+                for (int64_t j = 0; j < h.second.second; ++j) sg(a, h.second.first[j], 1, true);
           sg(a, it.ens.x_off, (int64_t)it.ens.K * it.ens.din, false);
           pt(a, it.ens.partials, true); pt(a, it.ens.V, true); pt(a, it.ens.R, true);
           pt(a, it.ens.enc, false); pt(a, it.ens.bias, false); pt(a, it.ens.dec, false);

@@ -302,8 +302,13 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
   __syncthreads();
   if (threadIdx.x < DOUT) {
     const int r = threadIdx.x;
-    T* out = a.partials + (a.defer ? (size_t)(step & 1) * a.partials_stride : (size_t)0);
-    out[((size_t)k * a.P + p) * DOUT + r] = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+    const T total = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+    if (a.direct) {                      // the workgroup saw the whole ensemble: this IS the decoded value
+      a.sig_w[a.didx[(size_t)k * DOUT + r]] = total;
+    } else {
+      T* out = a.partials + (a.defer ? (size_t)(step & 1) * a.partials_stride : (size_t)0);
+      out[((size_t)k * a.P + p) * DOUT + r] = total;
+    }
   }
 }
 

@@ -40,6 +40,7 @@ struct EnsArgs {
   // deferred finish (one launch per timestep): the prologue of step t completes step t-1 for its own
   // ensemble - sums the previous partials, updates the recurrent filter states, hands results on - and
   // the partials / filter states ping-pong between two buffers by step parity.
+  int direct;                      // P == 1 (one workgroup per ensemble): decoded rows go straight to sig_w[didx[...]] - no finish
   int defer;
   int sub;                         // step offset of this launch inside a captured graph (step = ctx->step + sub)
   long long partials_stride;       // elements between the two partial buffers

@@ -294,7 +294,7 @@ def test_slam_optin_plans_equal_default(Simulator):
     sm = _small_slam(weights_every=None)
     model = build(sm.model)
     outs = []
-    for flags in (0, 32 | 64, 256, 1024, 2048, 4096):
+    for flags in (0, 32 | 64, 256, 1024, 2048, 4096, 8192):
         with Simulator(None, model=model, dtype="f64", flags=flags) as sim:
             sim.run_steps(120)
             outs.append(sim.data[sm.probe])
@@ -303,6 +303,7 @@ def test_slam_optin_plans_equal_default(Simulator):
     np.testing.assert_allclose(outs[3], outs[0], atol=1e-12, rtol=0)
     np.testing.assert_array_equal(outs[4], outs[0])            # fused (opt-in) vs separate chunk reduction: same order, same bits
     np.testing.assert_array_equal(outs[5], outs[0])            # one launch per operator vs batched neighbours
+    np.testing.assert_array_equal(outs[6], outs[0])            # finish operator vs direct write of one-workgroup ensembles
 
 
 def test_feedforward_model_runs_fully_batched(Simulator):
