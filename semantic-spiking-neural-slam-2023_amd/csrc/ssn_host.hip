@@ -1209,11 +1209,14 @@ struct Sim final : ssn_sim {
     auto xlds = [&](const Item& it) { return (size_t)it.cols * sizeof(T) <= 48 * 1024; };
     for (int i = 0; i < n; ++i) {
       Item& lead = items[(size_t)i];
-      if (lead.merged || !(lead.type == IT_MATVEC || lead.type == IT_NEURONS || lead.type == IT_DFT)) continue;
+      if (lead.merged || !(lead.type == IT_MATVEC || lead.type == IT_NEURONS || lead.type == IT_DFT || lead.type == IT_ENS)) continue;
+      if (lead.type == IT_ENS && (lead.dominant || lead.ens.defer)) continue;
+      const int cap = lead.type == IT_ENS ? ssn::MAX_ENS_BATCH : ssn::MAX_BATCH;
       int k = 1;
-      while (i + k < n && k < ssn::MAX_BATCH && items[(size_t)(i + k)].type == lead.type) {
+      while (i + k < n && k < cap && items[(size_t)(i + k)].type == lead.type) {
         const Item& nx = items[(size_t)(i + k)];
         if (lead.type == IT_MATVEC && xlds(nx) != xlds(lead)) break;
+        if (lead.type == IT_ENS && (nx.dominant || nx.ens.din != lead.ens.din || nx.ens.dout != lead.ens.dout || nx.ens.fast != lead.ens.fast)) break;
         bool indep = true;
         for (int d : item_deps[(size_t)(i + k)]) if (d >= i && d < i + k) indep = false;
         if (!indep) break;
@@ -1335,7 +1338,14 @@ struct Sim final : ssn_sim {
       case IT_PROGRAM: return ssn::launch_program<T>(stream, d_mops, d_progs + it.op_begin, 1, d_segs, prog_lds[it.op_begin], sig, d_ctx);
       case IT_ENS: {
         if (e0) { hipError_t e = hipEventRecord(e0, stream); if (e != hipSuccess) return e; }
-        hipError_t e = ssn::launch_ensarray<T>(stream, it.ens);
+        hipError_t e;
+        if (it.batch > 1) {
+          ssn::EnsBatch<T> b{};
+          for (int q = 0; q < it.batch; ++q) b.a[q] = g[q].ens;
+          e = ssn::launch_ensarray_batch<T>(stream, b, it.batch);
+        } else {
+          e = ssn::launch_ensarray<T>(stream, it.ens);
+        }
         if (e != hipSuccess) return e;
         if (e1) return hipEventRecord(e1, stream);
         return hipSuccess;

@@ -118,7 +118,9 @@ __device__ inline T wave_sum(T v) {
 template <int DOUT> struct DecPitch { static constexpr int value = DOUT <= 4 ? 4 : 8; };
 
 template <typename T, int DIN, int DOUT, int MODE>   // MODE 0 generic | 1 fast, spike-sparse decoders | 2 fast, dense decoders
-__global__ __launch_bounds__(256) void k_ensarray(EnsArgs<T> a) {
+__global__ __launch_bounds__(256) void k_ensarray(EnsBatch<T> batch) {
+  const EnsArgs<T>& a = batch.a[blockIdx.y];
+  if ((int)blockIdx.x >= a.K * a.P) return;          // (grid.x is sized for the larger array of a batch)
   using vec = typename VecT<T>::type;
   constexpr int W = VecT<T>::W;
   constexpr bool FAST = MODE != 0;
@@ -386,10 +388,13 @@ hipError_t launch_ens_finish(hipStream_t s, const FinishArgs<T>& f) {
 }
 
 template <typename T, int DIN, int MODE>
-static hipError_t launch_ens_dout(hipStream_t s, const EnsArgs<T>& a) {
-  const dim3 grid((unsigned)(a.K * a.P)), block(256);
+static hipError_t launch_ens_dout(hipStream_t s, const EnsBatch<T>& b, int count) {
+  const EnsArgs<T>& a = b.a[0];
+  int wgs = 0;
+  for (int i = 0; i < count; ++i) wgs = std::max(wgs, b.a[i].K * b.a[i].P);
+  const dim3 grid((unsigned)wgs, (unsigned)count), block(256);
   switch (a.dout) {
-#define SSN_CASE(D) case D: hipLaunchKernelGGL((k_ensarray<T, DIN, D, MODE>), grid, block, 0, s, a); break;
+#define SSN_CASE(D) case D: hipLaunchKernelGGL((k_ensarray<T, DIN, D, MODE>), grid, block, 0, s, b); break;
     SSN_CASE(1) SSN_CASE(2) SSN_CASE(3) SSN_CASE(4) SSN_CASE(5) SSN_CASE(6) SSN_CASE(7) SSN_CASE(8)
 #undef SSN_CASE
     default: return hipErrorInvalidValue;
@@ -398,21 +403,27 @@ static hipError_t launch_ens_dout(hipStream_t s, const EnsArgs<T>& a) {
 }
 
 template <typename T, int MODE>
-static hipError_t launch_ens_din(hipStream_t s, const EnsArgs<T>& a) {
-  switch (a.din) {
-    case 1: return launch_ens_dout<T, 1, MODE>(s, a);
-    case 2: return launch_ens_dout<T, 2, MODE>(s, a);
-    case 3: return launch_ens_dout<T, 3, MODE>(s, a);
-    case 4: return launch_ens_dout<T, 4, MODE>(s, a);
+static hipError_t launch_ens_din(hipStream_t s, const EnsBatch<T>& b, int count) {
+  switch (b.a[0].din) {
+    case 1: return launch_ens_dout<T, 1, MODE>(s, b, count);
+    case 2: return launch_ens_dout<T, 2, MODE>(s, b, count);
+    case 3: return launch_ens_dout<T, 3, MODE>(s, b, count);
+    case 4: return launch_ens_dout<T, 4, MODE>(s, b, count);
     default: return hipErrorInvalidValue;
   }
 }
 
 template <typename T>
+hipError_t launch_ensarray_batch(hipStream_t s, const EnsBatch<T>& b, int count) {
+  if (b.a[0].fast == 1) return launch_ens_din<T, 1>(s, b, count);
+  if (b.a[0].fast == 2) return launch_ens_din<T, 2>(s, b, count);
+  return launch_ens_din<T, 0>(s, b, count);
+}
+template <typename T>
 hipError_t launch_ensarray(hipStream_t s, const EnsArgs<T>& a) {
-  if (a.fast == 1) return launch_ens_din<T, 1>(s, a);
-  if (a.fast == 2) return launch_ens_din<T, 2>(s, a);
-  return launch_ens_din<T, 0>(s, a);
+  EnsBatch<T> b{};
+  b.a[0] = a;
+  return launch_ensarray_batch<T>(s, b, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1339,6 +1350,7 @@ namespace ssn {
   template hipError_t launch_dft<T>(hipStream_t, const DftBatch&, int);                                            \
   template bool ens_block_supported<T>(int, int, int, int*, int*, int*, int*);                                         \
   template hipError_t launch_ensarray<T>(hipStream_t, const EnsArgs<T>&);                                    \
+  template hipError_t launch_ensarray_batch<T>(hipStream_t, const EnsBatch<T>&, int);                        \
   template hipError_t launch_dec_pack<T>(hipStream_t, const T*, T*, int, int, int, int, int, int);           \
   template hipError_t launch_state_unpack<T>(hipStream_t, const T*, T*, int64_t, int);                       \
   template hipError_t launch_program<T>(hipStream_t, const MicroOp<T>*, const ProgDesc*, int, const ProgSeg*, int, T*, StepCtx*); \

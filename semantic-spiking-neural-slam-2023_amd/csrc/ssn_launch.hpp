@@ -134,6 +134,8 @@ template <typename T> struct MatvecBatch { MatvecArgs<T> a[MAX_BATCH]; };
 template <typename T> struct NeuronsArgs { NeuronParams<T> np; const T* J; T* out; T* V; T* R; int n; T amp; int* seg_list; int* seg_cnt; };
 template <typename T> struct NeuronsBatch { NeuronsArgs<T> a[MAX_BATCH]; };
 struct DftBatch { DftArgs a[MAX_BATCH]; };
+constexpr int MAX_ENS_BATCH = 2;
+template <typename T> struct EnsBatch { EnsArgs<T> a[MAX_ENS_BATCH]; };
 
 enum MicroKind {
   M_FILL = 1, M_AXPY_INC, M_AXPY_SET, M_LOWPASS, M_TABLE, M_MATVEC_INC, M_MATVEC_SET, M_ENS_FINISH,
@@ -192,6 +194,7 @@ struct BatchOp {
 };
 
 template <typename T> hipError_t launch_ensarray(hipStream_t, const EnsArgs<T>&);
+template <typename T> hipError_t launch_ensarray_batch(hipStream_t, const EnsBatch<T>&, int count);   // equal din / dout / variant
 template <typename T> hipError_t launch_dec_pack(hipStream_t, const T* src, T* dst, int K, int dout, int n, int n_pad, int DP, int unpack);
 template <typename T> hipError_t launch_state_unpack(hipStream_t, const T* src, T* out, int64_t n, int want_refractory);
 template <typename T> hipError_t launch_ens_finish(hipStream_t, const FinishArgs<T>&);
