@@ -71,7 +71,7 @@ struct Buf {
   int64_t ldt = 0;
 };
 
-enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_NEURONS_COMPACT, IT_DFT };
+enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_NEURONS_COMPACT, IT_DFT, IT_SPMV_ROWS };
 
 }  // namespace
 
@@ -974,6 +974,17 @@ struct Sim final : ssn_sim {
             Item it; it.type = IT_SPMV; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.dst = partial;
             it.rows = (int)o.i[2]; it.cols = (int)o.i[3]; it.ld = (int)w.ldt; it.n = chunks; it.seg = seg;
             for (auto& sl : spike_lists) if (sl.first == o.i[1]) { it.list = sl.second.first; it.count = sl.second.second; }
+            if (seg > 0 && (flags & 16384)) {
+              // opt-in experiment: rows-owned product, no partial sums and no reduce program behind it.  Measured SLOWER
+              // on SLAM config 3 (393 vs 345 us per timestep at 27 vs 33 launches): 64 workgroups with three dependent
+              // load levels per spike-list segment lose more than the six saved launches give back.
+              Item it; it.type = IT_SPMV_ROWS; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.out = sig + o.i[0]; it.set = (int)o.i[5];
+              it.rows = (int)o.i[2]; it.cols = (int)o.i[3]; it.ld = (int)w.ldt;
+              for (auto& sl : spike_lists) if (sl.first == o.i[1]) { it.list = sl.second.first; it.count = sl.second.second; }
+              items.push_back(it);
+              force_barrier = true;
+              break;
+            }
             if (seg > 0 && (flags & 2048) && (o.i[2] + 255) / 256 <= 64) {
               // opt-in experiment: the last workgroup of each row block adds the chunk sums itself (no reduce program
               // behind the product).  Measured SLOWER on SLAM config 3 (446 vs 372 us per timestep, 37 vs 42 launches):
@@ -1281,6 +1292,10 @@ struct Sim final : ssn_sim {
           sg(a, it.src - sig, it.cols, false); pt(a, it.Wm, false);
           if (it.dst >= sig && it.dst < sig + n_sig) sg(a, it.dst - sig, it.rows, true); else pt(a, it.dst, true);
           break;
+        case IT_SPMV_ROWS:
+          sg(a, it.src - sig, it.cols, false); pt(a, it.Wm, false); pt(a, it.list, false); pt(a, it.count, false);
+          sg(a, it.out - sig, it.rows, true);
+          break;
         case IT_SPMV:
           sg(a, it.src - sig, it.cols, false); pt(a, it.Wm, false); pt(a, it.list, false); pt(a, it.count, false); pt(a, it.dst, true);
           if (it.out) sg(a, it.out - sig, it.rows, true);
@@ -1362,6 +1377,7 @@ struct Sim final : ssn_sim {
         for (int q = 0; q < it.batch; ++q) b.a[q] = g[q].dft;
         return ssn::launch_dft<T>(stream, b, it.batch);
       }
+      case IT_SPMV_ROWS: return ssn::launch_spmv_rows<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.list, it.count, it.out, it.set);
       case IT_SPMV: return ssn::launch_spmv_partial<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count, it.seg,
                                                        it.out, it.set, it.tickets);
       case IT_NEURONS_COMPACT: return ssn::launch_neurons_compact<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count);

@@ -903,6 +903,53 @@ __global__ __launch_bounds__(256) void k_spmv_partial(const T* __restrict__ Wt, 
   }
 }
 
+// k_spmv_rows: the same product with NO partial sums in memory.  A workgroup owns 16 output rows; its 256 threads
+// are 16 row lanes x 16 spike lanes: spike lane l walks the spike-list segments l, l + 16, l + 32, ... (eight row
+// reads in flight), the 16 spike-lane sums of a row are added in lane order through LDS, and the row is written
+// to the signal vector directly - one launch per product instead of product + reduce program.
+template <typename T>
+__global__ __launch_bounds__(256) void k_spmv_rows(const T* __restrict__ Wt, int ldt, const T* __restrict__ spikes, int n, int rows,
+                                                   const int* __restrict__ glist, const int* __restrict__ gcount,
+                                                   T* __restrict__ out, int out_set) {
+  __shared__ T part[16][17];
+  const int tid = threadIdx.x, rl = tid & 15, sl = tid >> 4;
+  const int r = blockIdx.x * 16 + rl;
+  const int rr = min(r, rows - 1);
+  const int n_seg = (n + 255) / 256;
+  T acc = T(0);
+  for (int sgm = sl; sgm < n_seg; sgm += 16) {
+    const int* l = glist + sgm * 256;
+    const int e = gcount[sgm];
+    int i = 0;
+    for (; i + 8 <= e; i += 8) {
+      int j[8]; T w[8], sv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) j[q] = l[i + q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { w[q] = Wt[(size_t)j[q] * ldt + rr]; sv[q] = spikes[j[q]]; }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += sv[q] * w[q];
+    }
+    for (; i < e; ++i) { const int j = l[i]; acc += spikes[j] * Wt[(size_t)j * ldt + rr]; }
+  }
+  part[sl][rl] = acc;
+  __syncthreads();
+  if (tid < 16 && blockIdx.x * 16 + tid < rows) {
+    T s = T(0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += part[q][tid];
+    T* d = out + blockIdx.x * 16 + tid;
+    if (out_set) *d = s; else *d += s;
+  }
+}
+
+template <typename T>
+hipError_t launch_spmv_rows(hipStream_t s, const T* Wt, int ldt, const T* spikes, int n, int rows, const int* list, const int* count,
+                            T* out, int out_set) {
+  hipLaunchKernelGGL((k_spmv_rows<T>), dim3((rows + 15) / 16), dim3(256), 0, s, Wt, ldt, spikes, n, rows, list, count, out, out_set);
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_spmv_partial(hipStream_t s, const T* Wt, int ldt, const T* spikes, int n, int rows, T* partial, int rows_pad, int chunks,
                                const int* list, const int* count, int seg, T* out, int out_set, unsigned int* tickets) {
@@ -1358,7 +1405,8 @@ namespace ssn {
   template hipError_t launch_ens_finish<T>(hipStream_t, const FinishArgs<T>&);                               \
   template hipError_t launch_matvec<T>(hipStream_t, const MatvecBatch<T>&, int);            \
   template hipError_t launch_matvec_ordered<T>(hipStream_t, const T*, const T*, T*, int, int, int);         \
-  template hipError_t launch_spmv_partial<T>(hipStream_t, const T*, int, const T*, int, int, T*, int, int, const int*, const int*, int, T*, int, unsigned int*);  \
+  template hipError_t launch_spmv_partial<T>(hipStream_t, const T*, int, const T*, int, int, T*, int, int, const int*, const int*, int, T*, int, unsigned int*); \
+  template hipError_t launch_spmv_rows<T>(hipStream_t, const T*, int, const T*, int, int, const int*, const int*, T*, int);  \
   template hipError_t launch_neurons_compact<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T, int*, int*);     \
   template hipError_t launch_transpose<T>(hipStream_t, const T*, T*, int, int, int, int);                   \
   template hipError_t launch_neurons<T>(hipStream_t, const NeuronsBatch<T>&, int); \

@@ -210,6 +210,8 @@ template <typename T> hipError_t launch_transpose(hipStream_t, const T* src, T* 
 template <typename T> hipError_t launch_spmv_partial(hipStream_t, const T* Wt, int ldt, const T* spikes, int n, int rows, T* partial,
                                                      int rows_pad, int chunks, const int* list, const int* count, int seg,
                                                      T* out, int out_set, unsigned int* tickets);
+template <typename T> hipError_t launch_spmv_rows(hipStream_t, const T* Wt, int ldt, const T* spikes, int n, int rows, const int* list, const int* count,
+                                                  T* out, int out_set);
 template <typename T> hipError_t launch_neurons_compact(hipStream_t, const NeuronParams<T>&, const T* J, T* out, T* V, T* R, int n, T amp,
                                                         int* list, int* count);
 template <typename T> hipError_t launch_neurons(hipStream_t, const NeuronsBatch<T>&, int count);

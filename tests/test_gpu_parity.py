@@ -294,12 +294,13 @@ def test_slam_optin_plans_equal_default(Simulator):
     sm = _small_slam(weights_every=None)
     model = build(sm.model)
     outs = []
-    for flags in (0, 32 | 64, 256, 1024, 2048, 4096, 8192):
+    for flags in (0, 32 | 64, 256, 1024, 2048, 4096, 8192, 16384):
         with Simulator(None, model=model, dtype="f64", flags=flags) as sim:
             sim.run_steps(120)
             outs.append(sim.data[sm.probe])
     np.testing.assert_allclose(outs[1], outs[0], atol=1e-12, rtol=0)
     np.testing.assert_array_equal(outs[2], outs[0])
+    np.testing.assert_allclose(outs[7], outs[0], atol=1e-12, rtol=0)     # rows-owned product (opt-in) vs chunk sums + reduce program
     np.testing.assert_allclose(outs[3], outs[0], atol=1e-12, rtol=0)
     np.testing.assert_array_equal(outs[4], outs[0])            # fused (opt-in) vs separate chunk reduction: same order, same bits
     np.testing.assert_array_equal(outs[5], outs[0])            # one launch per operator vs batched neighbours
