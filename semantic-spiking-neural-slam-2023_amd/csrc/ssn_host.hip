@@ -900,9 +900,18 @@ struct Sim final : ssn_sim {
       push_micro(op, -10, false);
     }
     std::vector<std::pair<int, ssn::BatchOp<T>>> pre_sorted, post_sorted;
+    std::vector<std::pair<MOp, int>> pending_reduce;
+    auto drain_reduces = [&]() {
+      bool first = true;
+      for (auto& pr : pending_reduce) { push_micro(pr.first, pr.second, first); first = false; }
+      pending_reduce.clear();
+    };
     for (int i = 0; i < m->n_ops; ++i) {
       const ssn_op_desc& o = m->ops[i];
       MOp op{};
+      if (o.stage == 1 && !fused && !pending_reduce.empty() &&
+          !(o.kind == SSN_OP_MATVEC && !is_micro(o) && bufs[o.i[4]].transposed && !(flags & 4096)))
+        drain_reduces();
       if (o.stage != 1) {
         ssn::BatchOp<T> b{};
         b.bsig = bsig; b.n_sig = n_sig; b.src_prev = o.src_prev ? 1 : 0;
@@ -996,10 +1005,13 @@ struct Sim final : ssn_sim {
               items.push_back(it);
               force_barrier = true;
             } else {
+              // the chunk reduction is deferred past any sparse products that follow directly (they read spike vectors,
+              // never a reduction's output): the products then sit next to each other and share a launch, and their
+              // reductions share one program
               items.push_back(it);
               MOp r{};
               r.kind = o.i[5] ? ssn::M_REDUCE_SET : ssn::M_REDUCE_INC; r.dst = o.i[0]; r.len = o.i[2]; r.i0 = chunks; r.i1 = rows_pad; r.p0 = partial;
-              push_micro(r, o.level, true);
+              pending_reduce.push_back({r, o.level});
             }
           } else {
             flush();
@@ -1109,6 +1121,7 @@ struct Sim final : ssn_sim {
         default: return fail(SSN_EINVAL, "unknown operator kind %d", o.kind);
       }
     }
+    drain_reduces();
     auto by_order = [](const std::pair<int, ssn::BatchOp<T>>& a, const std::pair<int, ssn::BatchOp<T>>& b) { return a.first < b.first; };
     std::stable_sort(pre_sorted.begin(), pre_sorted.end(), by_order);
     std::stable_sort(post_sorted.begin(), post_sorted.end(), by_order);
@@ -1220,7 +1233,7 @@ struct Sim final : ssn_sim {
     auto xlds = [&](const Item& it) { return (size_t)it.cols * sizeof(T) <= 48 * 1024; };
     for (int i = 0; i < n; ++i) {
       Item& lead = items[(size_t)i];
-      if (lead.merged || !(lead.type == IT_MATVEC || lead.type == IT_NEURONS || lead.type == IT_DFT || lead.type == IT_ENS)) continue;
+      if (lead.merged || !(lead.type == IT_MATVEC || lead.type == IT_NEURONS || lead.type == IT_DFT || lead.type == IT_ENS || lead.type == IT_SPMV)) continue;
       if (lead.type == IT_ENS && (lead.dominant || lead.ens.defer)) continue;
       const int cap = lead.type == IT_ENS ? ssn::MAX_ENS_BATCH : ssn::MAX_BATCH;
       int k = 1;
@@ -1378,8 +1391,13 @@ struct Sim final : ssn_sim {
         return ssn::launch_dft<T>(stream, b, it.batch);
       }
       case IT_SPMV_ROWS: return ssn::launch_spmv_rows<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.list, it.count, it.out, it.set);
-      case IT_SPMV: return ssn::launch_spmv_partial<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count, it.seg,
-                                                       it.out, it.set, it.tickets);
+      case IT_SPMV: {
+        ssn::SpmvBatch<T> b{};
+        for (int q = 0; q < it.batch; ++q)
+          b.a[q] = ssn::SpmvArgs<T>{g[q].Wm, g[q].ld, g[q].src, g[q].cols, g[q].rows, g[q].dst, g[q].ld, g[q].n, g[q].list, g[q].count, g[q].seg,
+                                    g[q].out, g[q].set, g[q].tickets};
+        return ssn::launch_spmv_partial<T>(stream, b, it.batch);
+      }
       case IT_NEURONS_COMPACT: return ssn::launch_neurons_compact<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count);
       case IT_NEURONS: {
         ssn::NeuronsBatch<T> b{};

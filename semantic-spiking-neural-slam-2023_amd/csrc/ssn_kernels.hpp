@@ -806,10 +806,21 @@ hipError_t launch_matvec(hipStream_t s, const MatvecBatch<T>& b, int count) {
 //   Traffic: (#spikes x rows) weights instead of (n x rows).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_spmv_partial(const T* __restrict__ Wt, int ldt, const T* __restrict__ spikes,
-                                                      int n, int rows, T* __restrict__ partial, int rows_pad, int chunks,
-                                                      const int* __restrict__ glist, const int* __restrict__ gcount, int seg,
-                                                      T* __restrict__ out, int out_set, unsigned int* __restrict__ tickets) {
+__global__ __launch_bounds__(256) void k_spmv_partial(SpmvBatch<T> batch) {
+  const SpmvArgs<T> sa = batch.a[blockIdx.z];
+  const T* __restrict__ Wt = sa.Wt;
+  const int ldt = sa.ldt;
+  const T* __restrict__ spikes = sa.spikes;
+  const int n = sa.n, rows = sa.rows;
+  T* __restrict__ partial = sa.partial;
+  const int rows_pad = sa.rows_pad, chunks = sa.chunks;
+  const int* __restrict__ glist = sa.list;
+  const int* __restrict__ gcount = sa.count;
+  const int seg = sa.seg;
+  T* __restrict__ out = sa.out;
+  const int out_set = sa.out_set;
+  unsigned int* __restrict__ tickets = sa.tickets;
+  if ((int)blockIdx.x * 256 >= rows || (int)blockIdx.y >= chunks) return;      // (grid sized for the largest product of a batch)
   extern __shared__ unsigned char smem[];
   __shared__ int counts[257];
   const int tid = threadIdx.x;
@@ -951,10 +962,14 @@ hipError_t launch_spmv_rows(hipStream_t s, const T* Wt, int ldt, const T* spikes
 }
 
 template <typename T>
-hipError_t launch_spmv_partial(hipStream_t s, const T* Wt, int ldt, const T* spikes, int n, int rows, T* partial, int rows_pad, int chunks,
-                               const int* list, const int* count, int seg, T* out, int out_set, unsigned int* tickets) {
-  hipLaunchKernelGGL((k_spmv_partial<T>), dim3((rows + 255) / 256, chunks), dim3(256), list ? (size_t)16 : (size_t)n * sizeof(int), s,
-                     Wt, ldt, spikes, n, rows, partial, rows_pad, chunks, list, count, seg, out, out_set, tickets);
+hipError_t launch_spmv_partial(hipStream_t s, const SpmvBatch<T>& b, int count) {
+  int rows = 0, chunks = 0;
+  size_t lds = 16;
+  for (int i = 0; i < count; ++i) {
+    rows = std::max(rows, b.a[i].rows); chunks = std::max(chunks, b.a[i].chunks);
+    if (!b.a[i].list) lds = std::max(lds, (size_t)b.a[i].n * sizeof(int));
+  }
+  hipLaunchKernelGGL((k_spmv_partial<T>), dim3((rows + 255) / 256, chunks, count), dim3(256), lds, s, b);
   return hipGetLastError();
 }
 
@@ -1405,7 +1420,7 @@ namespace ssn {
   template hipError_t launch_ens_finish<T>(hipStream_t, const FinishArgs<T>&);                               \
   template hipError_t launch_matvec<T>(hipStream_t, const MatvecBatch<T>&, int);            \
   template hipError_t launch_matvec_ordered<T>(hipStream_t, const T*, const T*, T*, int, int, int);         \
-  template hipError_t launch_spmv_partial<T>(hipStream_t, const T*, int, const T*, int, int, T*, int, int, const int*, const int*, int, T*, int, unsigned int*); \
+  template hipError_t launch_spmv_partial<T>(hipStream_t, const SpmvBatch<T>&, int); \
   template hipError_t launch_spmv_rows<T>(hipStream_t, const T*, int, const T*, int, int, const int*, const int*, T*, int);  \
   template hipError_t launch_neurons_compact<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T, int*, int*);     \
   template hipError_t launch_transpose<T>(hipStream_t, const T*, T*, int, int, int, int);                   \

@@ -134,6 +134,9 @@ template <typename T> struct MatvecBatch { MatvecArgs<T> a[MAX_BATCH]; };
 template <typename T> struct NeuronsArgs { NeuronParams<T> np; const T* J; T* out; T* V; T* R; int n; T amp; int* seg_list; int* seg_cnt; };
 template <typename T> struct NeuronsBatch { NeuronsArgs<T> a[MAX_BATCH]; };
 struct DftBatch { DftArgs a[MAX_BATCH]; };
+template <typename T> struct SpmvArgs { const T* Wt; int ldt; const T* spikes; int n, rows; T* partial; int rows_pad, chunks; const int* list; const int* count;
+                                       int seg; T* out; int out_set; unsigned int* tickets; };
+template <typename T> struct SpmvBatch { SpmvArgs<T> a[MAX_BATCH]; };
 constexpr int MAX_ENS_BATCH = 2;
 template <typename T> struct EnsBatch { EnsArgs<T> a[MAX_ENS_BATCH]; };
 
@@ -207,9 +210,7 @@ template <typename T> hipError_t program_set_max_lds(int bytes);
 template <typename T> hipError_t launch_matvec(hipStream_t, const MatvecBatch<T>&, int count);
 template <typename T> hipError_t launch_matvec_ordered(hipStream_t, const T* Wt, const T* x, T* y, int rows, int cols, int ldt);
 template <typename T> hipError_t launch_transpose(hipStream_t, const T* src, T* dst, int rows, int cols, int ld, int ldt);
-template <typename T> hipError_t launch_spmv_partial(hipStream_t, const T* Wt, int ldt, const T* spikes, int n, int rows, T* partial,
-                                                     int rows_pad, int chunks, const int* list, const int* count, int seg,
-                                                     T* out, int out_set, unsigned int* tickets);
+template <typename T> hipError_t launch_spmv_partial(hipStream_t, const SpmvBatch<T>&, int count);
 template <typename T> hipError_t launch_spmv_rows(hipStream_t, const T* Wt, int ldt, const T* spikes, int n, int rows, const int* list, const int* count,
                                                   T* out, int out_set);
 template <typename T> hipError_t launch_neurons_compact(hipStream_t, const NeuronParams<T>&, const T* J, T* out, T* V, T* R, int n, T amp,
