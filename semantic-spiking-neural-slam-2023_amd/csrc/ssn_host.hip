@@ -112,6 +112,7 @@ struct Sim final : ssn_sim {
     int* list = nullptr; int* count = nullptr;     // spike list (k_neurons_compact -> k_spmv_partial)
     int seg = 0;                                   // > 0: segmented spike list (k_neurons), segments per spmv chunk
     T* out = nullptr; unsigned int* tickets = nullptr;   // spmv with the chunk reduction fused in (writes the signal itself)
+    int level = -1;                                // scheduling round of the operator (builder): equal level = independent
     int batch = 1;                                 // this item and the next batch-1 items (same kind, independent) share one launch
     bool merged = false;                           // launched by the item that leads its batch
     ssn::DftArgs dft;
@@ -162,6 +163,8 @@ struct Sim final : ssn_sim {
   std::vector<std::vector<int>> item_deps;
   std::vector<hipStream_t> side_streams;
   std::vector<hipEvent_t> dag_events;
+  bool capturing_rounds = false;              // launch_steps: fork independent big operators of one round over side streams
+  size_t round_ev = 0;
   ssn::StepCtx* d_ctx = nullptr;
   std::vector<ssn::TableSlot> tables;
   ssn::TableSlot* d_tables = nullptr;
@@ -909,6 +912,9 @@ struct Sim final : ssn_sim {
     for (int i = 0; i < m->n_ops; ++i) {
       const ssn_op_desc& o = m->ops[i];
       MOp op{};
+      const size_t items_before = items.size();
+      struct LevelTag { std::vector<Item>& v; size_t from; int level; ~LevelTag() { for (size_t q = from; q < v.size(); ++q) if (v[q].type != IT_PROGRAM && v[q].level < 0) v[q].level = level; } }
+          level_tag{items, items_before, o.level};
       if (o.stage == 1 && !fused && !pending_reduce.empty() &&
           !(o.kind == SSN_OP_MATVEC && !is_micro(o) && bufs[o.i[4]].transposed && !(flags & 4096)))
         drain_reduces();
@@ -1429,6 +1435,49 @@ struct Sim final : ssn_sim {
         const Item& it = items[i];
         hipError_t e = hipSuccess;
         if (fused && can_fuse && i == 0 && s > 0) continue;               // head already ran with the previous tail
+        if (capturing_rounds && it.type != IT_PROGRAM && !it.merged) {
+          // a run of big operators of one scheduling round (independent of each other): the first stays on this
+          // stream, the others fork onto side streams and join before whatever follows - inside the captured graph
+          // they become parallel branches
+          int j = i + 1, leaders = 1;
+          while (j < n_items && items[(size_t)j].type != IT_PROGRAM && (items[(size_t)j].merged || items[(size_t)j].level == it.level)) {
+            bool indep = true;
+            if (!items[(size_t)j].merged)
+              for (int d : item_deps[(size_t)j]) if (d >= i && d < j) indep = false;
+            if (!indep) break;
+            leaders += items[(size_t)j].merged ? 0 : 1;
+            ++j;
+          }
+          if (leaders >= 2) {
+            hipStream_t main_stream = stream;
+            hipEvent_t fork = dag_events[round_ev++];
+            if ((e = hipEventRecord(fork, main_stream)) != hipSuccess) return e;
+            int q = 0;
+            std::vector<int> used;
+            for (int t = i; t < j; ++t) {
+              if (items[(size_t)t].merged) continue;
+              if (q > 0) {
+                const int sidx = (q - 1) % (int)side_streams.size();
+                if (std::find(used.begin(), used.end(), sidx) == used.end()) {
+                  if ((e = hipStreamWaitEvent(side_streams[(size_t)sidx], fork, 0)) != hipSuccess) return e;
+                  used.push_back(sidx);
+                }
+                stream = side_streams[(size_t)sidx];
+              }
+              e = launch_item(items[(size_t)t], nullptr, nullptr);
+              stream = main_stream;
+              if (e != hipSuccess) return e;
+              ++q;
+            }
+            for (int sidx : used) {
+              hipEvent_t done = dag_events[round_ev++];
+              if ((e = hipEventRecord(done, side_streams[(size_t)sidx])) != hipSuccess) return e;
+              if ((e = hipStreamWaitEvent(main_stream, done, 0)) != hipSuccess) return e;
+            }
+            i = j - 1;
+            continue;
+          }
+        }
         if (fused && can_fuse && i == n_items - 1 && s + 1 < count)
           e = ssn::launch_program<T>(stream, d_mops, d_progs + tail_begin, 2, d_segs, prog_lds[tail_begin + 1], sig, d_ctx);
         else
@@ -1537,8 +1586,20 @@ struct Sim final : ssn_sim {
       if (dbg) fprintf(stderr, "[ssn] graph instantiated\n");
       return SSN_OK;
     }
+    // opt-in experiment (measured SLOWER on SLAM config 3: 350 vs 320 us per timestep - a fork / join between streams
+    // inside the graph costs more than the overlap of 5-30 us kernels gives back)
+    const bool rounds = (flags & 32768) && !fused_core && item_deps.size() == items.size() && items.size() >= 4;
+    if (rounds) {
+      side_streams.resize(3);
+      for (auto& st : side_streams) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      dag_events.resize((size_t)steps_per_graph * (2 * items.size() + 8));
+      for (auto& ev : dag_events) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
     HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    capturing_rounds = rounds;
+    round_ev = 0;
     hipError_t e = launch_steps(steps_per_graph, true);
+    capturing_rounds = false;
     hipError_t e2 = hipStreamEndCapture(stream, &graph);
     HIPCHK(e);
     HIPCHK(e2);
