@@ -466,6 +466,26 @@ def test_block_kernel_cluster_mode(Simulator):
         os.environ.pop("SSN_BLOCK_CLUSTER", None)
 
 
+def test_block_kernel_other_lif_parameters(Simulator):
+    """Non-default LIF constants through the whole-block kernel; a refractory period shorter than dt (or dt / tau_rc
+    above 1/8) is outside the branch-free f32 step's assumptions and must fall back to the per-timestep kernel."""
+    import sspslam_amd.frontend as fe
+    for lif, expect_block_f32 in ((fe.LIF(tau_rc=0.05, tau_ref=0.0022), True), (fe.LIF(tau_rc=0.03, tau_ref=0.0005), False),
+                                  (fe.LIF(tau_rc=0.006, tau_ref=0.002), False)):
+        pm = small_pathint(ssp_dim=19, n=700, T=10.0, limit=0.2, neuron_type=lif)
+        model = build(pm.model, n_eval_points=400)
+        ref = OracleSimulator(model)
+        ref.run_steps(200)
+        with Simulator(None, model=model, dtype="f64", block_steps=64) as sim:
+            sim.run_steps(200)
+            assert sim.counters()["launches_per_step"] == 0                      # f64 block kernel: the generic LIF step
+            np.testing.assert_allclose(sim.data[pm.probe], ref.probe_data(0), atol=1e-9, rtol=0)
+        with Simulator(None, model=model, dtype="f32", block_steps=64) as sim:
+            sim.run_steps(200)
+            assert (sim.counters()["launches_per_step"] == 0) == expect_block_f32
+            assert H.cosine_error(sim.data[pm.probe][20:], ref.probe_data(0)[20:]).max() < 1e-3
+
+
 def test_block_kernel_variants_f32(Simulator):
     """k_ens_block register/LDS variants (neurons per thread 1..6 by size; forced ones through the tuning knob)
     against the per-timestep kernel: f32, short window, cosine bar."""
