@@ -1,0 +1,24 @@
+"""Where the wall time of a whole `sim.run(T)` + `sim.data[probe]` goes at config 2 (PCIe-inclusive rate):
+input tabulation + upload (prepare), the device run, probe read-back.  usage: bench_end_to_end.py [T]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from sspslam_amd import harness as H
+from sspslam_amd.builder import build
+from sspslam_amd.simulator import Simulator
+
+T = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
+s = H.make_ssp_space(2, 1015)
+path, vels = H.make_random_path(2 * max(T, 10.0) + 3.0, limit=0.1, seed=0)
+pm = H.make_pathint_model(s, path, vels, 10000)
+bm = build(pm.model, n_eval_points=4000)
+sim = Simulator(None, model=bm, dtype="f32")
+steps = int(T / 0.001)
+sim.prepare(1024); sim.run_steps(1024, collect=False); sim._collect()          # warm
+for rep in range(2):
+    t0 = time.perf_counter(); sim.prepare(steps); t1 = time.perf_counter()
+    sim.run_steps(steps, collect=False); t2 = time.perf_counter()
+    sim._collect(); out = sim.data[pm.probe]; t3 = time.perf_counter()
+    print("T = %.0f s: prepare (tabulate + upload) %.1f ms, run %.1f ms (%.1f sim-s/wall-s), probe read-back (%d x %d -> float64 host) %.1f ms; "
+          "end to end %.1f sim-s/wall-s" % (T, (t1 - t0) * 1e3, (t2 - t1) * 1e3, T / (t2 - t1), steps, out.shape[1], (t3 - t2) * 1e3, T / (t3 - t0)), flush=True)
+    sim.clear_probe_data()
