@@ -286,6 +286,17 @@ class Simulator:
         self._check(self._lib.ssn_set_table_device(self._h, table_id, C.c_void_p(rows_dev_ptr), n_rows, tb["width"],
                                                    idx.ctypes.data, idx.size, first_step))
 
+    PIPELINE_CHUNK = 2048
+
+    def _tabulate_chunk(self, first, n):
+        """(first, n, [(rows, idx) per table]) for the n timesteps after 0-based step ``first``."""
+        steps = np.arange(first + 1, first + n + 1)
+        tabs = []
+        for tb in self.model.tables:
+            rows, idx = tabulate(tb["fn"], tb["width"], steps, self.dt)
+            tabs.append((np.ascontiguousarray(rows, dtype=np.float64), np.ascontiguousarray(idx, dtype=np.int32)))
+        return first, n, tabs
+
     # -- running -------------------------------------------------------------------------------
     def run(self, time_in_seconds, progress_bar=None):
         self.run_steps(int(np.round(float(time_in_seconds) / self.dt)))
@@ -299,17 +310,51 @@ class Simulator:
             return
         if self.closed:
             raise fe.SimulationError("simulator is closed")
+        pipelined = None
         if self._prepared_until < self.n_steps + steps or self._prepared_until == 0:
-            self.prepare(steps)
+            if steps > 2 * self.PIPELINE_CHUNK and self.model.tables and not profile:
+                # long run straight from run(): the node closures of chunk k+1 are evaluated on a helper thread while
+                # the device steps chunk k (ssn_run_steps releases the GIL); tables are uploaded between chunks
+                if getattr(self, "_uncollected", False):
+                    self._collect()
+                self._check(self._lib.ssn_reserve_probes(self._h, steps))
+                self._fetched = {}
+                self._reserved_until = self.n_steps + steps
+                pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_CHUNK, steps))
+            else:
+                self.prepare(steps)
         buf_probes = [(k, v[2]) for k, v in self._probe_index.items() if v[0] == "buf"]
         done = 0
         while done < steps:
             chunk = steps - done
+            worker = None
+            if pipelined is not None:
+                first, n_tab, tabs = pipelined
+                for tid, (rows, idx) in enumerate(tabs):
+                    self._check(self._lib.ssn_set_table(self._h, tid, rows.ctypes.data, rows.shape[0], self.model.tables[tid]["width"],
+                                                        idx.ctypes.data, idx.size, first))
+                self._prepared_until = first + n_tab
+                chunk = min(chunk, n_tab)
+                nxt = self.n_steps + chunk
+                pipelined = None
+                if done + chunk < steps:
+                    import threading
+                    box = {}
+                    n_next = min(self.PIPELINE_CHUNK, steps - done - chunk)
+                    worker = threading.Thread(target=lambda: box.update(r=self._tabulate_chunk(nxt, n_next)))
+                    worker.start()
             for _, p in buf_probes:
                 chunk = min(chunk, p["every"] - (self.n_steps % p["every"]))
             self._check(self._lib.ssn_run_steps(self._h, chunk, 1 if profile else 0))
             self.n_steps += chunk
             done += chunk
+            if worker is not None:
+                worker.join()
+                if "r" not in box:
+                    raise fe.SimulationError("evaluating the input nodes for the next chunk failed")
+                pipelined = box["r"]
+                if self.n_steps != pipelined[0]:          # a weight-probe boundary cut the chunk short: re-tabulate from here
+                    pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_CHUNK, steps - done))
             for key, p in buf_probes:
                 if self.n_steps % p["every"] == 0:
                     self._chunks[key].append(self.read_buffer(self._probe_buffer_id(p))[None])

@@ -466,6 +466,23 @@ def test_block_kernel_cluster_mode(Simulator):
         os.environ.pop("SSN_BLOCK_CLUSTER", None)
 
 
+def test_long_run_pipelines_input_tabulation(Simulator):
+    """run_steps() on an unprepared simulator tabulates the input nodes chunk by chunk on a helper thread while the
+    device steps the previous chunk: same samples as preparing the whole run first."""
+    pm = small_pathint(ssp_dim=7, n=64, T=10.0, limit=0.2)
+    model = build(pm.model)
+    with Simulator(None, model=model, dtype="f64") as sim:
+        sim.prepare(7000)
+        sim.run_steps(7000)
+        want = sim.data[pm.probe]
+    with Simulator(None, model=model, dtype="f64") as sim:
+        assert 7000 > 2 * sim.PIPELINE_CHUNK
+        sim.run_steps(7000)
+        np.testing.assert_array_equal(sim.data[pm.probe], want)
+        sim.run_steps(100)
+        assert sim.data[pm.probe].shape[0] == 7100
+
+
 def test_block_kernel_other_lif_parameters(Simulator):
     """Non-default LIF constants through the whole-block kernel; a refractory period shorter than dt (or dt / tau_rc
     above 1/8) is outside the branch-free f32 step's assumptions and must fall back to the per-timestep kernel."""

@@ -9,7 +9,7 @@ from sspslam_amd.simulator import Simulator
 
 T = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
 s = H.make_ssp_space(2, 1015)
-path, vels = H.make_random_path(2 * max(T, 10.0) + 3.0, limit=0.1, seed=0)
+path, vels = H.make_random_path(3 * max(T, 10.0) + 3.0, limit=0.1, seed=0)
 pm = H.make_pathint_model(s, path, vels, 10000)
 bm = build(pm.model, n_eval_points=4000)
 sim = Simulator(None, model=bm, dtype="f32")
@@ -22,3 +22,8 @@ for rep in range(2):
     print("T = %.0f s: prepare (tabulate + upload) %.1f ms, run %.1f ms (%.1f sim-s/wall-s), probe read-back (%d x %d -> float64 host) %.1f ms; "
           "end to end %.1f sim-s/wall-s" % (T, (t1 - t0) * 1e3, (t2 - t1) * 1e3, T / (t2 - t1), steps, out.shape[1], (t3 - t2) * 1e3, T / (t3 - t0)), flush=True)
     sim.clear_probe_data()
+t0 = time.perf_counter()
+sim.run_steps(steps)                       # unprepared: tabulation of chunk k+1 overlaps the device run of chunk k
+out = sim.data[pm.probe]
+t1 = time.perf_counter()
+print("T = %.0f s: plain run_steps + data (pipelined tabulation): %.1f ms -> %.1f sim-s/wall-s end to end" % (T, (t1 - t0) * 1e3, T / (t1 - t0)), flush=True)
