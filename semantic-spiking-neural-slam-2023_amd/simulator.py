@@ -152,13 +152,15 @@ def tabulate(fn, width, steps, dt):
         return np.asarray(rows, dtype=np.float64).reshape(-1, width), np.asarray(idx, dtype=np.int32)
     rows, idx = [], np.empty(len(steps), dtype=np.int32)
     prev = None
-    for j, s in enumerate(steps):
-        v = np.asarray(fn(s * dt), dtype=np.float64).reshape(-1)
+    asarray, f64 = np.asarray, np.float64
+    for j, t in enumerate((np.asarray(steps) * dt).tolist()):        # t = step*dt in float64, as nengo computes it
+        v = asarray(fn(t), dtype=f64).reshape(-1)
         if v.size != width:
             raise fe.SimulationError(f"node function returned {v.size} values, expected {width}")
-        if prev is None or not np.array_equal(v, prev):
+        key = v.tobytes()                                             # (bitwise row comparison: cheaper than array_equal)
+        if key != prev:
             rows.append(v)
-            prev = v
+            prev = key
         idx[j] = len(rows) - 1
     return (np.stack(rows) if rows else np.zeros((0, width))), idx
 
