@@ -440,7 +440,7 @@ hipError_t launch_ensarray(hipStream_t s, const EnsArgs<T>& a) {
 // ---------------------------------------------------------------------------------------------
 template <int DUMMY>
 __global__ __launch_bounds__(1024) void k_dft(DftBatch batch) {
-  const DftArgs a = batch.a[blockIdx.x];
+  const DftArgs& a = batch.a[blockIdx.x];       // (a reference: the radix list is indexed dynamically - a copy would live in scratch)
   extern __shared__ __align__(16) unsigned char ssn_dft_dyn[];
   const int N = a.N, H = N / 2 + 1, tid = threadIdx.x, nthr = blockDim.x;
   float2* x = reinterpret_cast<float2*>(ssn_dft_dyn);
