@@ -516,15 +516,21 @@ hipError_t launch_dft(hipStream_t s, const DftBatch& b, int count) {
 // the dozen tiny nengo operators between two big kernels into a single launch.
 // ---------------------------------------------------------------------------------------------
 // for i = tid, tid + 1024, ... < len: store(i, load(i)), four elements per trip with all loads issued first
+template <typename T, int U, typename L, typename S>
+__device__ inline void vecn_loop(int tid, long long len, L load, S store) {
+  for (long long i0 = tid; i0 < len; i0 += U * 1024) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const long long i = i0 + u * 1024; if (i < len) v[u] = load(i); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const long long i = i0 + u * 1024; if (i < len) store(i, v[u]); }
+  }
+}
+// (long operators - the row hand-offs of a SLAM timestep move 10-20 k elements each - keep 16 loads in flight per thread)
 template <typename T, typename L, typename S>
 __device__ inline void vec4_loop(int tid, long long len, L load, S store) {
-  for (long long i0 = tid; i0 < len; i0 += 4096) {
-    T v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const long long i = i0 + u * 1024; if (i < len) v[u] = load(i); }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const long long i = i0 + u * 1024; if (i < len) store(i, v[u]); }
-  }
+  if (len > 8192) vecn_loop<T, 16>(tid, len, load, store);
+  else vecn_loop<T, 4>(tid, len, load, store);
 }
 
 template <typename T>
