@@ -126,6 +126,8 @@ typedef struct ssn_model_desc {
                                               (k_ens_block): step it once per timestep (k_ensarray) instead,
                                          256 = generic plan: fork the independent branches of a timestep over several
                                               streams inside the step graph (data-hazard analysis in the planner),
+                                         65536 = a workgroup barrier at every level change inside a program (no barrier elision for
+                                              element-aligned dependencies between element-wise operators),
                                          32768 = parallel branches inside the step graph: independent big operators of one scheduling
                                               round fork over side streams during capture (experiment, measured 9 % slower),
                                          16384 = rows-owned sparse decoder product in one launch (k_spmv_rows; experiment, measured

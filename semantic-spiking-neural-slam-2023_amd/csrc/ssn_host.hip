@@ -878,8 +878,38 @@ struct Sim final : ssn_sim {
     std::vector<MOp> cur;
     int prev_level = -1;
     bool force_barrier = false;
+    // Element-wise micro operators are executed with element p of a range starting at `base` on thread
+    // (p - base) mod 1024.  A dependency between two of them therefore needs no workgroup barrier when both map every
+    // shared element to the same thread (equal range starts modulo 1024): program order inside the thread suffices.
+    struct EwAcc { long long lo, len; bool w; };
+    auto ew_access = [&](const MOp& m, std::vector<EwAcc>& out) -> bool {
+      switch (m.kind) {
+        case ssn::M_FILL: case ssn::M_TABLE: case ssn::M_ROW_IN: out.push_back({m.dst, m.len, true}); return true;
+        case ssn::M_AXPY_SET: out.push_back({m.src, m.len, false}); out.push_back({m.dst, m.len, true}); return true;
+        case ssn::M_AXPY_INC: case ssn::M_LOWPASS: out.push_back({m.src, m.len, false}); out.push_back({m.dst, m.len, true}); return true;
+        case ssn::M_ROW_OUT: case ssn::M_PROBE: out.push_back({m.src, m.len, false}); return true;
+        default: return false;
+      }
+    };
+    auto level_change_needs_barrier = [&](const MOp& op) -> bool {
+      if (flags & 65536) return true;
+      std::vector<EwAcc> mine;
+      if (!ew_access(op, mine)) return true;
+      for (size_t q = cur.size(); q-- > 0;) {             // operators since the last barrier
+        std::vector<EwAcc> theirs;
+        if (!ew_access(cur[q], theirs)) return true;
+        for (const EwAcc& x : mine)
+          for (const EwAcc& y : theirs)
+            if ((x.w || y.w) && x.lo < y.lo + y.len && y.lo < x.lo + x.len && ((x.lo - y.lo) % 1024) != 0) return true;
+        if (cur[q].barrier) break;
+      }
+      return false;
+    };
     auto push_micro = [&](MOp op, int level, bool exec_inserted) {
-      op.barrier = cur.empty() ? 0 : ((force_barrier || exec_inserted || level != prev_level) ? 1 : 0);
+      if (cur.empty()) op.barrier = 0;
+      else if (force_barrier || exec_inserted) op.barrier = 1;
+      else if (level != prev_level) op.barrier = level_change_needs_barrier(op) ? 1 : 0;
+      else op.barrier = 0;
       force_barrier = exec_inserted;
       prev_level = level;
       cur.push_back(op);
