@@ -71,7 +71,7 @@ struct Buf {
   int64_t ldt = 0;
 };
 
-enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_NEURONS_COMPACT, IT_DFT, IT_SPMV_ROWS };
+enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_NEURONS_COMPACT, IT_DFT, IT_SPMV_ROWS, IT_VECOPS };
 
 }  // namespace
 
@@ -161,6 +161,7 @@ struct Sim final : ssn_sim {
   // buffers and scratch memory) - lets the step graph fork independent branches over several streams
   struct Rng { const void* space; int64_t lo, hi; bool w; };
   std::vector<std::vector<int>> item_deps;
+  std::vector<MOp> vecops_host;               // operators of the grid-wide first level (IT_VECOPS), host copy
   std::vector<hipStream_t> side_streams;
   std::vector<hipEvent_t> dag_events;
   bool capturing_rounds = false;              // launch_steps: fork independent big operators of one round over side streams
@@ -1199,6 +1200,29 @@ struct Sim final : ssn_sim {
     }
     // micro-op storage: programs in order, then a copy of the head behind the tail for the fused launch.
     // Each program gets an LDS staging plan when the signals it touches fit (see stage_program).
+    // Long first level of the head program -> its own grid-wide launch (k_vecops).  The head then no longer starts the
+    // timestep, so the tail / head fusion is given up: worth it from ~16 k elements on (SLAM config 3: 42 -> ~23 us).
+    std::vector<MOp>& vec_ops = vecops_host;
+    vec_ops.clear();
+    if (!fused && !(flags & 131072) && !items.empty() && items.front().type == IT_PROGRAM && !programs.empty()) {
+      std::vector<MOp>& head = programs[(size_t)item_prog[0]];
+      size_t lv = 0;
+      long long elems = 0;
+      bool ew_only = true;
+      for (; lv < head.size() && (lv == 0 || !head[lv].barrier); ++lv) {
+        const int kd = head[lv].kind;
+        ew_only = ew_only && (kd == ssn::M_FILL || kd == ssn::M_ROW_IN || kd == ssn::M_TABLE || kd == ssn::M_AXPY_INC ||
+                              kd == ssn::M_AXPY_SET || kd == ssn::M_LOWPASS);
+        elems += head[lv].len;
+      }
+      if (ew_only && elems >= 16384 && lv < head.size()) {
+        vec_ops.assign(head.begin(), head.begin() + (long)lv);
+        head.erase(head.begin(), head.begin() + (long)lv);
+        head[0].barrier = 0;
+        Item vi; vi.type = IT_VECOPS; vi.n = (int)std::min<long long>(256, (elems + 2047) / 2048);
+        items.insert(items.begin(), vi);
+      }
+    }
     int n_prog = (int)programs.size();
     mops.clear();
     prog_descs.clear();
@@ -1235,6 +1259,10 @@ struct Sim final : ssn_sim {
     if (!prog_descs.empty()) HIPCHK(hipMemcpy(d_progs, prog_descs.data(), prog_descs.size() * sizeof(ssn::ProgDesc), hipMemcpyHostToDevice));
     if (!prog_segs.empty()) HIPCHK(hipMemcpy(d_segs, prog_segs.data(), prog_segs.size() * sizeof(ssn::ProgSeg), hipMemcpyHostToDevice));
     ssn::program_set_max_lds<T>(LDS_CAP);
+    if (!vec_ops.empty()) {
+      items.front().op_begin = (int)mops.size(); items.front().op_count = (int)vec_ops.size();
+      mops.insert(mops.end(), vec_ops.begin(), vec_ops.end());
+    }
     CHK(dmalloc(&d_mops, (int64_t)mops.size() * (int64_t)sizeof(MOp)));
     HIPCHK(hipMemcpy(d_mops, mops.data(), mops.size() * sizeof(MOp), hipMemcpyHostToDevice));
     launches_per_step = (int)items.size() - (can_fuse ? 1 : 0);
@@ -1296,32 +1324,33 @@ struct Sim final : ssn_sim {
     std::vector<std::vector<Rng>> acc(items.size());
     auto sg = [&](std::vector<Rng>& a, int64_t lo, int64_t len, bool w) { if (len > 0) a.push_back(Rng{S, lo, lo + len, w}); };
     auto pt = [&](std::vector<Rng>& a, const void* p, bool w) { if (p) a.push_back(Rng{p, 0, 1, w}); };
+    auto micro_access = [&](std::vector<Rng>& a, const MOp& op) {
+      switch (op.kind) {
+        case ssn::M_FILL: case ssn::M_TABLE: case ssn::M_ROW_IN: sg(a, op.dst, op.len, true); break;
+        case ssn::M_AXPY_INC: case ssn::M_LOWPASS: sg(a, op.src, op.len, false); sg(a, op.dst, op.len, true); break;
+        case ssn::M_AXPY_SET: sg(a, op.src, op.len, false); sg(a, op.dst, op.len, true); break;
+        case ssn::M_MATVEC_INC: case ssn::M_MATVEC_SET: sg(a, op.src, op.i0, false); sg(a, op.dst, op.len, true); pt(a, op.p0, false); break;
+        case ssn::M_GATE: sg(a, op.src, 2 * op.len + 1, false); sg(a, op.dst, op.len, true); break;
+        case ssn::M_ARGMAX_GATHER: pt(a, op.p1, false); pt(a, op.p0, false); sg(a, op.dst, op.len, true); break;
+        case ssn::M_PROBE: case ssn::M_ROW_OUT: sg(a, op.src, op.len, false); break;
+        case ssn::M_REDUCE_SET: case ssn::M_REDUCE_INC: pt(a, op.p0, false); sg(a, op.dst, op.len, true); break;
+        case ssn::M_ENS_FINISH: {
+          pt(a, op.p0, false);
+          for (auto& h : host_idx)
+            if (h.first == op.p1)
+              for (int64_t j = 0; j < h.second.second; ++j) sg(a, h.second.first[j], 1, true);
+          break;
+        }
+        default: break;      // M_STEP_END: the tail program is a join point anyway
+      }
+    };
     int prog_i = 0;
     for (size_t i = 0; i < items.size(); ++i) {
       const Item& it = items[i];
       std::vector<Rng>& a = acc[i];
       switch (it.type) {
         case IT_PROGRAM: {
-          for (const MOp& op : programs[(size_t)item_prog[(size_t)prog_i]]) {
-            switch (op.kind) {
-              case ssn::M_FILL: case ssn::M_TABLE: case ssn::M_ROW_IN: sg(a, op.dst, op.len, true); break;
-              case ssn::M_AXPY_INC: case ssn::M_LOWPASS: sg(a, op.src, op.len, false); sg(a, op.dst, op.len, true); break;
-              case ssn::M_AXPY_SET: sg(a, op.src, op.len, false); sg(a, op.dst, op.len, true); break;
-              case ssn::M_MATVEC_INC: case ssn::M_MATVEC_SET: sg(a, op.src, op.i0, false); sg(a, op.dst, op.len, true); pt(a, op.p0, false); break;
-              case ssn::M_GATE: sg(a, op.src, 2 * op.len + 1, false); sg(a, op.dst, op.len, true); break;
-              case ssn::M_ARGMAX_GATHER: pt(a, op.p1, false); pt(a, op.p0, false); sg(a, op.dst, op.len, true); break;
-              case ssn::M_PROBE: case ssn::M_ROW_OUT: sg(a, op.src, op.len, false); break;
-              case ssn::M_REDUCE_SET: case ssn::M_REDUCE_INC: pt(a, op.p0, false); sg(a, op.dst, op.len, true); break;
-              case ssn::M_ENS_FINISH: {
-                pt(a, op.p0, false);
-                for (auto& h : host_idx)
-                  if (h.first == op.p1)
-                    for (int64_t j = 0; j < h.second.second; ++j) sg(a, h.second.first[j], 1, true);
-                break;
-              }
-              default: break;      // M_STEP_END: the tail program is a join point anyway
-            }
-          }
+          for (const MOp& op : programs[(size_t)item_prog[(size_t)prog_i]]) micro_access(a, op);
           ++prog_i;
           break;
         }
@@ -1333,6 +1362,9 @@ struct Sim final : ssn_sim {
           sg(a, it.ens.x_off, (int64_t)it.ens.K * it.ens.din, false);
           pt(a, it.ens.partials, true); pt(a, it.ens.V, true); pt(a, it.ens.R, true);
           pt(a, it.ens.enc, false); pt(a, it.ens.bias, false); pt(a, it.ens.dec, false);
+          break;
+        case IT_VECOPS:
+          for (const MOp& op : vecops_host) micro_access(a, op);
           break;
         case IT_DFT:
           sg(a, it.src - sig, it.cols, false); sg(a, it.dst - sig, it.rows, true); pt(a, it.dft.tw, false);
@@ -1400,6 +1432,7 @@ struct Sim final : ssn_sim {
     const Item* g = &it;                            // (batch members are adjacent in `items`)
     switch (it.type) {
       case IT_PROGRAM: return ssn::launch_program<T>(stream, d_mops, d_progs + it.op_begin, 1, d_segs, prog_lds[it.op_begin], sig, d_ctx);
+      case IT_VECOPS: return ssn::launch_vecops<T>(stream, d_mops + it.op_begin, it.op_count, it.n, sig, d_ctx);
       case IT_ENS: {
         if (e0) { hipError_t e = hipEventRecord(e0, stream); if (e != hipSuccess) return e; }
         hipError_t e;

@@ -716,6 +716,53 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
  }
 }
 
+// k_vecops: the first level of a timestep's head program when it is long (SLAM config 3: ~100 k elements of resets
+// and hand-offs from the pre stage) - independent element-wise operators, executed grid-wide instead of by the
+// program's single workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void k_vecops(const MicroOp<T>* __restrict__ ops, int n_ops, T* __restrict__ sig, const StepCtx* __restrict__ ctx) {
+  const long long step = ctx->step;
+  const long long gtid = (long long)blockIdx.x * 256 + threadIdx.x, gsz = (long long)gridDim.x * 256;
+  for (int o = 0; o < n_ops; ++o) {
+    const MicroOp<T> op = ops[o];
+    switch (op.kind) {
+      case M_FILL:
+        for (long long i = gtid; i < op.len; i += gsz) sig[op.dst + i] = op.a;
+        break;
+      case M_AXPY_INC:
+        for (long long i = gtid; i < op.len; i += gsz) sig[op.dst + i] += op.a * sig[op.src + i];
+        break;
+      case M_AXPY_SET:
+        for (long long i = gtid; i < op.len; i += gsz) sig[op.dst + i] = op.a * sig[op.src + i];
+        break;
+      case M_LOWPASS:
+        for (long long i = gtid; i < op.len; i += gsz) sig[op.dst + i] = op.a * sig[op.dst + i] + op.b * sig[op.src + i];
+        break;
+      case M_ROW_IN: {
+        const T* row = (const T*)op.p0 + (size_t)(step - ctx->block_start + 1) * op.i0;
+        for (long long i = gtid; i < op.len; i += gsz) sig[op.dst + i] = row[op.i1 + i];
+        break;
+      }
+      case M_TABLE: {
+        const TableSlot* t = (const TableSlot*)op.p0;
+        const long long rel = step - t->first_step;
+        int row = -1;
+        if (rel >= 0 && rel < t->n_idx) row = t->idx[rel];
+        const bool have = row >= 0 && row < t->n_rows;
+        const T* rows = (const T*)t->rows;
+        for (long long i = gtid; i < op.len; i += gsz) sig[op.dst + i] = have ? rows[(size_t)row * t->width + i] : T(0);
+        break;
+      }
+      default: break;
+    }
+  }
+}
+template <typename T>
+hipError_t launch_vecops(hipStream_t s, const MicroOp<T>* ops, int n_ops, int wgs, T* sig, const StepCtx* ctx) {
+  hipLaunchKernelGGL((k_vecops<T>), dim3(wgs), dim3(256), 0, s, ops, n_ops, sig, ctx);
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_program(hipStream_t s, const MicroOp<T>* d_ops, const ProgDesc* progs, int n_progs, const ProgSeg* segs, int lds_bytes,
                           T* sig, StepCtx* ctx) {
@@ -1423,6 +1470,7 @@ namespace ssn {
   template hipError_t launch_state_unpack<T>(hipStream_t, const T*, T*, int64_t, int);                       \
   template hipError_t launch_program<T>(hipStream_t, const MicroOp<T>*, const ProgDesc*, int, const ProgSeg*, int, T*, StepCtx*); \
   template hipError_t program_set_max_lds<T>(int);                                                          \
+  template hipError_t launch_vecops<T>(hipStream_t, const MicroOp<T>*, int, int, T*, const StepCtx*);        \
   template hipError_t launch_ens_finish<T>(hipStream_t, const FinishArgs<T>&);                               \
   template hipError_t launch_matvec<T>(hipStream_t, const MatvecBatch<T>&, int);            \
   template hipError_t launch_matvec_ordered<T>(hipStream_t, const T*, const T*, T*, int, int, int);         \

@@ -207,6 +207,7 @@ template <typename T> bool ens_block_supported(int din, int dout, int n, int* th
 template <typename T> hipError_t launch_program(hipStream_t, const MicroOp<T>* ops, const ProgDesc* progs, int n_progs, const ProgSeg* segs,
                                                int lds_bytes, T* sig, StepCtx* ctx);
 template <typename T> hipError_t program_set_max_lds(int bytes);
+template <typename T> hipError_t launch_vecops(hipStream_t, const MicroOp<T>* ops, int n_ops, int wgs, T* sig, const StepCtx* ctx);
 template <typename T> hipError_t launch_matvec(hipStream_t, const MatvecBatch<T>&, int count);
 template <typename T> hipError_t launch_matvec_ordered(hipStream_t, const T* Wt, const T* x, T* y, int rows, int cols, int ldt);
 template <typename T> hipError_t launch_transpose(hipStream_t, const T* src, T* dst, int rows, int cols, int ld, int ldt);

@@ -294,7 +294,7 @@ def test_slam_optin_plans_equal_default(Simulator):
     sm = _small_slam(weights_every=None)
     model = build(sm.model)
     outs = []
-    for flags in (0, 32 | 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
+    for flags in (0, 32 | 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072):
         with Simulator(None, model=model, dtype="f64", flags=flags) as sim:
             sim.run_steps(120)
             outs.append(sim.data[sm.probe])
@@ -307,6 +307,7 @@ def test_slam_optin_plans_equal_default(Simulator):
     np.testing.assert_array_equal(outs[6], outs[0])            # finish operator vs direct write of one-workgroup ensembles
     np.testing.assert_array_equal(outs[8], outs[0])            # parallel branches per scheduling round (opt-in) vs the serial step graph
     np.testing.assert_array_equal(outs[9], outs[0])            # a barrier at every level change vs elided barriers
+    np.testing.assert_array_equal(outs[10], outs[0])           # head program kept whole vs its long first level run grid-wide
 
 
 def test_feedforward_model_runs_fully_batched(Simulator):
