@@ -84,6 +84,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C semantic-spiking-neural-slam-2023_amd/csrc` (there is no CPU fallback)")
+    # PyTorch-ROCm ships its own libamdhip64 / HSA runtime.  When the system runtime this library links against is
+    # mapped first and torch (used by the decoder solver) initialises the GPU afterwards, later HIP calls from here
+    # fail with "no ROCm-capable device is detected"; the other order works.  So: torch first, when it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported

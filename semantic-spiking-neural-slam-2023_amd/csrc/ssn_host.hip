@@ -1908,7 +1908,9 @@ int ssn_create(const ssn_model_desc* desc, ssn_sim** out) {
   if (desc->n_signals <= 0 || !desc->signal_init || desc->n_ops <= 0 || !desc->ops || desc->dt <= 0)
     return fail(SSN_EINVAL, "empty or inconsistent model description");
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SSN_EHIP, "no HIP device available (there is no CPU fallback)");
+  const hipError_t dev_err = hipGetDeviceCount(&ndev);
+  if (dev_err != hipSuccess || ndev <= 0)
+    return fail(SSN_EHIP, "no HIP device available (there is no CPU fallback): hipGetDeviceCount -> %s, %d devices", hipGetErrorString(dev_err), ndev);
   if (desc->device < 0 || desc->device >= ndev) return fail(SSN_EINVAL, "device %d out of range (%d devices)", desc->device, ndev);
   if (desc->dtype == SSN_F32) return create_sim<float>(desc, out);
   if (desc->dtype == SSN_F64) return create_sim<double>(desc, out);

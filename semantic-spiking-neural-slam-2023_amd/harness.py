@@ -22,6 +22,8 @@ def make_random_path(T, dt=0.001, domain_dim=2, limit=0.1, seed=0, radius=1.0):
     """(path, vels): per-axis ``WhiteSignal(T, high=limit, seed=seed+axis)`` min-max scaled to
     +-0.9*radius; ``vels = diff(path)/dt`` with a leading zero row."""
     path = np.hstack([nengo.WhiteSignal(T, high=limit, seed=seed + i).run(T, dt=dt) for i in range(domain_dim)])
+    if not np.all(np.isfinite(path)):
+        raise nengo.ValidationError(f"a {T} s band-limited path has no frequency below {limit} Hz (need T >= {1.0 / limit} s)", "limit")
     for i in range(domain_dim):
         x = path[:, i]
         path[:, i] = 1.8 * radius * (x - x.min()) / (x.max() - x.min()) - 0.9 * radius

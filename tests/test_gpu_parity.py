@@ -4,6 +4,8 @@ the NumPy oracle on the same built model and the same seeded inputs.
 Bars: f64 (parity mode) - 1e-9 absolute on the probe trajectory (observed ~1e-16: same operation order,
 -ffp-contract=off); f32 (fast mode) - 1e-3 cosine error, the tolerance BASELINE.json's north_star states,
 on windows short enough that spike-level chaos has not amplified the rounding difference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -15,6 +17,7 @@ from oracle import OracleSimulator
 from helpers import small_pathint
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -466,6 +469,20 @@ def test_block_kernel_cluster_mode(Simulator):
                 assert ce.max() < 1e-3, (P, ce.max())
     finally:
         os.environ.pop("SSN_BLOCK_CLUSTER", None)
+
+
+def test_example_script_with_the_reference_command_line(Simulator, tmp_path):
+    """examples/run_pathint.py: the reference's run_pathint.py options end to end, result file in its format."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("run_pathint_example", os.path.join(ROOT, "examples", "run_pathint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(["--ssp-dim", "7", "--pi-n-neurons", "64", "--T", "0.4", "--limit", "0.5", "--save", "--save-dir", str(tmp_path)])
+    assert out.shape == (400, 7)
+    files = os.listdir(tmp_path)
+    assert len(files) == 1 and files[0].startswith("pi_backend_mi355x_sspdim_7_pinneurons_64_T_0_")
+    z = np.load(tmp_path / files[0], allow_pickle=True)
+    assert z["pi_sim_out"].shape == (400, 7) and z["pi_path"].shape == (400, 2) and float(z["elapsed_time"]) > 0
 
 
 def test_long_run_pipelines_input_tabulation(Simulator):
