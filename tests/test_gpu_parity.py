@@ -477,12 +477,26 @@ def test_example_script_with_the_reference_command_line(Simulator, tmp_path):
     spec = importlib.util.spec_from_file_location("run_pathint_example", os.path.join(ROOT, "examples", "run_pathint.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    out = mod.main(["--ssp-dim", "7", "--pi-n-neurons", "64", "--T", "0.4", "--limit", "0.5", "--save", "--save-dir", str(tmp_path)])
-    assert out.shape == (400, 7)
+    out = mod.main(["--ssp-dim", "7", "--pi-n-neurons", "64", "--T", "2.5", "--limit", "0.5", "--save", "--save-dir", str(tmp_path)])
+    assert out.shape == (2500, 7) and np.isfinite(out).all()
     files = os.listdir(tmp_path)
-    assert len(files) == 1 and files[0].startswith("pi_backend_mi355x_sspdim_7_pinneurons_64_T_0_")
+    assert len(files) == 1 and files[0].startswith("pi_backend_mi355x_sspdim_7_pinneurons_64_T_2_")
     z = np.load(tmp_path / files[0], allow_pickle=True)
-    assert z["pi_sim_out"].shape == (400, 7) and z["pi_path"].shape == (400, 2) and float(z["elapsed_time"]) > 0
+    assert z["pi_sim_out"].shape == (2500, 7) and z["pi_path"].shape == (2500, 2) and float(z["elapsed_time"]) > 0
+
+
+def test_slam_example_script(Simulator, tmp_path):
+    """examples/run_slam.py: options of the reference's run_slam.py, map recall and the result file."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("run_slam_example", os.path.join(ROOT, "examples", "run_slam.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out, lm_locs = mod.main(["--ssp-dim", "55", "--pi-n-neurons", "60", "--mem-n-neurons", "200", "--circonv-n-neurons", "30",
+                             "--n-landmarks", "5", "--view-rad", "0.6", "--T", "5", "--limit", "0.2", "--save",
+                             "--save-dir", str(tmp_path)])
+    assert out.shape == (5000, 55) and lm_locs.shape == (5, 2) and np.isfinite(out).all()
+    z = np.load(tmp_path / os.listdir(tmp_path)[0], allow_pickle=True)
+    assert z["slam_sim_out"].shape == (5000, 55) and z["landmark_loc_est"].shape == (5, 2)
 
 
 def test_long_run_pipelines_input_tabulation(Simulator):
