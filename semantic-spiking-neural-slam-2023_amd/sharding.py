@@ -256,7 +256,16 @@ class ShardedPathIntegration:
             return
         self._ungathered = 0
         first = self.n_steps - n
-        full = self._gather_device(n)
+        try:
+            full = self._gather_device(n)
+        except Exception as e:                 # (deterministic API errors hit every rank alike: all fall back together)
+            import warnings
+            warnings.warn(f"device-resident block exchange failed ({e!r}); using the host path from here on")
+            self.device_exchange = False
+            self.sim._collect()
+            local = self.sim.probe_tail(self.osc_probe, n) if self.osc_probe is not None else np.zeros((n, 0))
+            self.sim.clear_probe_data()
+            full = self._gather(local) if self.world > 1 else local
         if self.readout is None:
             return
         if self.defer_readout > 0:

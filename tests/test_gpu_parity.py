@@ -391,6 +391,18 @@ def test_sharded_runner_device_exchange(Simulator):
     finally:
         if created:
             dist.destroy_process_group()
+    # a failing device exchange falls back to the host path (and says so)
+    pm4 = small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2)
+    r = ShardedPathIntegration(pm4, 0, 1, dtype="f64", block=128, device_exchange=True, gather_every=1)
+
+    def broken(n):
+        raise RuntimeError("simulated collective failure")
+    r._gather_device = broken
+    r.prepare(300)
+    with pytest.warns(UserWarning, match="host path"):
+        r.run_steps(300)
+    np.testing.assert_allclose(r.probe_data(), ref.probe_data(0), atol=1e-9, rtol=0)
+    r.close()
     # a last rank with fewer VCOs than the others (28 VCOs over 3 ranks: 10, 10, 8): its samples are padded to the
     # common width before the all-gather; without a process group its slot of the gathered block is checked alone
     pm3 = small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2)
