@@ -140,3 +140,23 @@ def test_reference_slamnetwork_class_on_our_stack(ref):
     pa, pb = a.probe_data(0), b.probe_data(0)
     assert np.abs(pb).max() > 0.1
     np.testing.assert_allclose(pa, pb, atol=1e-12, rtol=0)            # observed 1.4e-16
+
+
+def test_recorded_path_of_the_reference_loads():
+    """``example_paths/twoRooms_path.npy`` through ``harness.load_path`` (the ``--path-data`` handling of
+    run_pathint.py:77-89): cut to 49 999 rows, each axis rescaled to +-0.9, velocities by differencing; and at a
+    20 ms recording step, interpolation to the 1 ms simulation step."""
+    from sspslam_amd import harness as H
+    f = os.path.join(REF, "example_paths", "twoRooms_path.npy")
+    raw = np.load(f)
+    path, vels = H.load_path(f)
+    assert path.shape == (49999, 2) and vels.shape == path.shape
+    np.testing.assert_allclose(path.min(0), -0.9, atol=1e-12)
+    np.testing.assert_allclose(path.max(0), 0.9, atol=1e-12)
+    # rescaling is affine per axis: the shape of the trajectory is the recorded one
+    for i in range(2):
+        c = np.corrcoef(path[:, i], raw[:49999, i])[0, 1]
+        assert c > 1 - 1e-12
+    np.testing.assert_allclose(np.cumsum(vels, axis=0) * 0.001 + path[0], path, atol=1e-9)
+    p2, _ = H.load_path(f, data_dt=0.02, max_rows=500)
+    assert p2.shape == (10000, 2)
