@@ -511,6 +511,25 @@ def test_slam_example_script(Simulator, tmp_path):
     assert z["slam_sim_out"].shape == (5000, 55) and z["landmark_loc_est"].shape == (5, 2)
 
 
+def test_pathint_3d_matches_oracle(Simulator):
+    """Three-dimensional domain (BASELINE config 5's space family: simplex basis in 3-D, random rotations from a seeded
+    generator): the VCO array has the same shape, so the whole-block kernel applies."""
+    space = H.make_ssp_space(3, ssp_dim=33, rng=np.random.default_rng(3))
+    assert space.ssp_dim == 33 and space.domain_dim == 3
+    path, vels = H.make_random_path(10.0, limit=0.2, seed=2, domain_dim=3)
+    pm = H.make_pathint_model(space, path, vels, 80)
+    model = build(pm.model)
+    ref = OracleSimulator(model)
+    ref.run_steps(250)
+    with Simulator(None, model=model, dtype="f64", block_steps=100) as sim:
+        sim.run_steps(250)
+        assert sim.counters()["launches_per_step"] == 0
+        np.testing.assert_allclose(sim.data[pm.probe], ref.probe_data(0), atol=1e-9, rtol=0)
+    with Simulator(None, model=model, dtype="f32") as sim:
+        sim.run_steps(250)
+        assert H.cosine_error(sim.data[pm.probe][20:], ref.probe_data(0)[20:]).max() < 1e-3
+
+
 def test_long_run_pipelines_input_tabulation(Simulator):
     """run_steps() on an unprepared simulator tabulates the input nodes chunk by chunk on a helper thread while the
     device steps the previous chunk: same samples as preparing the whole run first."""
