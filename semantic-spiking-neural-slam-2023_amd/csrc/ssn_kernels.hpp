@@ -1265,12 +1265,12 @@ __global__ __launch_bounds__(64) void kb_lowpass(BatchOp<T> o) {
 // of kb_lowpass): thread (element i, chunk c) first runs its chunk from a zero state to get the chunk's own
 // contribution L_c, the chunk carries  Y_c = a^len_c * Y_{c-1} + L_c  are chained through LDS, then every thread
 // re-runs its chunk from the right carry and writes the outputs.  2 * B / C dependent steps instead of B.
-template <int C>
-__global__ __launch_bounds__(64 * C) void kb_lowpass_chunked(BatchOp<float> o) {
-  __shared__ float sl[C][64];
-  __shared__ float sp[C][64];
-  const int e = threadIdx.x & 63, c = threadIdx.x >> 6;
-  const long long i = (long long)blockIdx.x * 64 + e;
+template <int C, int E>                       // C time chunks x E elements per workgroup (C * E threads)
+__global__ __launch_bounds__(C * E) void kb_lowpass_chunked(BatchOp<float> o) {
+  __shared__ float sl[C][E];
+  __shared__ float sp[C][E];
+  const int e = threadIdx.x % E, c = threadIdx.x / E;
+  const long long i = (long long)blockIdx.x * E + e;
   const int per = (o.B + C - 1) / C;
   const int t0 = min(o.B, c * per), t1 = min(o.B, t0 + per);
   const bool ok = i < o.len;
@@ -1408,7 +1408,7 @@ hipError_t launch_batch_op(hipStream_t s, const BatchOp<T>& o) {
   if (o.kind == M_LOWPASS) {
     if constexpr (sizeof(T) == 4) {
       if (o.B >= 256) {
-        hipLaunchKernelGGL((kb_lowpass_chunked<8>), dim3((unsigned)((o.len + 63) / 64)), dim3(512), 0, s, o);
+        hipLaunchKernelGGL((kb_lowpass_chunked<32, 32>), dim3((unsigned)((o.len + 31) / 32)), dim3(1024), 0, s, o);
         return hipGetLastError();
       }
     }
