@@ -126,6 +126,7 @@ typedef struct ssn_model_desc {
                                               (k_ens_block): step it once per timestep (k_ensarray) instead,
                                          256 = generic plan: fork the independent branches of a timestep over several
                                               streams inside the step graph (data-hazard analysis in the planner),
+                                         262144 = one launch per element-wise operator of the time-batched stages (no batching),
                                          131072 = the head program of a timestep is kept whole (its long first level is otherwise run
                                               grid-wide by k_vecops, giving up the tail / head fusion),
                                          65536 = a workgroup barrier at every level change inside a program (no barrier elision for

@@ -1418,10 +1418,44 @@ struct Sim final : ssn_sim {
   }
 
   hipError_t run_batch(std::vector<ssn::BatchOp<T>>& ops, int B, int64_t step0) {
-    for (auto& o : ops) {
-      o.B = B; o.step0 = step0;
-      hipError_t e = ssn::launch_batch_op<T>(stream, o);
+    auto elementwise = [](const ssn::BatchOp<T>& o) {
+      return o.kind == ssn::M_FILL || o.kind == ssn::M_AXPY_INC || o.kind == ssn::M_AXPY_SET || o.kind == ssn::M_TABLE || o.kind == ssn::M_PROBE;
+    };
+    // signal ranges (rows are handled identically by every operator, so column ranges decide): written / read
+    auto conflict = [&](const ssn::BatchOp<T>& a, const ssn::BatchOp<T>& b) {
+      auto ov = [](long long x, long long xl, long long y, long long yl) { return x < y + yl && y < x + xl; };
+      auto wr = [](const ssn::BatchOp<T>& o) { return o.kind != ssn::M_PROBE; };
+      auto rd = [](const ssn::BatchOp<T>& o) { return o.kind == ssn::M_AXPY_INC || o.kind == ssn::M_AXPY_SET || o.kind == ssn::M_PROBE; };
+      if (wr(a) && wr(b) && ov(a.dst, a.len, b.dst, b.len)) return true;
+      if (wr(a) && rd(b) && ov(a.dst, a.len, b.src, b.len)) return true;
+      if (rd(a) && wr(b) && ov(a.src, a.len, b.dst, b.len)) return true;
+      return false;
+    };
+    for (size_t i = 0; i < ops.size();) {
+      ops[i].B = B; ops[i].step0 = step0;
+      if (elementwise(ops[i]) && !(flags & 262144)) {
+        // consecutive element-wise operators without a data hazard between them share one launch
+        ssn::BatchOpList<T> l{};
+        l.op[0] = ops[i];
+        l.count = 1;
+        size_t j = i + 1;
+        for (; j < ops.size() && l.count < ssn::MAX_BATCH_OPS && elementwise(ops[j]); ++j) {
+          ops[j].B = B; ops[j].step0 = step0;
+          bool clash = false;
+          for (int q = 0; q < l.count; ++q) clash = clash || conflict(l.op[q], ops[j]);
+          if (clash) break;
+          l.op[l.count++] = ops[j];
+        }
+        if (l.count > 1) {
+          hipError_t e = ssn::launch_batch_elementwise<T>(stream, l);
+          if (e != hipSuccess) return e;
+          i = j;
+          continue;
+        }
+      }
+      hipError_t e = ssn::launch_batch_op<T>(stream, ops[i]);
       if (e != hipSuccess) return e;
+      ++i;
     }
     return hipSuccess;
   }

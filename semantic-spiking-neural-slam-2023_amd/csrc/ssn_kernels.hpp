@@ -1210,7 +1210,7 @@ hipError_t launch_voja(hipStream_t s, T* E, const T* spk, const T* key, const T*
 // becomes a scan along time.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void kb_elementwise(BatchOp<T> o) {
+__device__ inline void kb_elementwise_body(const BatchOp<T>& o) {
   const long long total = (long long)o.B * o.len;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const long long t = e / o.len, i = e - t * o.len;
@@ -1240,6 +1240,23 @@ __global__ __launch_bounds__(256) void kb_elementwise(BatchOp<T> o) {
       default: break;
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void kb_elementwise(BatchOp<T> o) { kb_elementwise_body<T>(o); }
+// several independent element-wise operators of a time-batched stage in one launch (a launch costs ~5 us)
+template <typename T>
+__global__ __launch_bounds__(256) void kb_elementwise_multi(BatchOpList<T> l) {
+  for (int q = 0; q < l.count; ++q) kb_elementwise_body<T>(l.op[q]);
+}
+template <typename T>
+hipError_t launch_batch_elementwise(hipStream_t s, const BatchOpList<T>& l) {
+  long long total = 0;
+  for (int q = 0; q < l.count; ++q) total = std::max(total, (long long)l.op[q].B * l.op[q].len);
+  if (total <= 0) return hipSuccess;
+  const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL((kb_elementwise_multi<T>), dim3(grid), dim3(256), 0, s, l);
+  return hipGetLastError();
 }
 
 // scan along time: y[t+1] = a*y[t] + b*u[t], one thread per signal element, rows read ahead in groups
@@ -1482,6 +1499,7 @@ namespace ssn {
   template hipError_t launch_pes<T>(hipStream_t, T*, const T*, const T*, int, int, int, T);                 \
   template hipError_t launch_voja<T>(hipStream_t, T*, const T*, const T*, const T*, const T*, int, int, int, T); \
   template hipError_t launch_batch_op<T>(hipStream_t, const BatchOp<T>&);                                   \
+  template hipError_t launch_batch_elementwise<T>(hipStream_t, const BatchOpList<T>&);                      \
   template hipError_t launch_convert_in<T>(hipStream_t, const double*, T*, int64_t, int64_t, int64_t);      \
   template hipError_t launch_convert_out<T>(hipStream_t, const T*, double*, int64_t, int64_t, int64_t);
 

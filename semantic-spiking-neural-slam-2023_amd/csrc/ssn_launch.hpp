@@ -196,6 +196,10 @@ struct BatchOp {
   long long step0;       // = block_start
 };
 
+constexpr int MAX_BATCH_OPS = 6;
+template <typename T> struct BatchOpList { BatchOp<T> op[MAX_BATCH_OPS]; int count; };
+template <typename T> hipError_t launch_batch_elementwise(hipStream_t, const BatchOpList<T>&);   // independent element-wise ops, one launch
+
 template <typename T> hipError_t launch_ensarray(hipStream_t, const EnsArgs<T>&);
 template <typename T> hipError_t launch_ensarray_batch(hipStream_t, const EnsBatch<T>&, int count);   // equal din / dout / variant
 template <typename T> hipError_t launch_dec_pack(hipStream_t, const T* src, T* dst, int K, int dout, int n, int n_pad, int DP, int unpack);

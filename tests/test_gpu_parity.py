@@ -297,7 +297,7 @@ def test_slam_optin_plans_equal_default(Simulator):
     sm = _small_slam(weights_every=None)
     model = build(sm.model)
     outs = []
-    for flags in (0, 32 | 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072):
+    for flags in (0, 32 | 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144):
         with Simulator(None, model=model, dtype="f64", flags=flags) as sim:
             sim.run_steps(120)
             outs.append(sim.data[sm.probe])
@@ -451,6 +451,12 @@ def test_fused_recurrent_core_equals_generic_path(Simulator):
         v_buf = next(o for o in model.ops if o["kind"] == "ensarray")["v"]
         got_v = sim.read_buffer(v_buf)
         np.testing.assert_allclose(got_v, np.asarray(ref.buf[v_buf]).reshape(got_v.shape), atol=1e-9, rtol=0)
+        batched_stage_out = sim.data[pm.probe]
+    # one launch per element-wise operator of the time-batched stages vs independent neighbours sharing a launch
+    with Simulator(None, model=model, dtype="f64", block_steps=96, flags=262144) as sim:
+        sim.run_steps(150)
+        sim.run_steps(150)
+        np.testing.assert_array_equal(sim.data[pm.probe], batched_stage_out)
 
 
 def test_block_kernel_cluster_mode(Simulator):
@@ -528,6 +534,30 @@ def test_pathint_3d_matches_oracle(Simulator):
     with Simulator(None, model=model, dtype="f32") as sim:
         sim.run_steps(250)
         assert H.cosine_error(sim.data[pm.probe][20:], ref.probe_data(0)[20:]).max() < 1e-3
+
+
+def test_slam_3d_matches_oracle(Simulator):
+    """BASELINE config 5's shape at test size: SLAMNetwork over a three-dimensional domain, 20 landmarks.  The
+    clean-up table is the reference's hard-coded 100 points per axis (slam.py:209) = 10^6 rows here, so the clean-up
+    product and its argmax run over a million candidates every timestep."""
+    import sspslam_amd.frontend as fe
+    space = H.make_ssp_space(3, ssp_dim=33, rng=np.random.default_rng(3))
+    path, vels = H.make_random_path(10.0, limit=0.1, seed=0, domain_dim=3)
+    sm = H.make_slam_model(space, path, vels, n_landmarks=20, pi_n_neurons=100, mem_n_neurons=200,
+                           circonv_n_neurons=50, view_rad=0.6, weights_sample_every=0.02)
+    model = build(sm.model)
+    assert [o["rows"] for o in model.ops if o["kind"] == "cleanup"] == [100 ** 3] and space.domain_dim == 3
+    ref = OracleSimulator(model)
+    ref.run_steps(60)
+    mem = sm.slam.assomemory.memory
+    with Simulator(None, model=model, dtype="f64") as sim:
+        sim.run_steps(60)
+        np.testing.assert_allclose(sim.data[sm.probe], ref.probe_data(0), atol=1e-9, rtol=0)
+        np.testing.assert_allclose(sim.data[sm.weights_probe], ref.probe_data(1), atol=1e-12, rtol=1e-9)
+    with Simulator(None, model=model, dtype="f32") as sim:
+        sim.run_steps(60)
+        ce = H.cosine_error(sim.data[sm.probe][20:], ref.probe_data(0)[20:])
+        assert ce.max() < 1e-3, ce.max()
 
 
 def test_long_run_pipelines_input_tabulation(Simulator):
