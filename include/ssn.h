@@ -70,6 +70,10 @@ typedef struct ssn_buffer_desc {
  *  PES      i0 W buf i1 rows i2 cols i3 err i4 act          f0 kappa          W += kappa*outer(err,act)
  *  VOJA     i0 E buf i1 rows i2 cols i3 spk i4 key i5 learn i6 scale buf  f0 lr*dt
  *  CLEANUP  i0 dst  i1 src   i2 rows i3 cols i4 table buf                     dst = T[argmax(T@src)]
+ *           optional factor tables of a sample grid (i5 != 0; buffer ids + 1): i5 dft buf (2K x cols: Re / Im rows of the
+ *           half spectrum), i6 lhs buf (i8 x 2K), i7 rhs buf (i9 x 2K), i8 * i9 = rows, i10 = 2K, (Re, Im) interleaved, with
+ *           T[a * i9 + r] . x = sum_k Re(conj(X_k) lhs[a, k] rhs[r, k]) - the f32 core then forms the similarities of a
+ *           large table (>= 64 MB) as one MFMA product instead of a pass over the table (reference slam.py:209-215)
  *  GATE     i0 dst  i1 src   i2 d                           f0 thres f1 rate  (reference slam.py:233-237)
  * level: scheduling round from the host builder; vector ops of equal level touch disjoint data. */
 typedef struct ssn_op_desc {
@@ -126,6 +130,7 @@ typedef struct ssn_model_desc {
                                               (k_ens_block): step it once per timestep (k_ensarray) instead,
                                          256 = generic plan: fork the independent branches of a timestep over several
                                               streams inside the step graph (data-hazard analysis in the planner),
+                                         524288 = clean-up similarities always from the pass over the table (no factored grid),
                                          262144 = one launch per element-wise operator of the time-batched stages (no batching),
                                          131072 = the head program of a timestep is kept whole (its long first level is otherwise run
                                               grid-wide by k_vecops, giving up the tail / head fusion),

@@ -322,7 +322,17 @@ class Builder:
             elif native[0] == "cleanup":
                 table = np.ascontiguousarray(native[1], dtype=float)
                 b = self.model.add_buffer(table, f"cleanup_table_{len(self.model.buffers)}")
-                self.op("cleanup", dst=rout, src=rin, rows=table.shape[0], cols=table.shape[1], w=b)
+                extra = {}
+                gf = native[2] if len(native) > 2 else None
+                if gf is not None and gf["lhs"].shape[0] * gf["rhs"].shape[0] == table.shape[0]:
+                    # factor tables of the sample grid (sspspace.grid_factors): the device may form the
+                    # similarities as a small matrix product instead of a pass over the whole table
+                    extra = {"g_" + nm: self.model.add_buffer(np.ascontiguousarray(gf[nm], dtype=float),
+                                                              f"cleanup_{nm}_{len(self.model.buffers)}")
+                             for nm in ("dft", "lhs", "rhs")}
+                    extra.update(grid_rows=int(gf["lhs"].shape[0]), grid_cols=int(gf["rhs"].shape[0]),
+                                 grid_k2=int(gf["lhs"].shape[1]))
+                self.op("cleanup", dst=rout, src=rin, rows=table.shape[0], cols=table.shape[1], w=b, **extra)
             elif native[0] == "gate":
                 _, d, thres, rate = native
                 self.op("gate", dst=rout, src=rin, d=int(d), thres=float(thres), rate=float(rate))
@@ -857,7 +867,8 @@ def op_access(o, model):
     if k == "voja":
         return [], [], [S(o["spk"], o["rows"]), S(o["key"], o["cols"]), S(o["learn"], 1), B(o["scale_buf"])], [B(o["w"])]
     if k == "cleanup":
-        return [S(o["dst"], o["cols"])], [], [S(o["src"], o["cols"]), B(o["w"])], []
+        return [S(o["dst"], o["cols"])], [], [S(o["src"], o["cols"]), B(o["w"])] + \
+            [B(o[nm]) for nm in ("g_dft", "g_lhs", "g_rhs") if nm in o], []
     if k == "gate":
         return [S(o["dst"], o["d"])], [], [S(o["src"], 2 * o["d"] + 1)], []
     raise fe.BuildError(f"unknown op kind {k}")

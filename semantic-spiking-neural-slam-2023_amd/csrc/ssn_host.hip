@@ -71,7 +71,7 @@ struct Buf {
   int64_t ldt = 0;
 };
 
-enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_NEURONS_COMPACT, IT_DFT, IT_SPMV_ROWS, IT_VECOPS };
+enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_NEURONS_COMPACT, IT_DFT, IT_SPMV_ROWS, IT_VECOPS, IT_GRID_LHS, IT_GRID_GEMM };
 
 }  // namespace
 
@@ -438,6 +438,14 @@ struct Sim final : ssn_sim {
           break;
         case SSN_OP_CLEANUP:
           CHK(shape((int)o.i[4], o.i[2], o.i[3], true, false));
+          if (o.i[5] > 0) {       // factor tables of the sample grid: dft (2K x d), lhs (n_a x 2K), rhs (N x 2K), n_a * N = rows
+            if (o.i[8] <= 0 || o.i[9] <= 0 || o.i[10] <= 0 || (o.i[10] & 1) || o.i[8] * o.i[9] != o.i[2])
+              return fail(SSN_EINVAL, "cleanup grid factors %lld x %lld (2K = %lld) do not match the %lld-row table",
+                          (long long)o.i[8], (long long)o.i[9], (long long)o.i[10], (long long)o.i[2]);
+            CHK(shape((int)o.i[5] - 1, o.i[10], o.i[3], true, false));
+            CHK(shape((int)o.i[6] - 1, o.i[8], o.i[10], true, false));
+            CHK(shape((int)o.i[7] - 1, o.i[9], o.i[10], true, false));
+          }
           CHK(check_range(o.i[0], o.i[3], "cleanup dst"));
           CHK(check_range(o.i[1], o.i[3], "cleanup src"));
           break;
@@ -1140,6 +1148,27 @@ struct Sim final : ssn_sim {
           scratch_bufs.push_back(scratch);
           Item it; it.type = IT_MATVEC; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.dst = scratch;
           it.rows = (int)o.i[2]; it.cols = (int)o.i[3]; it.ld = (int)w.ld; it.set = 1;
+          const char* gmin = getenv("SSN_GRID_MIN_MB");
+          const int64_t grid_min_bytes = (gmin ? atoll(gmin) : 64) << 20;
+          if (sizeof(T) == 4 && o.i[5] > 0 && !(flags & 524288) && o.i[2] * o.i[3] * (int64_t)sizeof(T) >= grid_min_bytes) {
+            // big sample grid (10^6 points in 3-D): similarities from the grid's factor tables - half spectrum of x
+            // (k_matvec with the DFT rows), left operand (k_grid_lhs), one MFMA product - instead of streaming the
+            // table; the table itself is only read for the winning row
+            const Buf& fd = bufs[o.i[5] - 1]; const Buf& fl = bufs[o.i[6] - 1]; const Buf& fr = bufs[o.i[7] - 1];
+            const int na = (int)o.i[8], nn = (int)o.i[9], k2 = (int)o.i[10];
+            T* X = nullptr; T* A = nullptr;
+            CHK(dmalloc(&X, k2 * (int64_t)sizeof(T)));
+            scratch_bufs.push_back(X);
+            CHK(dmalloc(&A, (int64_t)na * k2 * (int64_t)sizeof(T)));
+            scratch_bufs.push_back(A);
+            Item sx; sx.type = IT_MATVEC; sx.Wm = (T*)fd.d; sx.src = sig + o.i[1]; sx.dst = X;
+            sx.rows = k2; sx.cols = (int)o.i[3]; sx.ld = (int)fd.ld; sx.set = 1;
+            items.push_back(sx);
+            Item sl; sl.type = IT_GRID_LHS; sl.src = X; sl.aux0 = (const T*)fl.d; sl.ld = (int)fl.ld; sl.dst = A;
+            sl.rows = na; sl.cols = k2;
+            items.push_back(sl);
+            it.type = IT_GRID_GEMM; it.src = A; it.Wm = (T*)fr.d; it.ld = (int)fr.ld; it.rows = na; it.n = nn; it.cols = k2;
+          }
           if (sizeof(T) == 8) {
             // parity mode: ordered accumulation over a transposed copy (ties are decided by rounding)
             const int ldt = ((int)o.i[2] + VW - 1) / VW * VW;
@@ -1377,6 +1406,12 @@ struct Sim final : ssn_sim {
           sg(a, it.src - sig, it.cols, false); pt(a, it.Wm, false); pt(a, it.list, false); pt(a, it.count, false);
           sg(a, it.out - sig, it.rows, true);
           break;
+        case IT_GRID_LHS:
+          pt(a, it.src, false); pt(a, it.aux0, false); pt(a, it.dst, true);
+          break;
+        case IT_GRID_GEMM:
+          pt(a, it.src, false); pt(a, it.Wm, false); pt(a, it.dst, true);
+          break;
         case IT_SPMV:
           sg(a, it.src - sig, it.cols, false); pt(a, it.Wm, false); pt(a, it.list, false); pt(a, it.count, false); pt(a, it.dst, true);
           if (it.out) sg(a, it.out - sig, it.rows, true);
@@ -1494,6 +1529,8 @@ struct Sim final : ssn_sim {
         return ssn::launch_dft<T>(stream, b, it.batch);
       }
       case IT_SPMV_ROWS: return ssn::launch_spmv_rows<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.list, it.count, it.out, it.set);
+      case IT_GRID_LHS: return ssn::launch_grid_lhs<T>(stream, it.src, it.aux0, it.ld, it.dst, it.cols, it.rows, it.cols / 2);
+      case IT_GRID_GEMM: return ssn::launch_gemm_nt<T>(stream, it.src, it.cols, it.Wm, it.ld, it.dst, it.n, it.rows, it.n, it.cols);
       case IT_SPMV: {
         ssn::SpmvBatch<T> b{};
         for (int q = 0; q < it.batch; ++q)

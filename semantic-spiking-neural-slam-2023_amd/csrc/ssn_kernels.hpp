@@ -1419,6 +1419,86 @@ __global__ __launch_bounds__(256) void kb_gemm_mfma_f32(BatchOp<float> o) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Clean-up over a large sample grid without the pass over the table (sspspace.grid_factors): the similarity of
+// x to grid point j = a * N + r is  sum_k Re(w_k conj(X_k) E1[a, k] . Erest[r, k]),  X = half spectrum of x.
+// k_grid_lhs forms the (n_a x 2K) left operand from X and the axis-1 factors; k_gemm_nt_mfma_f32 multiplies it
+// with the (N x 2K) factors of the remaining axes on the matrix cores: C[m][n] = sum_k A[m][k] W[n][k].
+// Same tiling as kb_gemm_mfma_f32 (64 x 64 per workgroup, K slabs of 32 through LDS, register prefetch).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_grid_lhs(const T* __restrict__ X, const T* __restrict__ E, int lde,
+                                                  T* __restrict__ A, int lda, int na, int K) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= na * K) return;
+  const int a = i / K, k = i - a * K;
+  const T xr = X[2 * k], xi = X[2 * k + 1];
+  const T er = E[(size_t)a * lde + 2 * k], ei = E[(size_t)a * lde + 2 * k + 1];
+  A[(size_t)a * lda + 2 * k] = xr * er + xi * ei;              //  Re(conj(X) E)
+  A[(size_t)a * lda + 2 * k + 1] = xi * er - xr * ei;          // -Im(conj(X) E)
+}
+
+template <typename T>
+hipError_t launch_grid_lhs(hipStream_t s, const T* X, const T* E, int lde, T* A, int lda, int na, int K) {
+  hipLaunchKernelGGL((k_grid_lhs<T>), dim3((unsigned)((na * K + 255) / 256)), dim3(256), 0, s, X, E, lde, A, lda, na, K);
+  return hipGetLastError();
+}
+
+template <int BK>
+__global__ __launch_bounds__(256) void k_gemm_nt_mfma_f32(const float* __restrict__ A, int lda, const float* __restrict__ Wm, int ldw,
+                                                          float* __restrict__ C, int ldc, int M, int N, int K) {
+  __shared__ float As[64][BK + 1];
+  __shared__ float Ws[64][BK + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int t0 = blockIdx.y * 64, r0 = blockIdx.x * 64;
+  const int lr = tid >> 5, lc = tid & 31;
+  float ra[8], rw[8];
+  auto fetch = [&](int k0) {
+    const int c = k0 + lc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = t0 + lr + 8 * i, r = r0 + lr + 8 * i;
+      ra[i] = (t < M && c < K) ? A[(size_t)t * lda + c] : 0.0f;
+      rw[i] = (r < N && c < K) ? Wm[(size_t)r * ldw + c] : 0.0f;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { As[lr + 8 * i][lc] = ra[i]; Ws[lr + 8 * i][lc] = rw[i]; }
+    __syncthreads();
+    if (k0 + BK < K) fetch(k0 + BK);
+    const float* ap = &As[wm * 32 + (lane & 31)][lane >> 5];
+    const float* wp = &Ws[wn * 32 + (lane & 31)][lane >> 5];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], wp[kk], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  const int r = r0 + wn * 32 + (lane & 31);
+  if (r < N) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int t = t0 + wm * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+      if (t < M) C[(size_t)t * ldc + r] = acc[v];
+    }
+  }
+}
+
+template <typename T>
+hipError_t launch_gemm_nt(hipStream_t s, const T* A, int lda, const T* Wm, int ldw, T* C, int ldc, int M, int N, int K) {
+  if constexpr (sizeof(T) == 4) {
+    hipLaunchKernelGGL((k_gemm_nt_mfma_f32<32>), dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0, s,
+                       A, lda, Wm, ldw, C, ldc, M, N, K);
+    return hipGetLastError();
+  } else {
+    return hipErrorInvalidValue;      // f64 is the parity mode: it keeps the ordered pass over the table
+  }
+}
+
 template <typename T>
 hipError_t launch_batch_op(hipStream_t s, const BatchOp<T>& o) {
   if (o.B <= 0 || o.len <= 0) return hipSuccess;
@@ -1499,6 +1579,8 @@ namespace ssn {
   template hipError_t launch_pes<T>(hipStream_t, T*, const T*, const T*, int, int, int, T);                 \
   template hipError_t launch_voja<T>(hipStream_t, T*, const T*, const T*, const T*, const T*, int, int, int, T); \
   template hipError_t launch_batch_op<T>(hipStream_t, const BatchOp<T>&);                                   \
+  template hipError_t launch_grid_lhs<T>(hipStream_t, const T*, const T*, int, T*, int, int, int);          \
+  template hipError_t launch_gemm_nt<T>(hipStream_t, const T*, int, const T*, int, T*, int, int, int, int); \
   template hipError_t launch_batch_elementwise<T>(hipStream_t, const BatchOpList<T>&);                      \
   template hipError_t launch_convert_in<T>(hipStream_t, const double*, T*, int64_t, int64_t, int64_t);      \
   template hipError_t launch_convert_out<T>(hipStream_t, const T*, double*, int64_t, int64_t, int64_t);

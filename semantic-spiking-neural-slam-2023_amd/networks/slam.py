@@ -70,6 +70,7 @@ class SLAMNetwork(nengo.Network):
         ovc_encoders = ssp_space.encode(ovc_pts)
         self.sample_ssps, self.sample_points = ssp_space.get_sample_pts_and_ssps(100)
         self.clean_up_fun = make_cleanup(self.sample_ssps)
+        self.grid_factors = ssp_space.grid_factors(100) if hasattr(ssp_space, "grid_factors") else None
         unitary = _unitary_fn(ssp_space)
 
         with self:
@@ -100,12 +101,12 @@ class SLAMNetwork(nengo.Network):
             cleanup = self.clean_up_fun
             if gc_n_neurons <= 0:
                 self.gridcells = nengo.Node(lambda t, x: cleanup(x), size_in=d, size_out=d)
-                self.gridcells.native = ("cleanup", self.sample_ssps)
+                self.gridcells.native = ("cleanup", self.sample_ssps, self.grid_factors)
                 nengo.Connection(self.pathintegrator.output, self.gridcells, synapse=tau)
                 nengo.Connection(self.gridcells, self.landmark_ssp_ens.input_a, synapse=None)
             else:
                 self.cleanup = nengo.Node(lambda t, x: cleanup(x), size_in=d, size_out=d)
-                self.cleanup.native = ("cleanup", self.sample_ssps)
+                self.cleanup.native = ("cleanup", self.sample_ssps, self.grid_factors)
                 self.gridcells = nengo.Ensemble(gc_n_neurons, d,
                                                 encoders=ssp_space.sample_grid_encoders(gc_n_neurons),
                                                 intercepts=nengo.CosineSimilarity(d + 2))

@@ -30,6 +30,7 @@ class SLAMViewNetwork(nengo.Network):
         intercept = (landmark_sps @ landmark_sps.T - np.eye(n_landmarks)).max()      # no 0.5 cap here (slam_view.py:200)
         self.sample_ssps, self.sample_points = ssp_space.get_sample_pts_and_ssps(100)
         self.clean_up_fun = make_cleanup(self.sample_ssps)
+        self.grid_factors = ssp_space.grid_factors(100) if hasattr(ssp_space, "grid_factors") else None
         cleanup = self.clean_up_fun
 
         with self:
@@ -55,12 +56,12 @@ class SLAMViewNetwork(nengo.Network):
 
             if gc_n_neurons <= 0:
                 self.gridcells = nengo.Node(lambda t, x: cleanup(x), size_in=d, size_out=d)
-                self.gridcells.native = ("cleanup", self.sample_ssps)
+                self.gridcells.native = ("cleanup", self.sample_ssps, self.grid_factors)
                 nengo.Connection(self.pathintegrator.output, self.gridcells, synapse=tau)
                 nengo.Connection(self.gridcells, self.assomemory.value_input, synapse=None)
             else:
                 self.cleanup = nengo.Node(lambda t, x: cleanup(x), size_in=d, size_out=d)
-                self.cleanup.native = ("cleanup", self.sample_ssps)
+                self.cleanup.native = ("cleanup", self.sample_ssps, self.grid_factors)
                 self.gridcells = nengo.Ensemble(gc_n_neurons, d, encoders=ssp_space.sample_grid_encoders(gc_n_neurons),
                                                 intercepts=nengo.CosineSimilarity(d + 2))
                 nengo.Connection(self.pathintegrator.output, self.cleanup, synapse=tau)

@@ -101,6 +101,8 @@ def pack_model(model, dtype, device=0, steps_per_graph=0, block_steps=0, flags=0
             ff[0] = o["lr_dt"]
         elif k == "cleanup":
             ii[:5] = [o["dst"], o["src"], o["rows"], o["cols"], o["w"]]
+            if "g_dft" in o:      # factor tables of the sample grid (buffer ids + 1; 0 = table only)
+                ii[5:11] = [o["g_dft"] + 1, o["g_lhs"] + 1, o["g_rhs"] + 1, o["grid_rows"], o["grid_cols"], o["grid_k2"]]
         elif k == "gate":
             ii[:3] = [o["dst"], o["src"], o["d"]]
             ff[:2] = [o["thres"], o["rate"]]

@@ -16,6 +16,9 @@ Same class / method names and argument meaning as the reference so harness code 
 Everything here is float64 NumPy: it runs once per model build, never inside the step loop.
 Golden vectors captured from the reference (tests/golden/make_golden.py) pin this file.
 """
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 __all__ = ["SPSpace", "SSPSpace", "HexagonalSSPSpace", "RandomSSPSpace", "conjsym"]
@@ -137,7 +140,21 @@ class SSPSpace:
 
     def encode(self, x):
         """(num_samples, domain_dim) -> (num_samples, ssp_dim) unit-norm SSPs."""
-        return np.fft.ifft(self.encode_fourier(x), axis=1).real
+        x = np.atleast_2d(np.asarray(x, dtype=float))
+        rows = max(1, (1 << 22) // self.ssp_dim)
+        if x.shape[0] <= 4 * rows:
+            return np.fft.ifft(self.encode_fourier(x), axis=1).real
+        # big sample grids (10^6 points in 3-D, slam.py:209): same rows, encoded a slab at a time so the
+        # complex spectrum never exists for the whole grid at once
+        # (slabs on a few host threads: NumPy's exp and FFT release the GIL)
+        out = np.empty((x.shape[0], self.ssp_dim))
+
+        def slab(lo):
+            out[lo:lo + rows] = np.fft.ifft(self.encode_fourier(x[lo:lo + rows]), axis=1).real
+
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+            list(pool.map(slab, range(0, x.shape[0], rows)))
+        return out
 
     def update_lengthscale(self, scale):
         scale = np.asarray(scale, dtype=float)
@@ -169,6 +186,45 @@ class SSPSpace:
             pts = self.get_sample_points(samples_per_dim=num_points_per_dim, method=method)
             self._grid_cache = {key: (self.encode(pts), pts)}
         return self._grid_cache[key]
+
+    def grid_factors(self, num_points_per_dim=100):
+        """Factorisation of the similarities between a vector and every SSP of the sample grid
+        (``get_sample_pts_and_ssps(n, 'grid')``), for the clean-up of large grids (``slam.py:209-215``).
+
+        A grid SSP is ``ifft(prod_m exp(i A[:, m] x_m / l_m))``, so with ``X = fft(x)`` and K = (d + 1) / 2 bins
+
+            <S_j, x> = sum_k Re( w_k conj(X_k) E1[a, k] . Erest[r, k] ),      j = a * n_rest + r,
+
+        where ``a`` indexes axis 1 and ``r`` the remaining axes in C order (``np.meshgrid``'s 'xy' order flattened),
+        w_0 = 1/d, w_k = 2/d.  Returns ``dict(dft=(2K, d), lhs=(n, 2K), rhs=(n_rest, 2K))`` of real arrays with
+        (Re, Im) interleaved along the last axis - the similarities become one (n x 2K) . (2K x n_rest) product
+        instead of a pass over the n^dim x d table - or None when the space does not factor this way."""
+        d, dim, n = self.ssp_dim, self.domain_dim, int(num_points_per_dim)
+        if dim < 2 or d % 2 == 0 or self.domain_bounds is None:
+            return None
+        A = np.asarray(self.phase_matrix, dtype=float)
+        K = (d + 1) // 2
+        if A.shape != (d, dim) or not np.allclose(A[1:], -A[1:][::-1]) or np.any(A[0] != 0):
+            return None
+        b = self.domain_bounds
+        axes = [np.linspace(b[i, 0], b[i, 1], n) / self.length_scale[i, 0] for i in range(dim)]
+        E = [np.exp(1j * np.outer(axes[m], A[:K, m])) for m in range(dim)]          # (n, K) per axis
+        w = np.full(K, 2.0 / d)
+        w[0] = 1.0 / d
+        rest = [m for m in range(dim) if m != 1]
+        Er = E[rest[0]]
+        for m in rest[1:]:
+            Er = (Er[:, None, :] * E[m][None, :, :]).reshape(-1, K)
+
+        def interleave(z):
+            out = np.empty(z.shape[:-1] + (2 * z.shape[-1],))
+            out[..., 0::2], out[..., 1::2] = z.real, z.imag
+            return out
+
+        W = np.exp(-2j * np.pi * np.outer(np.arange(K), np.arange(d)) / d)           # X_k = sum_c x_c W[k, c]
+        dft = np.empty((2 * K, d))
+        dft[0::2], dft[1::2] = W.real, W.imag
+        return {"dft": dft, "lhs": interleave(E[1] * w[None, :]), "rhs": interleave(Er)}
 
     # -- decoding --------------------------------------------------------------------------
     def decode(self, ssp, method="from-set", sampling_method="grid", num_samples=300,
