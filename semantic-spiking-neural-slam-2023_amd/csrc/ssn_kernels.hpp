@@ -792,9 +792,12 @@ __global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
   // y = W x, one wave per FOUR rows (16 rows per workgroup): the source vector is staged in LDS once per
   // workgroup (XLDS) and each lane keeps four independent 16-byte row loads in flight per trip.  Per row the
   // lane-strided accumulation and the wave reduction are the same sequence as a one-row-per-wave kernel.
+  // XLDS = false: x is longer than the 48 KB stage (dense ensembles of more than 12 288 neurons) - it goes through
+  // the stage a slab at a time; slabs hold a multiple of 64 vectors, so every lane still adds its terms in the same order.
   using vec = typename VecT<T>::type;
   constexpr int W = VecT<T>::W;
   constexpr int RW = 4;
+  constexpr int SLAB = 48 * 1024 / (int)sizeof(T);
   extern __shared__ __align__(16) unsigned char ssn_mv_dyn[];
   T* xs = reinterpret_cast<T*>(ssn_mv_dyn);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -806,12 +809,11 @@ __global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
   }
   nz = __syncthreads_or(nz);
   const int r0 = (blockIdx.x * 4 + wave) * RW;
-  if (r0 >= rows) return;
   if (!nz) {                                   // all-zero input (correction / init paths are zero most of the time)
     if (set && lane < RW && r0 + lane < rows) sig_dst[r0 + lane] = T(0);
     return;
   }
-  const T* __restrict__ x = XLDS ? xs : sig_src;
+  const bool active = r0 < rows;               // (a wave past the last row still takes part in the slab barriers)
   const T* wr[RW];
 #pragma unroll
   for (int q = 0; q < RW; ++q) wr[q] = Wm + (size_t)min(r0 + q, rows - 1) * ld;
@@ -819,16 +821,39 @@ __global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
 #pragma unroll
   for (int q = 0; q < RW; ++q) s[q] = T(0);
   const int n_vec = cols / W;
-  for (int v = lane; v < n_vec; v += 64) {
-    T w[RW][W], xv[W];
+  if (XLDS) {
+    if (!active) return;
+    for (int v = lane; v < n_vec; v += 64) {
+      T w[RW][W], xv[W];
 #pragma unroll
-    for (int q = 0; q < RW; ++q) *(vec*)w[q] = *(const vec*)(wr[q] + (size_t)v * W);
-    *(vec*)xv = *(const vec*)(x + (size_t)v * W);
+      for (int q = 0; q < RW; ++q) *(vec*)w[q] = *(const vec*)(wr[q] + (size_t)v * W);
+      *(vec*)xv = *(const vec*)(xs + (size_t)v * W);
 #pragma unroll
-    for (int q = 0; q < RW; ++q)
+      for (int q = 0; q < RW; ++q)
 #pragma unroll
-      for (int j = 0; j < W; ++j) s[q] += w[q][j] * xv[j];
+        for (int j = 0; j < W; ++j) s[q] += w[q][j] * xv[j];
+    }
+  } else {
+    for (int c0 = 0; c0 < n_vec * W; c0 += SLAB) {
+      const int cn = min(SLAB, n_vec * W - c0);
+      __syncthreads();
+      for (int c = threadIdx.x; c < cn; c += 256) xs[c] = sig_src[c0 + c];
+      __syncthreads();
+      if (active)
+        for (int v = lane; v < cn / W; v += 64) {
+          T w[RW][W], xv[W];
+#pragma unroll
+          for (int q = 0; q < RW; ++q) *(vec*)w[q] = *(const vec*)(wr[q] + c0 + (size_t)v * W);
+          *(vec*)xv = *(const vec*)(xs + (size_t)v * W);
+#pragma unroll
+          for (int q = 0; q < RW; ++q)
+#pragma unroll
+            for (int j = 0; j < W; ++j) s[q] += w[q][j] * xv[j];
+        }
+    }
+    if (!active) return;
   }
+  const T* __restrict__ x = XLDS ? xs : sig_src;
   for (int c = n_vec * W + lane; c < cols; c += 64)
 #pragma unroll
     for (int q = 0; q < RW; ++q) s[q] += wr[q][c] * x[c];
@@ -846,7 +871,7 @@ hipError_t launch_matvec(hipStream_t s, const MatvecBatch<T>& b, int count) {
   const size_t xb = (size_t)cols * sizeof(T);
   const dim3 grid((rows + 15) / 16, count), block(256);
   if (xb <= 48 * 1024) hipLaunchKernelGGL((k_matvec<T, true>), grid, block, xb, s, b);
-  else hipLaunchKernelGGL((k_matvec<T, false>), grid, block, 0, s, b);
+  else hipLaunchKernelGGL((k_matvec<T, false>), grid, block, 48 * 1024, s, b);
   return hipGetLastError();
 }
 

@@ -114,6 +114,35 @@ def test_neuron_types_and_dense_ensembles(Simulator):
             np.testing.assert_allclose(sim.data[ps], ref.probe_data(1), atol=1e-9)
 
 
+def test_dense_product_over_a_long_activity_vector(Simulator):
+    """A learned (PES) decoder product over 13 000 activities: the source vector is longer than k_matvec's 48 KB LDS
+    stage (12 288 f32 / 6 144 f64), so it goes through the stage in slabs - same result as the oracle, and the
+    two-row product leaves three of the workgroup's four waves without rows (they still join the slab barriers)."""
+    with nengo.Network(seed=1) as m:
+        u = nengo.Node(lambda t: [np.sin(6 * t), np.cos(6 * t)])
+        pre = nengo.Ensemble(13000, 2)
+        post = nengo.Node(size_in=2)
+        err = nengo.Node(size_in=2)
+        nengo.Connection(u, pre, synapse=None)
+        c = nengo.Connection(pre, post, function=lambda x: [0.0, 0.0], learning_rule_type=nengo.PES(2e-4), synapse=0.005)
+        nengo.Connection(post, err, synapse=None)
+        nengo.Connection(u, err, transform=-1, synapse=None)
+        nengo.Connection(err, c.learning_rule, synapse=None)
+        p = nengo.Probe(post, synapse=0.01)
+    model = build(m)
+    assert any(o["kind"] == "matvec" and o["cols"] == 13000 for o in model.ops)
+    ref = OracleSimulator(model)
+    ref.run_steps(150)
+    want = ref.probe_data(0)
+    assert np.abs(want).max() > 0.3                                   # the rule has learned to follow the input
+    with Simulator(None, model=model, dtype="f64") as sim:
+        sim.run_steps(150)
+        np.testing.assert_allclose(sim.data[p], want, atol=1e-9, rtol=0)
+    with Simulator(None, model=model, dtype="f32") as sim:
+        sim.run_steps(150)
+        np.testing.assert_allclose(sim.data[p], want, atol=2e-3, rtol=0)
+
+
 def test_config2_size_properties(Simulator):
     """BASELINE config 2 size (508 VCOs x 10 000 neurons) with cheap random decoders: the oracle cannot
     keep up at this size, so check size-independent properties - determinism across graph/eager paths,

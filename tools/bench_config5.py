@@ -52,7 +52,7 @@ out = sim.data[sm.probe]
 real = sm.real_ssp[:out.shape[0]]
 sims = np.sum(out * real, axis=1) / np.maximum(np.linalg.norm(out, axis=1), 1e-12)
 table_gb = sm.slam.sample_ssps.size * 4 / 1e9
-print("%.3f sim-s/wall-s (%.1f us/step), launches/step %d, device GB %.1f; clean-up table alone %.2f GB/step = %.0f GB/s; "
+print("%.3f sim-s/wall-s (%.1f us/step), launches/step %d, device GB %.1f; clean-up table %.2f GB (a pass over it every step would need %.0f GB/s); "
       "similarity to the true SSP after 0.2 s: min %.4f mean %.4f" %
       (steps * 1e-3 / el, el / steps * 1e6, c["launches_per_step"], c["device_bytes"] / 1e9, table_gb,
        table_gb / (el / steps), sims[200:].min(), sims[200:].mean()), flush=True)
