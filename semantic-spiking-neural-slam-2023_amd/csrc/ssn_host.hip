@@ -71,7 +71,7 @@ struct Buf {
   int64_t ldt = 0;
 };
 
-enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_NEURONS_COMPACT, IT_DFT, IT_SPMV_ROWS, IT_VECOPS, IT_GRID_LHS, IT_GRID_GEMM };
+enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_NEURONS_COMPACT, IT_DFT, IT_SPMV_ROWS, IT_VECOPS, IT_GRID_LHS, IT_GRID_GEMM, IT_ARGMAX_PART };
 
 }  // namespace
 
@@ -1181,6 +1181,16 @@ struct Sim final : ssn_sim {
           items.push_back(it);
           MOp g{};
           g.kind = ssn::M_ARGMAX_GATHER; g.dst = o.i[0]; g.len = o.i[3]; g.i0 = o.i[2]; g.i1 = w.ld; g.p0 = w.d; g.p1 = scratch;
+          if (o.i[2] >= 65536) {
+            // long similarity vector: first maxima of P slices in their own launch, the program picks among the P candidates
+            const int P = (int)std::min<int64_t>(1024, (o.i[2] + 4095) / 4096);
+            T* part = nullptr;
+            CHK(dmalloc(&part, P * (int64_t)(sizeof(T) + sizeof(int))));
+            scratch_bufs.push_back(part);
+            Item ap; ap.type = IT_ARGMAX_PART; ap.src = scratch; ap.dst = part; ap.rows = (int)o.i[2]; ap.n = P;
+            items.push_back(ap);
+            g.p1 = part; g.src = P;
+          }
           push_micro(g, o.level, true);
           break;
         }
@@ -1412,6 +1422,9 @@ struct Sim final : ssn_sim {
         case IT_GRID_GEMM:
           pt(a, it.src, false); pt(a, it.Wm, false); pt(a, it.dst, true);
           break;
+        case IT_ARGMAX_PART:
+          pt(a, it.src, false); pt(a, it.dst, true);
+          break;
         case IT_SPMV:
           sg(a, it.src - sig, it.cols, false); pt(a, it.Wm, false); pt(a, it.list, false); pt(a, it.count, false); pt(a, it.dst, true);
           if (it.out) sg(a, it.out - sig, it.rows, true);
@@ -1529,6 +1542,7 @@ struct Sim final : ssn_sim {
         return ssn::launch_dft<T>(stream, b, it.batch);
       }
       case IT_SPMV_ROWS: return ssn::launch_spmv_rows<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.list, it.count, it.out, it.set);
+      case IT_ARGMAX_PART: return ssn::launch_argmax_partial<T>(stream, it.src, (long long)it.rows, it.dst, it.n);
       case IT_GRID_LHS: return ssn::launch_grid_lhs<T>(stream, it.src, it.aux0, it.ld, it.dst, it.cols, it.rows, it.cols / 2);
       case IT_GRID_GEMM: return ssn::launch_gemm_nt<T>(stream, it.src, it.cols, it.Wm, it.ld, it.dst, it.n, it.rows, it.n, it.cols);
       case IT_SPMV: {

@@ -625,16 +625,24 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
         break;
       }
       case M_ARGMAX_GATHER: {   // p1 = sims (i0 rows, scratch), p0 = table (i0 x ld=i1), len = cols: dst = table[argmax]
+        // src = P > 0: p1 holds the first maxima of P consecutive slices (k_argmax_partial): P values, then their P row indices
         T best = T(-INFINITY);
         int bi = 0x7fffffff;
         const T* sims = (const T*)op.p1;
-        for (int i0 = tid; i0 < (int)op.i0; i0 += 4096) {       // four reads in flight, examined in ascending order
+        const int n_cand = op.src > 0 ? (int)op.src : (int)op.i0;
+        const int* cand_idx = op.src > 0 ? (const int*)(sims + op.src) : nullptr;
+        for (int i0 = tid; i0 < n_cand; i0 += 4096) {       // four reads in flight, examined in ascending order
           T v[4];
+          int vi[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { const int i = i0 + u * 1024; v[u] = i < (int)op.i0 ? sims[i] : T(-INFINITY); }
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 1024;
+            v[u] = i < n_cand ? sims[i] : T(-INFINITY);
+            vi[u] = (cand_idx && i < n_cand) ? cand_idx[i] : i;
+          }
 #pragma unroll
           for (int u = 0; u < 4; ++u)
-            if (v[u] > best) { best = v[u]; bi = i0 + u * 1024; }     // first maximum within a thread (ascending i)
+            if (v[u] > best) { best = v[u]; bi = vi[u]; }     // first maximum within a thread (ascending i)
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -781,22 +789,24 @@ hipError_t program_set_max_lds(int bytes) {
 // path integrator outside loop closures) the wave skips W entirely - exact, and it saves the
 // whole matrix read.
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool XLDS>
+template <typename T, bool XLDS, int RW>
 __global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
   const MatvecArgs<T> ma = batch.a[blockIdx.y];
   const T* __restrict__ Wm = ma.Wm;
   const T* __restrict__ sig_src = ma.src;
   T* __restrict__ sig_dst = ma.dst;
   const int rows = ma.rows, cols = ma.cols, ld = ma.ld, set = ma.set;
-  if ((int)blockIdx.x * 16 >= rows) return;      // (grid.x is sized for the tallest matrix of the batch)
-  // y = W x, one wave per FOUR rows (16 rows per workgroup): the source vector is staged in LDS once per
-  // workgroup (XLDS) and each lane keeps four independent 16-byte row loads in flight per trip.  Per row the
-  // lane-strided accumulation and the wave reduction are the same sequence as a one-row-per-wave kernel.
+  if ((int)blockIdx.x * 4 * RW >= rows) return;      // (grid.x is sized for the tallest matrix of the batch)
+  // y = W x, one wave per RW rows (4 RW rows per workgroup): the source vector is staged in LDS once per
+  // workgroup and each lane keeps four independent 16-byte row loads in flight per trip - four rows (RW = 4), or
+  // four consecutive vectors of one row (RW = 1: short, wide matrices such as a learned decoder product, which
+  // would otherwise fill a quarter of the CUs).  Per row the lane-strided accumulation and the wave reduction are
+  // the same sequence in every variant.
   // XLDS = false: x is longer than the 48 KB stage (dense ensembles of more than 12 288 neurons) - it goes through
-  // the stage a slab at a time; slabs hold a multiple of 64 vectors, so every lane still adds its terms in the same order.
+  // the stage a slab at a time; slabs hold a multiple of 256 vectors, so every lane still adds its terms in the same order.
   using vec = typename VecT<T>::type;
   constexpr int W = VecT<T>::W;
-  constexpr int RW = 4;
+  constexpr int CU = 4 / RW;                     // vectors of one row in flight per lane
   constexpr int SLAB = 48 * 1024 / (int)sizeof(T);
   extern __shared__ __align__(16) unsigned char ssn_mv_dyn[];
   T* xs = reinterpret_cast<T*>(ssn_mv_dyn);
@@ -821,35 +831,36 @@ __global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
 #pragma unroll
   for (int q = 0; q < RW; ++q) s[q] = T(0);
   const int n_vec = cols / W;
+  auto accumulate = [&](int c0, int nv) {      // columns [c0, c0 + nv W) of the rows against xs[0, nv W)
+    for (int v = lane; v < nv; v += 64 * CU) {
+      T w[RW][CU][W], xv[CU][W];
+#pragma unroll
+      for (int u = 0; u < CU; ++u)
+        if (v + 64 * u < nv) {
+#pragma unroll
+          for (int q = 0; q < RW; ++q) *(vec*)w[q][u] = *(const vec*)(wr[q] + c0 + (size_t)(v + 64 * u) * W);
+          *(vec*)xv[u] = *(const vec*)(xs + (size_t)(v + 64 * u) * W);
+        }
+#pragma unroll
+      for (int u = 0; u < CU; ++u)
+        if (v + 64 * u < nv) {
+#pragma unroll
+          for (int q = 0; q < RW; ++q)
+#pragma unroll
+            for (int j = 0; j < W; ++j) s[q] += w[q][u][j] * xv[u][j];
+        }
+    }
+  };
   if (XLDS) {
     if (!active) return;
-    for (int v = lane; v < n_vec; v += 64) {
-      T w[RW][W], xv[W];
-#pragma unroll
-      for (int q = 0; q < RW; ++q) *(vec*)w[q] = *(const vec*)(wr[q] + (size_t)v * W);
-      *(vec*)xv = *(const vec*)(xs + (size_t)v * W);
-#pragma unroll
-      for (int q = 0; q < RW; ++q)
-#pragma unroll
-        for (int j = 0; j < W; ++j) s[q] += w[q][j] * xv[j];
-    }
+    accumulate(0, n_vec);
   } else {
     for (int c0 = 0; c0 < n_vec * W; c0 += SLAB) {
       const int cn = min(SLAB, n_vec * W - c0);
       __syncthreads();
       for (int c = threadIdx.x; c < cn; c += 256) xs[c] = sig_src[c0 + c];
       __syncthreads();
-      if (active)
-        for (int v = lane; v < cn / W; v += 64) {
-          T w[RW][W], xv[W];
-#pragma unroll
-          for (int q = 0; q < RW; ++q) *(vec*)w[q] = *(const vec*)(wr[q] + c0 + (size_t)v * W);
-          *(vec*)xv = *(const vec*)(xs + (size_t)v * W);
-#pragma unroll
-          for (int q = 0; q < RW; ++q)
-#pragma unroll
-            for (int j = 0; j < W; ++j) s[q] += w[q][j] * xv[j];
-        }
+      if (active) accumulate(c0, cn / W);
     }
     if (!active) return;
   }
@@ -869,9 +880,16 @@ hipError_t launch_matvec(hipStream_t s, const MatvecBatch<T>& b, int count) {
   int rows = 0, cols = 0;
   for (int i = 0; i < count; ++i) { rows = std::max(rows, b.a[i].rows); cols = std::max(cols, b.a[i].cols); }
   const size_t xb = (size_t)cols * sizeof(T);
-  const dim3 grid((rows + 15) / 16, count), block(256);
-  if (xb <= 48 * 1024) hipLaunchKernelGGL((k_matvec<T, true>), grid, block, xb, s, b);
-  else hipLaunchKernelGGL((k_matvec<T, false>), grid, block, 48 * 1024, s, b);
+  const dim3 block(256);
+  if (rows <= 4096) {        // four rows per wave would leave most CUs without a workgroup
+    const dim3 grid((rows + 3) / 4, count);
+    if (xb <= 48 * 1024) hipLaunchKernelGGL((k_matvec<T, true, 1>), grid, block, xb, s, b);
+    else hipLaunchKernelGGL((k_matvec<T, false, 1>), grid, block, 48 * 1024, s, b);
+  } else {
+    const dim3 grid((rows + 15) / 16, count);
+    if (xb <= 48 * 1024) hipLaunchKernelGGL((k_matvec<T, true, 4>), grid, block, xb, s, b);
+    else hipLaunchKernelGGL((k_matvec<T, false, 4>), grid, block, 48 * 1024, s, b);
+  }
   return hipGetLastError();
 }
 
@@ -1444,6 +1462,49 @@ __global__ __launch_bounds__(256) void kb_gemm_mfma_f32(BatchOp<float> o) {
   }
 }
 
+// k_argmax_partial: first maximum (lowest index on ties) of each of P consecutive slices of a long similarity
+// vector; the program's argmax then only looks at the P candidates (a single workgroup scanning 10^6 similarities
+// costs ~100 us).  Output: P values followed by P int row indices.
+template <typename T>
+__global__ __launch_bounds__(256) void k_argmax_partial(const T* __restrict__ sims, long long n, T* __restrict__ out, int P) {
+  __shared__ T sred[4];
+  __shared__ int sidx[4];
+  const long long per = (n + P - 1) / P;
+  const long long lo = (long long)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  const int tid = threadIdx.x;
+  T best = T(-INFINITY);
+  int bi = 0x7fffffff;
+  for (long long i0 = lo + tid; i0 < hi; i0 += 1024) {
+    T v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const long long i = i0 + u * 256; v[u] = i < hi ? sims[i] : T(-INFINITY); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (v[u] > best) { best = v[u]; bi = (int)(i0 + u * 256); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const T ov = __shfl_down(best, off, 64);
+    const int oi = __shfl_down(bi, off, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if ((tid & 63) == 0) { sred[tid >> 6] = best; sidx[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    best = sred[0]; bi = sidx[0];
+    for (int w = 1; w < 4; ++w)
+      if (sred[w] > best || (sred[w] == best && sidx[w] < bi)) { best = sred[w]; bi = sidx[w]; }
+    out[blockIdx.x] = best;
+    reinterpret_cast<int*>(out + P)[blockIdx.x] = bi == 0x7fffffff ? (int)lo : bi;
+  }
+}
+
+template <typename T>
+hipError_t launch_argmax_partial(hipStream_t s, const T* sims, long long n, T* out, int P) {
+  hipLaunchKernelGGL((k_argmax_partial<T>), dim3((unsigned)P), dim3(256), 0, s, sims, n, out, P);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Clean-up over a large sample grid without the pass over the table (sspspace.grid_factors): the similarity of
 // x to grid point j = a * N + r is  sum_k Re(w_k conj(X_k) E1[a, k] . Erest[r, k]),  X = half spectrum of x.
@@ -1605,6 +1666,7 @@ namespace ssn {
   template hipError_t launch_voja<T>(hipStream_t, T*, const T*, const T*, const T*, const T*, int, int, int, T); \
   template hipError_t launch_batch_op<T>(hipStream_t, const BatchOp<T>&);                                   \
   template hipError_t launch_grid_lhs<T>(hipStream_t, const T*, const T*, int, T*, int, int, int);          \
+  template hipError_t launch_argmax_partial<T>(hipStream_t, const T*, long long, T*, int);                  \
   template hipError_t launch_gemm_nt<T>(hipStream_t, const T*, int, const T*, int, T*, int, int, int, int); \
   template hipError_t launch_batch_elementwise<T>(hipStream_t, const BatchOpList<T>&);                      \
   template hipError_t launch_convert_in<T>(hipStream_t, const double*, T*, int64_t, int64_t, int64_t);      \
