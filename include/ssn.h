@@ -130,6 +130,8 @@ typedef struct ssn_model_desc {
                                               (k_ens_block): step it once per timestep (k_ensarray) instead,
                                          256 = generic plan: fork the independent branches of a timestep over several
                                               streams inside the step graph (data-hazard analysis in the planner),
+                                         1048576 = programs stay where the operator order put them (no sinking of a program
+                                              into the next one past operators that do not depend on it),
                                          524288 = clean-up similarities always from the pass over the table (no factored grid),
                                          262144 = one launch per element-wise operator of the time-batched stages (no batching),
                                          131072 = the head program of a timestep is kept whole (its long first level is otherwise run

@@ -1237,6 +1237,34 @@ struct Sim final : ssn_sim {
       dom_units = (int64_t)a.K * a.n;
       dom_bytes = (double)dom_units * (a.din + a.dout + 5) * sizeof(T);
     }
+    // Sink programs: a program none of the operators up to the next program depends on (e.g. the clean-up's
+    // argmax + row gather, whose result is first used after the path integrator's ensembles; the chunk reductions
+    // of sparse products whose sums are first used behind the next neuron populations) joins that next program -
+    // same operators, same order among dependent ones, one launch (~8 us inside the step graph) fewer each.
+    if (!fused && !(flags & 1048576)) {
+      for (bool changed = true; changed;) {
+        changed = false;
+        analyse_dependencies(programs, item_prog);
+        int pi = 0;
+        for (size_t i = 0; i < items.size() && !changed; ++i) {
+          if (items[i].type != IT_PROGRAM) continue;
+          const int my_prog = pi++;
+          if (i == 0) continue;                                  // the head starts the timestep
+          size_t j = i + 1;
+          bool free_to_move = true;
+          for (; j < items.size() && items[j].type != IT_PROGRAM; ++j)
+            for (int dep : item_deps[j]) free_to_move = free_to_move && dep != (int)i;
+          if (j >= items.size() || j == i + 1 || !free_to_move) continue;
+          std::vector<MOp>& dst = programs[(size_t)my_prog + 1];
+          if (!dst.empty()) dst[0].barrier = 1;
+          dst.insert(dst.begin(), programs[(size_t)my_prog].begin(), programs[(size_t)my_prog].end());
+          programs.erase(programs.begin() + my_prog);
+          items.erase(items.begin() + (long)i);
+          item_prog.pop_back();
+          changed = true;
+        }
+      }
+    }
     // micro-op storage: programs in order, then a copy of the head behind the tail for the fused launch.
     // Each program gets an LDS staging plan when the signals it touches fit (see stage_program).
     // Long first level of the head program -> its own grid-wide launch (k_vecops).  The head then no longer starts the

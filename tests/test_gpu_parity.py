@@ -326,7 +326,7 @@ def test_slam_optin_plans_equal_default(Simulator):
     sm = _small_slam(weights_every=None)
     model = build(sm.model)
     outs = []
-    for flags in (0, 32 | 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144):
+    for flags in (0, 32 | 64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 1048576):
         with Simulator(None, model=model, dtype="f64", flags=flags) as sim:
             sim.run_steps(120)
             outs.append(sim.data[sm.probe])
@@ -340,6 +340,7 @@ def test_slam_optin_plans_equal_default(Simulator):
     np.testing.assert_array_equal(outs[8], outs[0])            # parallel branches per scheduling round (opt-in) vs the serial step graph
     np.testing.assert_array_equal(outs[9], outs[0])            # a barrier at every level change vs elided barriers
     np.testing.assert_array_equal(outs[10], outs[0])           # head program kept whole vs its long first level run grid-wide
+    np.testing.assert_array_equal(outs[12], outs[0])           # programs left in operator order vs sunk into the next program
 
 
 def test_feedforward_model_runs_fully_batched(Simulator):
