@@ -367,7 +367,8 @@ struct Sim final : ssn_sim {
     if (!(flags & 8))
       for (int i = 0; i < m->n_ops; ++i) {
         const ssn_op_desc& o = m->ops[i];
-        if (o.kind != SSN_OP_MATVEC || o.stage != 1 || is_micro(o) || o.i[3] < 128 || o.i[3] > 15000) continue;
+        if (o.kind != SSN_OP_MATVEC || o.stage != 1 || is_micro(o) || o.i[3] < 128) continue;
+        if (o.i[3] > 15000 && (flags & (32 | 1024))) continue;      // (the in-kernel / single-workgroup spike lists live in LDS)
         for (int j = 0; j < m->n_ops; ++j) {
           const ssn_op_desc& q = m->ops[j];
           if (q.kind == SSN_OP_NEURONS && q.i[5] == SSN_LIF && q.i[1] == o.i[1] && q.i[2] == o.i[3]) sparse_w.insert((int)o.i[4]);
@@ -1143,14 +1144,22 @@ struct Sim final : ssn_sim {
           // similarities S @ x into a scratch vector (k_matvec), then argmax + row gather in the next program
           flush();
           const Buf& w = bufs[o.i[4]];
+          const char* gmin = getenv("SSN_GRID_MIN_MB");
+          const int64_t grid_min_bytes = (gmin ? atoll(gmin) : 64) << 20;
+          const bool grid_route = sizeof(T) == 4 && o.i[5] > 0 && !(flags & 524288) && o.i[2] * o.i[3] * (int64_t)sizeof(T) >= grid_min_bytes;
+          // K-split of the grid product (partial products summed by the argmax's first stage): enough workgroups to hide latency
+          int gsplit = grid_route && o.i[2] >= 65536 ? (int)std::min<int64_t>(4, std::max<int64_t>(1, o.i[10] / 448)) : 1;
+          if (grid_route && o.i[2] >= 65536 && getenv("SSN_GRID_SPLIT")) gsplit = std::max(1, std::min(8, atoi(getenv("SSN_GRID_SPLIT"))));
+          for (int it2 = 0; it2 < 4; ++it2) {            // the split count the launcher's 32-column slabs actually produce
+            const int kper = (((int)o.i[10] + gsplit - 1) / gsplit + 31) / 32 * 32;
+            gsplit = ((int)o.i[10] + kper - 1) / kper;
+          }
           T* scratch = nullptr;
-          CHK(dmalloc(&scratch, o.i[2] * (int64_t)sizeof(T)));
+          CHK(dmalloc(&scratch, o.i[2] * gsplit * (int64_t)sizeof(T)));
           scratch_bufs.push_back(scratch);
           Item it; it.type = IT_MATVEC; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.dst = scratch;
           it.rows = (int)o.i[2]; it.cols = (int)o.i[3]; it.ld = (int)w.ld; it.set = 1;
-          const char* gmin = getenv("SSN_GRID_MIN_MB");
-          const int64_t grid_min_bytes = (gmin ? atoll(gmin) : 64) << 20;
-          if (sizeof(T) == 4 && o.i[5] > 0 && !(flags & 524288) && o.i[2] * o.i[3] * (int64_t)sizeof(T) >= grid_min_bytes) {
+          if (grid_route) {
             // big sample grid (10^6 points in 3-D): similarities from the grid's factor tables - half spectrum of x
             // (k_matvec with the DFT rows), left operand (k_grid_lhs), one MFMA product - instead of streaming the
             // table; the table itself is only read for the winning row
@@ -1168,6 +1177,7 @@ struct Sim final : ssn_sim {
             sl.rows = na; sl.cols = k2;
             items.push_back(sl);
             it.type = IT_GRID_GEMM; it.src = A; it.Wm = (T*)fr.d; it.ld = (int)fr.ld; it.rows = na; it.n = nn; it.cols = k2;
+            it.seg = gsplit;
           }
           if (sizeof(T) == 8) {
             // parity mode: ordered accumulation over a transposed copy (ties are decided by rounding)
@@ -1187,7 +1197,7 @@ struct Sim final : ssn_sim {
             T* part = nullptr;
             CHK(dmalloc(&part, P * (int64_t)(sizeof(T) + sizeof(int))));
             scratch_bufs.push_back(part);
-            Item ap; ap.type = IT_ARGMAX_PART; ap.src = scratch; ap.dst = part; ap.rows = (int)o.i[2]; ap.n = P;
+            Item ap; ap.type = IT_ARGMAX_PART; ap.src = scratch; ap.dst = part; ap.rows = (int)o.i[2]; ap.n = P; ap.seg = gsplit;
             items.push_back(ap);
             g.p1 = part; g.src = P;
           }
@@ -1570,9 +1580,9 @@ struct Sim final : ssn_sim {
         return ssn::launch_dft<T>(stream, b, it.batch);
       }
       case IT_SPMV_ROWS: return ssn::launch_spmv_rows<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.list, it.count, it.out, it.set);
-      case IT_ARGMAX_PART: return ssn::launch_argmax_partial<T>(stream, it.src, (long long)it.rows, it.dst, it.n);
+      case IT_ARGMAX_PART: return ssn::launch_argmax_partial<T>(stream, it.src, (long long)it.rows, it.dst, it.n, std::max(1, it.seg));
       case IT_GRID_LHS: return ssn::launch_grid_lhs<T>(stream, it.src, it.aux0, it.ld, it.dst, it.cols, it.rows, it.cols / 2);
-      case IT_GRID_GEMM: return ssn::launch_gemm_nt<T>(stream, it.src, it.cols, it.Wm, it.ld, it.dst, it.n, it.rows, it.n, it.cols);
+      case IT_GRID_GEMM: return ssn::launch_gemm_nt<T>(stream, it.src, it.cols, it.Wm, it.ld, it.dst, it.n, it.rows, it.n, it.cols, std::max(1, it.seg));
       case IT_SPMV: {
         ssn::SpmvBatch<T> b{};
         for (int q = 0; q < it.batch; ++q)

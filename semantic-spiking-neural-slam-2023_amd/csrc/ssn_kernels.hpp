@@ -789,7 +789,7 @@ hipError_t program_set_max_lds(int bytes) {
 // path integrator outside loop closures) the wave skips W entirely - exact, and it saves the
 // whole matrix read.
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool XLDS, int RW>
+template <typename T, bool XLDS, int RW, int CUV = 8>
 __global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
   const MatvecArgs<T> ma = batch.a[blockIdx.y];
   const T* __restrict__ Wm = ma.Wm;
@@ -798,30 +798,32 @@ __global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
   const int rows = ma.rows, cols = ma.cols, ld = ma.ld, set = ma.set;
   if ((int)blockIdx.x * 4 * RW >= rows) return;      // (grid.x is sized for the tallest matrix of the batch)
   // y = W x, one wave per RW rows (4 RW rows per workgroup): the source vector is staged in LDS once per
-  // workgroup and each lane keeps four independent 16-byte row loads in flight per trip - four rows (RW = 4), or
-  // four consecutive vectors of one row (RW = 1: short, wide matrices such as a learned decoder product, which
-  // would otherwise fill a quarter of the CUs).  Per row the lane-strided accumulation and the wave reduction are
+  // workgroup and each lane keeps independent 16-byte row loads in flight per trip - one of each of four rows (RW = 4),
+  // or CUV consecutive vectors of one row (RW = 1: short, wide matrices such as a learned decoder product, which
+  // would otherwise fill a quarter of the CUs and need the extra loads per lane to cover the memory latency).  Per row the lane-strided accumulation and the wave reduction are
   // the same sequence in every variant.
   // XLDS = false: x is longer than the 48 KB stage (dense ensembles of more than 12 288 neurons) - it goes through
-  // the stage a slab at a time; slabs hold a multiple of 256 vectors, so every lane still adds its terms in the same order.
+  // the stage a slab at a time; slabs hold a multiple of 512 vectors, so every lane still adds its terms in the same order.
   using vec = typename VecT<T>::type;
   constexpr int W = VecT<T>::W;
-  constexpr int CU = 4 / RW;                     // vectors of one row in flight per lane
+  constexpr int CU = RW == 1 ? CUV : 1;            // vectors of one row in flight per lane (RW = 1: few workgroups, more per lane)
   constexpr int SLAB = 48 * 1024 / (int)sizeof(T);
   extern __shared__ __align__(16) unsigned char ssn_mv_dyn[];
   T* xs = reinterpret_cast<T*>(ssn_mv_dyn);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int nz = 0;
-  for (int c = threadIdx.x; c < cols; c += 256) {
-    const T v = sig_src[c];
-    if (XLDS) xs[c] = v;
-    nz |= (v != T(0));
-  }
-  nz = __syncthreads_or(nz);
   const int r0 = (blockIdx.x * 4 + wave) * RW;
-  if (!nz) {                                   // all-zero input (correction / init paths are zero most of the time)
-    if (set && lane < RW && r0 + lane < rows) sig_dst[r0 + lane] = T(0);
-    return;
+  if (XLDS) {
+    int nz = 0;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+      const T v = sig_src[c];
+      xs[c] = v;
+      nz |= (v != T(0));
+    }
+    nz = __syncthreads_or(nz);
+    if (!nz) {                                   // all-zero input (correction / init paths are zero most of the time)
+      if (set && lane < RW && r0 + lane < rows) sig_dst[r0 + lane] = T(0);
+      return;
+    }
   }
   const bool active = r0 < rows;               // (a wave past the last row still takes part in the slab barriers)
   const T* wr[RW];
@@ -858,9 +860,10 @@ __global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
     for (int c0 = 0; c0 < n_vec * W; c0 += SLAB) {
       const int cn = min(SLAB, n_vec * W - c0);
       __syncthreads();
-      for (int c = threadIdx.x; c < cn; c += 256) xs[c] = sig_src[c0 + c];
-      __syncthreads();
-      if (active) accumulate(c0, cn / W);
+      int nz = 0;
+      for (int c = threadIdx.x; c < cn; c += 256) { const T v = sig_src[c0 + c]; xs[c] = v; nz |= (v != T(0)); }
+      nz = __syncthreads_or(nz);
+      if (active && nz) accumulate(c0, cn / W);      // an all-zero slab adds nothing
     }
     if (!active) return;
   }
@@ -883,8 +886,9 @@ hipError_t launch_matvec(hipStream_t s, const MatvecBatch<T>& b, int count) {
   const dim3 block(256);
   if (rows <= 4096) {        // four rows per wave would leave most CUs without a workgroup
     const dim3 grid((rows + 3) / 4, count);
-    if (xb <= 48 * 1024) hipLaunchKernelGGL((k_matvec<T, true, 1>), grid, block, xb, s, b);
-    else hipLaunchKernelGGL((k_matvec<T, false, 1>), grid, block, 48 * 1024, s, b);
+    // (vectors of a row in flight per lane: 4 measured better than 8 with the vector in LDS at 1015 x 1524; 8 for the slab variant)
+    if (xb <= 48 * 1024) hipLaunchKernelGGL((k_matvec<T, true, 1, 4>), grid, block, xb, s, b);
+    else hipLaunchKernelGGL((k_matvec<T, false, 1, 8>), grid, block, 48 * 1024, s, b);
   } else {
     const dim3 grid((rows + 15) / 16, count);
     if (xb <= 48 * 1024) hipLaunchKernelGGL((k_matvec<T, true, 4>), grid, block, xb, s, b);
@@ -1466,7 +1470,7 @@ __global__ __launch_bounds__(256) void kb_gemm_mfma_f32(BatchOp<float> o) {
 // vector; the program's argmax then only looks at the P candidates (a single workgroup scanning 10^6 similarities
 // costs ~100 us).  Output: P values followed by P int row indices.
 template <typename T>
-__global__ __launch_bounds__(256) void k_argmax_partial(const T* __restrict__ sims, long long n, T* __restrict__ out, int P) {
+__global__ __launch_bounds__(256) void k_argmax_partial(const T* __restrict__ sims, long long n, T* __restrict__ out, int P, int nsplit) {
   __shared__ T sred[4];
   __shared__ int sidx[4];
   const long long per = (n + P - 1) / P;
@@ -1477,7 +1481,11 @@ __global__ __launch_bounds__(256) void k_argmax_partial(const T* __restrict__ si
   for (long long i0 = lo + tid; i0 < hi; i0 += 1024) {
     T v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const long long i = i0 + u * 256; v[u] = i < hi ? sims[i] : T(-INFINITY); }
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * 256;
+      v[u] = i < hi ? sims[i] : T(-INFINITY);
+      for (int sp = 1; sp < nsplit; ++sp) v[u] += i < hi ? sims[(size_t)sp * n + i] : T(0);     // K-split partial products, fixed order
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (v[u] > best) { best = v[u]; bi = (int)(i0 + u * 256); }
@@ -1500,8 +1508,8 @@ __global__ __launch_bounds__(256) void k_argmax_partial(const T* __restrict__ si
 }
 
 template <typename T>
-hipError_t launch_argmax_partial(hipStream_t s, const T* sims, long long n, T* out, int P) {
-  hipLaunchKernelGGL((k_argmax_partial<T>), dim3((unsigned)P), dim3(256), 0, s, sims, n, out, P);
+hipError_t launch_argmax_partial(hipStream_t s, const T* sims, long long n, T* out, int P, int nsplit) {
+  hipLaunchKernelGGL((k_argmax_partial<T>), dim3((unsigned)P), dim3(256), 0, s, sims, n, out, P, nsplit);
   return hipGetLastError();
 }
 
@@ -1532,7 +1540,11 @@ hipError_t launch_grid_lhs(hipStream_t s, const T* X, const T* E, int lde, T* A,
 
 template <int BK>
 __global__ __launch_bounds__(256) void k_gemm_nt_mfma_f32(const float* __restrict__ A, int lda, const float* __restrict__ Wm, int ldw,
-                                                          float* __restrict__ C, int ldc, int M, int N, int K) {
+                                                          float* __restrict__ C, int ldc, int M, int N, int Kall, int kper) {
+  // blockIdx.z = K split: columns [z kper, min(Kall, (z + 1) kper)) of both operands, partial product z of C (M x ldc each)
+  const int kz = blockIdx.z * kper;
+  const int K = min(Kall - kz, kper);
+  A += kz; Wm += kz; C += (size_t)blockIdx.z * M * ldc;
   __shared__ float As[64][BK + 1];
   __shared__ float Ws[64][BK + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1575,10 +1587,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt_mfma_f32(const float* __restric
 }
 
 template <typename T>
-hipError_t launch_gemm_nt(hipStream_t s, const T* A, int lda, const T* Wm, int ldw, T* C, int ldc, int M, int N, int K) {
+hipError_t launch_gemm_nt(hipStream_t s, const T* A, int lda, const T* Wm, int ldw, T* C, int ldc, int M, int N, int K, int splits) {
   if constexpr (sizeof(T) == 4) {
-    hipLaunchKernelGGL((k_gemm_nt_mfma_f32<32>), dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0, s,
-                       A, lda, Wm, ldw, C, ldc, M, N, K);
+    const int kper = ((K + splits - 1) / splits + 31) / 32 * 32;
+    hipLaunchKernelGGL((k_gemm_nt_mfma_f32<32>), dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)((K + kper - 1) / kper)),
+                       dim3(256), 0, s, A, lda, Wm, ldw, C, ldc, M, N, K, kper);
     return hipGetLastError();
   } else {
     return hipErrorInvalidValue;      // f64 is the parity mode: it keeps the ordered pass over the table
@@ -1666,8 +1679,8 @@ namespace ssn {
   template hipError_t launch_voja<T>(hipStream_t, T*, const T*, const T*, const T*, const T*, int, int, int, T); \
   template hipError_t launch_batch_op<T>(hipStream_t, const BatchOp<T>&);                                   \
   template hipError_t launch_grid_lhs<T>(hipStream_t, const T*, const T*, int, T*, int, int, int);          \
-  template hipError_t launch_argmax_partial<T>(hipStream_t, const T*, long long, T*, int);                  \
-  template hipError_t launch_gemm_nt<T>(hipStream_t, const T*, int, const T*, int, T*, int, int, int, int); \
+  template hipError_t launch_argmax_partial<T>(hipStream_t, const T*, long long, T*, int, int);             \
+  template hipError_t launch_gemm_nt<T>(hipStream_t, const T*, int, const T*, int, T*, int, int, int, int, int); \
   template hipError_t launch_batch_elementwise<T>(hipStream_t, const BatchOpList<T>&);                      \
   template hipError_t launch_convert_in<T>(hipStream_t, const double*, T*, int64_t, int64_t, int64_t);      \
   template hipError_t launch_convert_out<T>(hipStream_t, const T*, double*, int64_t, int64_t, int64_t);

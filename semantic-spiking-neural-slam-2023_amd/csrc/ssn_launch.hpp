@@ -226,9 +226,9 @@ template <typename T> hipError_t launch_voja(hipStream_t, T* E, const T* spk, co
                                             int rows, int cols, int ld, T lr_dt);
 template <typename T> hipError_t launch_batch_op(hipStream_t, const BatchOp<T>&);
 // clean-up over a factored sample grid: left operand from the half spectrum, then C[M x N] = A[M x K] . W[N x K]^T
-template <typename T> hipError_t launch_argmax_partial(hipStream_t, const T* sims, long long n, T* out, int P);
+template <typename T> hipError_t launch_argmax_partial(hipStream_t, const T* sims, long long n, T* out, int P, int nsplit);
 template <typename T> hipError_t launch_grid_lhs(hipStream_t, const T* X, const T* E, int lde, T* A, int lda, int na, int K);
-template <typename T> hipError_t launch_gemm_nt(hipStream_t, const T* A, int lda, const T* Wm, int ldw, T* C, int ldc, int M, int N, int K);
+template <typename T> hipError_t launch_gemm_nt(hipStream_t, const T* A, int lda, const T* Wm, int ldw, T* C, int ldc, int M, int N, int K, int splits);
 template <typename T> hipError_t launch_convert_in(hipStream_t, const double* src, T* dst, int64_t rows, int64_t cols, int64_t ld);
 template <typename T> hipError_t launch_convert_out(hipStream_t, const T* src, double* dst, int64_t rows, int64_t cols, int64_t ld);
 

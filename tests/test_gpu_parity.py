@@ -114,13 +114,15 @@ def test_neuron_types_and_dense_ensembles(Simulator):
             np.testing.assert_allclose(sim.data[ps], ref.probe_data(1), atol=1e-9)
 
 
-def test_dense_product_over_a_long_activity_vector(Simulator):
-    """A learned (PES) decoder product over 13 000 activities: the source vector is longer than k_matvec's 48 KB LDS
-    stage (12 288 f32 / 6 144 f64), so it goes through the stage in slabs - same result as the oracle, and the
-    two-row product leaves three of the workgroup's four waves without rows (they still join the slab barriers)."""
+@pytest.mark.parametrize("neuron_type,n", [("LIFRate", 13000), ("LIF", 16000)])
+def test_dense_product_over_a_long_activity_vector(Simulator, neuron_type, n):
+    """A learned (PES) decoder product over more activities than k_matvec's 48 KB LDS stage holds (12 288 f32 /
+    6 144 f64).  Rate neurons: dense product, the source vector goes through the stage in slabs, and the two-row
+    product leaves three of the workgroup's four waves without rows (they still join the slab barriers).  Spiking
+    neurons: the spike-sparse product over neuron-major weights with segmented spike lists (no size limit)."""
     with nengo.Network(seed=1) as m:
         u = nengo.Node(lambda t: [np.sin(6 * t), np.cos(6 * t)])
-        pre = nengo.Ensemble(13000, 2)
+        pre = nengo.Ensemble(n, 2, neuron_type=getattr(nengo, neuron_type)())
         post = nengo.Node(size_in=2)
         err = nengo.Node(size_in=2)
         nengo.Connection(u, pre, synapse=None)
@@ -130,7 +132,7 @@ def test_dense_product_over_a_long_activity_vector(Simulator):
         nengo.Connection(err, c.learning_rule, synapse=None)
         p = nengo.Probe(post, synapse=0.01)
     model = build(m)
-    assert any(o["kind"] == "matvec" and o["cols"] == 13000 for o in model.ops)
+    assert any(o["kind"] == "matvec" and o["cols"] == n for o in model.ops)
     ref = OracleSimulator(model)
     ref.run_steps(150)
     want = ref.probe_data(0)
@@ -594,8 +596,12 @@ def test_slam_3d_matches_oracle(Simulator):
     # default for tables >= 64 MB) or from the pass over the table (flag 524288).  Near-ties between neighbouring grid
     # points (cosine 0.99 apart) may resolve differently in f32, so: the same row on nearly all steps, a neighbour otherwise
     launches = []
-    for flags in (0, 524288):
+    for flags, split in ((0, None), (524288, None), (0, "2")):      # last: K-split product, partials summed by the argmax stage
+        os.environ.pop("SSN_GRID_SPLIT", None)
+        if split:
+            os.environ["SSN_GRID_SPLIT"] = split
         with Simulator(None, model=model, dtype="f32", flags=flags) as sim:
+            os.environ.pop("SSN_GRID_SPLIT", None)
             sim.run_steps(60)
             ce = H.cosine_error(sim.data[sm.probe][20:], ref.probe_data(0)[20:])
             assert ce.max() < 1e-3, (flags, ce.max())
