@@ -83,6 +83,29 @@ def test_sample_grid_and_decode(g):
     np.testing.assert_array_equal(s.decode(g["hex2_55_noisy"], "from-set", "grid", 31), g["hex2_55_decoded_31"])
 
 
+@pytest.mark.parametrize("dim,d,n", [(2, 55, 100), (3, 33, 20), (3, 73, 12)])
+def test_grid_factors_reproduce_the_table_product(dim, d, n):
+    """sspspace.grid_factors (the device's clean-up over large grids): with X the half spectrum of x, the (n x 2K) left
+    operand times the (n^(dim-1) x 2K) factors of the other axes equals sample_ssps @ x row for row - the reference's
+    meshgrid order included (slam.py:209-215, sspspace.py:424-466)."""
+    s = HexagonalSSPSpace(dim, ssp_dim=d, domain_bounds=np.tile([-1.0, 1.0], (dim, 1)), length_scale=0.2,
+                          rng=np.random.default_rng(5))
+    table, _ = s.get_sample_pts_and_ssps(n)
+    f = s.grid_factors(n)
+    K2 = d + 1
+    assert f["dft"].shape == (K2, d) and f["lhs"].shape == (n, K2) and f["rhs"].shape == (n ** (dim - 1), K2)
+    for x in np.random.RandomState(0).randn(3, d):
+        X = f["dft"] @ x
+        np.testing.assert_allclose(X[0::2] + 1j * X[1::2], np.fft.fft(x)[:K2 // 2], atol=1e-12)
+        lhs = np.empty_like(f["lhs"])
+        lhs[:, 0::2] = X[0::2] * f["lhs"][:, 0::2] + X[1::2] * f["lhs"][:, 1::2]          #  Re(conj(X) E)
+        lhs[:, 1::2] = X[1::2] * f["lhs"][:, 0::2] - X[0::2] * f["lhs"][:, 1::2]          # -Im(conj(X) E)
+        np.testing.assert_allclose((lhs @ f["rhs"].T).reshape(-1), table @ x, atol=1e-12)
+    # spaces that do not factor this way (1-D domain, no bounds) say so
+    assert HexagonalSSPSpace(1, ssp_dim=13, domain_bounds=np.array([[-1.0, 1.0]])).grid_factors(10) is None
+    assert HexagonalSSPSpace(2, ssp_dim=55, length_scale=0.2).grid_factors(10) is None
+
+
 def test_grid_1015_checksums(g):
     s = HexagonalSSPSpace(2, ssp_dim=1015, domain_bounds=B2, length_scale=0.2)
     ss, _ = s.get_sample_pts_and_ssps(100)
