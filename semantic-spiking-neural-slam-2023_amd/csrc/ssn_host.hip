@@ -354,6 +354,7 @@ struct Sim final : ssn_sim {
     HIPCHK(hipEventCreate(&ev_run0));
     HIPCHK(hipEventCreate(&ev_run1));
     n_sig = m->n_signals;
+    if (n_sig >= (1LL << 31)) return fail(SSN_EINVAL, "%lld signals: the vector operators index with 32 bits", (long long)n_sig);
     sig_init.assign(m->signal_init, m->signal_init + n_sig);
     CHK(dmalloc(&sig, (n_sig + 8) * (int64_t)sizeof(T)));
     bufs.resize(m->n_buffers);

@@ -517,20 +517,21 @@ hipError_t launch_dft(hipStream_t s, const DftBatch& b, int count) {
 // ---------------------------------------------------------------------------------------------
 // for i = tid, tid + 1024, ... < len: store(i, load(i)), four elements per trip with all loads issued first
 template <typename T, int U, typename L, typename S>
-__device__ inline void vecn_loop(int tid, long long len, L load, S store) {
-  for (long long i0 = tid; i0 < len; i0 += U * 1024) {
+__device__ inline void vecn_loop(int tid, int len, L load, S store) {
+  for (int i0 = tid; i0 < len; i0 += U * 1024) {
     T v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const long long i = i0 + u * 1024; if (i < len) v[u] = load(i); }
+    for (int u = 0; u < U; ++u) { const int i = i0 + u * 1024; if (i < len) v[u] = load(i); }
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const long long i = i0 + u * 1024; if (i < len) store(i, v[u]); }
+    for (int u = 0; u < U; ++u) { const int i = i0 + u * 1024; if (i < len) store(i, v[u]); }
   }
 }
-// (long operators - the row hand-offs of a SLAM timestep move 10-20 k elements each - keep 16 loads in flight per thread)
+// (long operators - the row hand-offs of a SLAM timestep move 10-20 k elements each - keep 16 loads in flight per thread;
+//  32-bit element indices against per-operator base pointers: the interpreter is sensitive to its instruction count)
 template <typename T, typename L, typename S>
 __device__ inline void vec4_loop(int tid, long long len, L load, S store) {
-  if (len > 8192) vecn_loop<T, 16>(tid, len, load, store);
-  else vecn_loop<T, 4>(tid, len, load, store);
+  if (len > 8192) vecn_loop<T, 16>(tid, (int)len, load, store);
+  else vecn_loop<T, 4>(tid, (int)len, load, store);
 }
 
 template <typename T>
@@ -563,18 +564,19 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
       // workgroup hides memory latency only through loads in flight (the head program of a SLAM timestep moves
       // ~120 k elements: 48 -> 14 us)
       case M_FILL:
-        for (long long i = tid; i < op.len; i += 1024) sig[op.dst + i] = op.a;
+        { T* const d = sig + op.dst; for (int i = tid; i < (int)op.len; i += 1024) d[i] = op.a; }
         break;
       case M_AXPY_INC:
-        vec4_loop<T>(tid, op.len, [&](long long i) { return sig[op.dst + i] + op.a * sig[op.src + i]; },
-                  [&](long long i, T v) { sig[op.dst + i] = v; });
+        { T* const d = sig + op.dst; const T* const x = sig + op.src;
+          vec4_loop<T>(tid, op.len, [&](int i) { return d[i] + op.a * x[i]; }, [&](int i, T v) { d[i] = v; }); }
         break;
       case M_AXPY_SET:
-        vec4_loop<T>(tid, op.len, [&](long long i) { return op.a * sig[op.src + i]; }, [&](long long i, T v) { sig[op.dst + i] = v; });
+        { T* const d = sig + op.dst; const T* const x = sig + op.src;
+          vec4_loop<T>(tid, op.len, [&](int i) { return op.a * x[i]; }, [&](int i, T v) { d[i] = v; }); }
         break;
       case M_LOWPASS:   // dst = a*dst + b*src, b = (1-a)*gain
-        vec4_loop<T>(tid, op.len, [&](long long i) { return op.a * sig[op.dst + i] + op.b * sig[op.src + i]; },
-                  [&](long long i, T v) { sig[op.dst + i] = v; });
+        { T* const d = sig + op.dst; const T* const x = sig + op.src;
+          vec4_loop<T>(tid, op.len, [&](int i) { return op.a * d[i] + op.b * x[i]; }, [&](int i, T v) { d[i] = v; }); }
         break;
       case M_TABLE: {   // p0 = TableSlot*
         const TableSlot* t = (const TableSlot*)op.p0;
@@ -583,8 +585,9 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
         if (rel >= 0 && rel < t->n_idx) row = t->idx[rel];
         const T* rows = (const T*)t->rows;
         const bool have = row >= 0 && row < t->n_rows;
-        vec4_loop<T>(tid, op.len, [&](long long i) { return have ? rows[(size_t)row * t->width + i] : T(0); },
-                     [&](long long i, T v) { sig[op.dst + i] = v; });
+        const T* const trow = rows + (have ? (size_t)row * t->width : 0);
+        T* const d = sig + op.dst;
+        vec4_loop<T>(tid, op.len, [&](int i) { return have ? trow[i] : T(0); }, [&](int i, T v) { d[i] = v; });
         break;
       }
       case M_MATVEC_INC:
@@ -657,7 +660,8 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
           if (sred[w] > best || (sred[w] == best && sidx[w] < bi)) { best = sred[w]; bi = sidx[w]; }
         if (bi == 0x7fffffff) bi = 0;
         const T* tab = (const T*)op.p0;
-        vec4_loop<T>(tid, op.len, [&](long long i) { return tab[(size_t)bi * op.i1 + i]; }, [&](long long i, T v) { sig[op.dst + i] = v; });
+        { const T* const trow = tab + (size_t)bi * op.i1; T* const d = sig + op.dst;
+          vec4_loop<T>(tid, op.len, [&](int i) { return trow[i]; }, [&](int i, T v) { d[i] = v; }); }
         __syncthreads();
         break;
       }
@@ -668,7 +672,8 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
           const long long slot = s1 / ps->every - 1 - ps->base_slot;
           if (slot >= 0 && slot < ps->capacity) {
             T* out = (T*)ps->data + (size_t)slot * op.len;
-            vec4_loop<T>(tid, op.len, [&](long long i) { return sig[op.src + i]; }, [&](long long i, T v) { out[i] = v; });
+            const T* const x = sig + op.src;
+            vec4_loop<T>(tid, op.len, [&](int i) { return x[i]; }, [&](int i, T v) { out[i] = v; });
           } else if (tid == 0) {
             ctx->probe_overflow = 1;
           }
@@ -677,13 +682,14 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
       }
       case M_ROW_IN: {    // p0 = bsig, i0 = n_sig: sig[dst..] = bsig[row][dst..], row = step - block_start + 1
         const T* row = (const T*)op.p0 + (size_t)(step - ctx->block_start + 1) * op.i0;
-        vec4_loop<T>(tid, op.len, [&](long long i) { return row[op.i1 + i]; },                    // i1 = offset in the signal vector
-                  [&](long long i, T v) { sig[op.dst + i] = v; });
+        { const T* const x = row + op.i1; T* const d = sig + op.dst;                                  // i1 = offset in the signal vector
+          vec4_loop<T>(tid, op.len, [&](int i) { return x[i]; }, [&](int i, T v) { d[i] = v; }); }
         break;
       }
       case M_ROW_OUT: {   // bsig[row][src..] = sig[src..]
         T* row = (T*)op.p0 + (size_t)(step - ctx->block_start + 1) * op.i0;
-        vec4_loop<T>(tid, op.len, [&](long long i) { return sig[op.src + i]; }, [&](long long i, T v) { row[op.i1 + i] = v; });
+        { const T* const x = sig + op.src; T* const d = row + op.i1;
+          vec4_loop<T>(tid, op.len, [&](int i) { return x[i]; }, [&](int i, T v) { d[i] = v; }); }
         break;
       }
       case M_REDUCE_SET:
