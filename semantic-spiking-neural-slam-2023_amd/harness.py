@@ -39,6 +39,32 @@ def make_ssp_space(domain_dim=2, ssp_dim=97, n_scales=0, n_rotates=3, length_sca
     return HexagonalSSPSpace(domain_dim, ssp_dim=ssp_dim, domain_bounds=bounds, length_scale=length_scale, rng=rng)
 
 
+def indexed_rows_node_fn(table, dt, until=None):
+    """The input-node closure of the reference scripts, ``lambda t: table[int((t - dt) / dt)]`` (``run_pathint.py:134``;
+    zeros from ``t >= until`` on, ``:136``), plus a vectorised twin ``fn.table(steps) -> (rows, idx)`` that the HIP
+    simulator's tabulation uses instead of one Python call per timestep (same float64 arithmetic, so the same rows)."""
+    table = np.asarray(table, dtype=float)
+    zero = np.zeros(table.shape[1])
+
+    def fn(t):
+        if until is not None and not t < until:
+            return zero
+        return table[int((t - dt) / dt)]
+
+    def rows_for(steps):
+        t = np.asarray(steps, dtype=np.int64) * dt                    # nengo's t = step * dt in float64
+        k = ((t - dt) / dt).astype(np.int64)                          # int(): truncation
+        live = np.ones(k.shape, dtype=bool) if until is None else t < until
+        if not live.any():
+            return np.zeros((0, table.shape[1])), np.full(k.shape, -1, dtype=np.int32)
+        lo, hi = int(k[live].min()), int(k[live].max())
+        idx = np.where(live, k - lo, -1).astype(np.int32)             # -1 = a row of zeros
+        return table[lo:hi + 1], idx
+
+    fn.table = rows_for
+    return fn
+
+
 class PathIntModel:
     pass
 
@@ -56,9 +82,8 @@ def make_pathint_model(ssp_space, path, vels, pi_n_neurons, tau=0.05, neuron_typ
     if neuron_type is not None:
         model.config[nengo.Ensemble].neuron_type = neuron_type
     with model:
-        vel_input = nengo.Node(lambda t: vels_scaled[int((t - dt) / dt)], label="vel_input")
-        init_state = nengo.Node(lambda t: real_ssp[int((t - dt) / dt)] if t < init_time else np.zeros(d),
-                                label="init_state")
+        vel_input = nengo.Node(indexed_rows_node_fn(vels_scaled, dt), label="vel_input")
+        init_state = nengo.Node(indexed_rows_node_fn(real_ssp, dt, until=init_time), label="init_state")
         out.pathintegrator = PathIntegration(ssp_space, pi_n_neurons, tau, scaling_factor=scale_fac,
                                              stable=True, solver_weights=False)
         nengo.Connection(vel_input, out.pathintegrator.velocity_input, synapse=None)

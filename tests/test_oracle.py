@@ -210,3 +210,27 @@ def test_slamview_model_runs_on_the_oracle_and_io_helpers(tmp_path):
     z = np.load(tmp_path / "slam.npz", allow_pickle=True)
     assert {"timesteps", "slam_sim_out", "slam_sims", "slam_path", "slam_error", "landmark_ssps_est",
             "landmark_loc_est", "obj_locs", "view_rad"} <= set(z.files)
+
+
+def test_vectorised_input_tables_equal_the_per_step_closures():
+    """harness.indexed_rows_node_fn: the `.table(steps)` twin used by the HIP simulator's tabulation returns, step for
+    step, the rows the reference's closure `lambda t: table[int((t - dt) / dt)]` returns (float64 time arithmetic
+    included: int((t - dt) / dt) is not always step - 1)."""
+    from sspslam_amd import harness as H
+    from sspslam_amd.simulator import tabulate
+    dt = 0.001
+    table = np.random.RandomState(0).randn(30001, 3)
+    for until in (None, 0.05):
+        fn = H.indexed_rows_node_fn(table, dt, until=until)
+        steps = np.arange(1, 30001)
+        rows, idx = fn.table(steps)
+        got = np.where(idx[:, None] >= 0, rows[np.maximum(idx, 0)], 0.0) if len(rows) else np.zeros((len(steps), 3))
+        plain = lambda t: fn(t)                                      # no .table attribute: the per-step path
+        rows2, idx2 = tabulate(plain, 3, steps, dt)
+        np.testing.assert_array_equal(got, rows2[idx2])
+        k = np.array([int((t - dt) / dt) for t in (steps * dt).tolist()])
+        assert until is not None or (k != steps - 1).any()           # the quirk is exercised
+        # a later chunk only (what the pipelined tabulation asks for)
+        r3, i3 = fn.table(np.arange(2049, 4097))
+        np.testing.assert_array_equal(np.where(i3[:, None] >= 0, r3[np.maximum(i3, 0)], 0.0) if len(r3) else np.zeros((2048, 3)),
+                                      got[2048:4096])
