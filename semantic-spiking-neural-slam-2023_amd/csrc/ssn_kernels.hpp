@@ -1416,54 +1416,59 @@ __global__ __launch_bounds__(256) void kb_gemm(BatchOp<T> o) {
     }
 }
 
-// f32 GEMM on the matrix cores: v_mfma_f32_32x32x2_f32 takes f32 operands and accumulates an exact f32 FMA
-// chain (MI355X_MICROARCH.md: the f32 MFMA rate equals the packed-FMA vector peak, but needs no register
-// blocking to get there).  64 x 64 output tile per 256-thread workgroup (4 waves x one 32x32 accumulator),
-// K in slabs of 32 through LDS, next slab prefetched into registers while the current one is multiplied.
-// Operand lanes: A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31]; result: col = l & 31,
-// row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5)  (cdna_hip_programming.md, MFMA layouts).
+// f32 GEMMs on the matrix cores: the f32-input MFMAs take f32 operands and accumulate an exact f32 FMA chain
+// (MI355X_MICROARCH.md: their rate equals the packed-FMA vector peak, but needs no register blocking to get there).
+// 64 x 64 output tile per workgroup, K in slabs of 32 through LDS, next slab prefetched into registers while the
+// current one is multiplied.  v_mfma_f32_32x32x2_f32 (k_gemm_nt_mfma_f32): A[i = l & 31][k = l >> 5],
+// B[k = l >> 5][j = l & 31]; result col = l & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5)
+// (cdna_hip_programming.md, MFMA layouts).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Sixteen waves per 64 x 64 tile, one 16 x 16 accumulator each (v_mfma_f32_16x16x4_f32; operands
+// A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; result col = l & 15, row = 4 (l >> 4) + reg): the grids of the
+// time-batched stages are small (384 tiles at 1000 x 1524 on 256 CUs), so a CU holds one or two tiles - with four waves
+// per tile (one 32 x 32 accumulator each, the first version) a SIMD had a single wave and nothing to hide its operand
+// loads behind; four waves per SIMD measured 10 % faster (48 vs 54 us).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int BK>
-__global__ __launch_bounds__(256) void kb_gemm_mfma_f32(BatchOp<float> o) {
-  __shared__ float As[64][BK + 1];
-  __shared__ float Ws[64][BK + 1];
+__global__ __launch_bounds__(1024) void kb_gemm_mfma_f32(BatchOp<float> o) {
+  __shared__ float As[64][BK + 4];          // row stride 36: (36 row + k) mod 64 is distinct for 16 rows x 4 k - conflict-free operand reads
+  __shared__ float Ws[64][BK + 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int rows = (int)o.len, cols = o.cols;
   const int t0 = blockIdx.y * 64, r0 = blockIdx.x * 64;
   const float* __restrict__ A = o.bsig + (size_t)(1 - o.src_prev) * o.n_sig + o.src;
   const float* __restrict__ Wm = (const float*)o.p0;
-  const int rows = (int)o.len, cols = o.cols;
-  const int lr = tid >> 5, lc = tid & 31;          // this thread stages rows lr + 8 i (i = 0..7), column lc of a slab
-  float ra[8], rw[8];
+  constexpr int RS = 1024 / BK, RPT = 64 / RS;      // this thread stages rows lr + RS i, column lc of a slab
+  const int lr = tid / BK, lc = tid % BK;
+  float ra[RPT], rw[RPT];
   auto fetch = [&](int k0) {
     const int c = k0 + lc;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int t = t0 + lr + 8 * i, r = r0 + lr + 8 * i;
+    for (int i = 0; i < RPT; ++i) {
+      const int t = t0 + lr + RS * i, r = r0 + lr + RS * i;
       ra[i] = (t < o.B && c < cols) ? A[(size_t)t * o.n_sig + c] : 0.0f;
       rw[i] = (r < rows && c < cols) ? Wm[(size_t)r * o.ld + c] : 0.0f;
     }
   };
-  f32x16 acc;
-#pragma unroll
-  for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+  f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
   fetch(0);
   for (int k0 = 0; k0 < cols; k0 += BK) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { As[lr + 8 * i][lc] = ra[i]; Ws[lr + 8 * i][lc] = rw[i]; }
+    for (int i = 0; i < RPT; ++i) { As[lr + RS * i][lc] = ra[i]; Ws[lr + RS * i][lc] = rw[i]; }
     __syncthreads();
     if (k0 + BK < cols) fetch(k0 + BK);
-    const float* ap = &As[wm * 32 + (lane & 31)][lane >> 5];
-    const float* wp = &Ws[wn * 32 + (lane & 31)][lane >> 5];
+    const float* ap = &As[wm * 16 + (lane & 15)][lane >> 4];
+    const float* wp = &Ws[wn * 16 + (lane & 15)][lane >> 4];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], wp[kk], acc, 0, 0, 0);
+    for (int kk = 0; kk < BK; kk += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk], wp[kk], acc, 0, 0, 0);
     __syncthreads();
   }
-  const int r = r0 + wn * 32 + (lane & 31);
+  const int r = r0 + wn * 16 + (lane & 15);
   if (r < rows) {
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int t = t0 + wm * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+    for (int v = 0; v < 4; ++v) {
+      const int t = t0 + wm * 16 + 4 * (lane >> 4) + v;
       if (t < o.B) {
         float* d = o.bsig + (size_t)(t + 1) * o.n_sig + o.dst + r;
         if (o.kind == M_MATVEC_SET) *d = acc[v]; else *d += acc[v];
@@ -1524,7 +1529,7 @@ hipError_t launch_argmax_partial(hipStream_t s, const T* sims, long long n, T* o
 // x to grid point j = a * N + r is  sum_k Re(w_k conj(X_k) E1[a, k] . Erest[r, k]),  X = half spectrum of x.
 // k_grid_lhs forms the (n_a x 2K) left operand from X and the axis-1 factors; k_gemm_nt_mfma_f32 multiplies it
 // with the (N x 2K) factors of the remaining axes on the matrix cores: C[m][n] = sum_k A[m][k] W[n][k].
-// Same tiling as kb_gemm_mfma_f32 (64 x 64 per workgroup, K slabs of 32 through LDS, register prefetch).
+// 64 x 64 tile per 256-thread workgroup (4 waves x one 32 x 32 accumulator), K slabs of 32 through LDS, register prefetch.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_grid_lhs(const T* __restrict__ X, const T* __restrict__ E, int lde,
@@ -1617,7 +1622,7 @@ hipError_t launch_batch_op(hipStream_t s, const BatchOp<T>& o) {
     hipLaunchKernelGGL((kb_lowpass<T>), dim3((unsigned)((o.len + 63) / 64)), dim3(64), 0, s, o);
   } else if ((o.kind == M_MATVEC_INC || o.kind == M_MATVEC_SET) && sizeof(T) == 4 && o.cols >= 64 && o.len >= 32 && o.B >= 32) {
     if constexpr (sizeof(T) == 4)
-      hipLaunchKernelGGL((kb_gemm_mfma_f32<32>), dim3((unsigned)((o.len + 63) / 64), (unsigned)((o.B + 63) / 64)), dim3(256), 0, s, o);
+      hipLaunchKernelGGL((kb_gemm_mfma_f32<32>), dim3((unsigned)((o.len + 63) / 64), (unsigned)((o.B + 63) / 64)), dim3(1024), 0, s, o);
   } else if (o.kind == M_MATVEC_INC || o.kind == M_MATVEC_SET) {
     hipLaunchKernelGGL((kb_gemm<T>), dim3((unsigned)((o.len + 31) / 32), (unsigned)((o.B + 31) / 32)), dim3(256), 0, s, o);
   } else {
