@@ -154,3 +154,33 @@ def test_circconv_network_computes_binding():
     got = sim.probe_data(0)[-100:].mean(0)
     want = circconv(a, b)
     assert got @ want / np.linalg.norm(got) / np.linalg.norm(want) > 0.97
+
+
+def test_cleanup_operator_carries_the_grid_factors():
+    """A clean-up node tagged by our networks hands the device the factor tables of its sample grid (three extra
+    buffers on the operator, shapes (2K, d), (n, 2K), (n^(dim-1), 2K)); a node tagged without factors, or whose table is
+    not that grid, gets the table only."""
+    from sspslam_amd import harness as H
+    s = H.make_ssp_space(2, 55)
+    table, _ = s.get_sample_pts_and_ssps(100)
+    gf = s.grid_factors(100)
+
+    def net(native):
+        with nengo.Network(seed=0) as m:
+            u = nengo.Node(lambda t: table[17] * np.cos(t))
+            c = nengo.Node(lambda t, x: table[np.argmax(table @ x)], size_in=55, size_out=55)
+            if native is not None:
+                c.native = native
+            nengo.Connection(u, c, synapse=0.01)
+            nengo.Probe(c)
+        return build(m)
+
+    model = net(("cleanup", table, gf))
+    op = next(o for o in model.ops if o["kind"] == "cleanup")
+    assert (op["grid_rows"], op["grid_cols"], op["grid_k2"]) == (100, 100, 56)
+    assert [model.buffers[op[k]].shape for k in ("g_dft", "g_lhs", "g_rhs")] == [(56, 55), (100, 56), (100, 56)]
+    assert len(op_access(op, model)[2]) == 5                      # reads: source range, table and the three factor buffers
+    for native in (("cleanup", table), ("cleanup", table[:5000], gf)):
+        op = next(o for o in net(native).ops if o["kind"] == "cleanup")
+        assert "g_dft" not in op and op["cols"] == 55
+
