@@ -1194,7 +1194,7 @@ struct Sim final : ssn_sim {
           g.kind = ssn::M_ARGMAX_GATHER; g.dst = o.i[0]; g.len = o.i[3]; g.i0 = o.i[2]; g.i1 = w.ld; g.p0 = w.d; g.p1 = scratch;
           if (o.i[2] >= 65536) {
             // long similarity vector: first maxima of P slices in their own launch, the program picks among the P candidates
-            const int P = (int)std::min<int64_t>(1024, (o.i[2] + 4095) / 4096);
+            const int P = (int)std::min<int64_t>(1024, (o.i[2] + 1023) / 1024);      // ~4 workgroups per CU at 10^6 rows
             T* part = nullptr;
             CHK(dmalloc(&part, P * (int64_t)(sizeof(T) + sizeof(int))));
             scratch_bufs.push_back(part);
