@@ -1286,14 +1286,26 @@ struct Sim final : ssn_sim {
       std::vector<MOp>& head = programs[(size_t)item_prog[0]];
       size_t lv = 0;
       long long elems = 0;
-      bool ew_only = true;
+      // The prefix that moves: element-wise operators up to the first barrier that are INDEPENDENT of each other.  Inside
+      // a program an operator may follow one it depends on without a barrier when both map every element to the same
+      // thread (push_micro); k_vecops maps elements to threads of the whole grid, so such a chain must not move as one.
+      auto reads_src = [](const MOp& m) { return m.kind == ssn::M_AXPY_INC || m.kind == ssn::M_AXPY_SET || m.kind == ssn::M_LOWPASS; };
+      auto overlap = [](long long a, long long al, long long b, long long bl) { return a < b + bl && b < a + al; };
       for (; lv < head.size() && (lv == 0 || !head[lv].barrier); ++lv) {
-        const int kd = head[lv].kind;
-        ew_only = ew_only && (kd == ssn::M_FILL || kd == ssn::M_ROW_IN || kd == ssn::M_TABLE || kd == ssn::M_AXPY_INC ||
-                              kd == ssn::M_AXPY_SET || kd == ssn::M_LOWPASS);
-        elems += head[lv].len;
+        const MOp& q = head[lv];
+        const int kd = q.kind;
+        if (!(kd == ssn::M_FILL || kd == ssn::M_ROW_IN || kd == ssn::M_TABLE || kd == ssn::M_AXPY_INC ||
+              kd == ssn::M_AXPY_SET || kd == ssn::M_LOWPASS)) break;
+        bool hazard = false;
+        for (size_t e = 0; e < lv && !hazard; ++e) {
+          const MOp& pr = head[e];
+          hazard = overlap(q.dst, q.len, pr.dst, pr.len) || (reads_src(pr) && overlap(q.dst, q.len, pr.src, pr.len)) ||
+                   (reads_src(q) && overlap(q.src, q.len, pr.dst, pr.len));
+        }
+        if (hazard) break;
+        elems += q.len;
       }
-      if (ew_only && elems >= 16384 && lv < head.size()) {
+      if (elems >= 16384 && lv > 0 && lv < head.size()) {
         vec_ops.assign(head.begin(), head.begin() + (long)lv);
         head.erase(head.begin(), head.begin() + (long)lv);
         head[0].barrier = 0;

@@ -568,6 +568,35 @@ def test_pathint_3d_matches_oracle(Simulator):
         assert H.cosine_error(sim.data[pm.probe][20:], ref.probe_data(0)[20:]).max() < 1e-3
 
 
+def test_slam_at_ssp_dim_1015_matches_oracle(Simulator):
+    """SLAMNetwork at the benchmark's dimension (BASELINE configs 2 / 3: ssp_dim = 1015 = 29 * 7 * 5) with fewer neurons
+    per population, so that the oracle can follow: the 10^4 x 1015 clean-up table, the 2032-row circular-convolution
+    transforms (k_dft with a radix-29 stage in the f32 core), 508 VCOs, PES and Voja on 1015-column matrices."""
+    space = H.make_ssp_space(2, 1015)
+    path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
+    sm = H.make_slam_model(space, path, vels, n_landmarks=10, pi_n_neurons=100, mem_n_neurons=1200, circonv_n_neurons=20,
+                           view_rad=0.6, weights_sample_every=0.05)
+    with sm.model:
+        p_clean = nengo.Probe(sm.slam.gridcells)
+    model = build(sm.model)
+    assert sorted(o["dft"] for o in model.ops if o["kind"] == "matvec" and o.get("dft")) == [1, 2, 2, 3, 5, 5]
+    ref = OracleSimulator(model)
+    ref.run_steps(100)
+    with Simulator(None, model=model, dtype="f64") as sim:
+        sim.run_steps(100)
+        np.testing.assert_allclose(sim.data[sm.probe], ref.probe_data(0), atol=1e-9, rtol=0)
+        np.testing.assert_allclose(sim.data[sm.weights_probe], ref.probe_data(1), atol=1e-12, rtol=1e-9)
+        np.testing.assert_allclose(sim.data[p_clean], ref.probe_data(2), atol=1e-12, rtol=0)
+    outs = []
+    for flags in (0, 512, 4096 | 1048576):       # FFT kernels | the dense transform matrices | one launch per operator, programs not sunk
+        with Simulator(None, model=model, dtype="f32", flags=flags) as sim:
+            sim.run_steps(100)
+            outs.append(sim.data[sm.probe])
+            ce = H.cosine_error(outs[-1][20:], ref.probe_data(0)[20:])
+            assert ce.max() < 1e-3, (flags, ce.max())
+    np.testing.assert_array_equal(outs[2], outs[0])
+
+
 def test_slam_3d_matches_oracle(Simulator):
     """BASELINE config 5's shape at test size: SLAMNetwork over a three-dimensional domain, 20 landmarks.  The
     clean-up table is the reference's hard-coded 100 points per axis (slam.py:209) = 10^6 rows here, so the clean-up
