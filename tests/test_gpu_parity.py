@@ -38,9 +38,10 @@ def run_pair(Simulator, model, probe, steps, dtype, **kw):
     return got, ref.probe_data(0), counters
 
 
-@pytest.mark.parametrize("ssp_dim,n", [(7, 64), (55, 500), (97, 130), (55, 1030)])
+@pytest.mark.parametrize("ssp_dim,n", [(7, 64), (55, 500), (97, 130), (55, 1030), (1015, 70)])
 def test_pathint_f64_matches_oracle(Simulator, ssp_dim, n):
-    """cfg1 (ssp_dim=55, n=500) and ragged sizes: n not a multiple of the vector width / workgroup chunk."""
+    """cfg1 (ssp_dim=55, n=500), ragged sizes (n not a multiple of the vector width / workgroup chunk) and the
+    benchmark's dimension (ssp_dim=1015: 508 VCOs, 1524 x 1015 read-in / read-out products) with few neurons per VCO."""
     pm = small_pathint(ssp_dim=ssp_dim, n=n, T=10.0, limit=0.2)
     model = build(pm.model)
     got, want, c = run_pair(Simulator, model, pm.probe, 400, "f64")
@@ -49,8 +50,9 @@ def test_pathint_f64_matches_oracle(Simulator, ssp_dim, n):
     assert c["n_steps"] == 400 and c["launches_per_step"] <= 8
 
 
-def test_pathint_f32_within_cosine_bar(Simulator):
-    pm = small_pathint(ssp_dim=55, n=500, T=10.0, limit=0.2)
+@pytest.mark.parametrize("ssp_dim,n", [(55, 500), (1015, 70)])
+def test_pathint_f32_within_cosine_bar(Simulator, ssp_dim, n):
+    pm = small_pathint(ssp_dim=ssp_dim, n=n, T=10.0, limit=0.2)
     model = build(pm.model)
     got, want, _ = run_pair(Simulator, model, pm.probe, 400, "f32")
     ce = H.cosine_error(got[20:], want[20:])
@@ -377,13 +379,14 @@ def test_feedforward_model_runs_fully_batched(Simulator):
             np.testing.assert_allclose(sim.data[p], ref.probe_data(i), atol=2e-5, rtol=0)
 
 
-def test_sharded_runner_on_hip_matches_unsharded(Simulator):
+@pytest.mark.parametrize("ssp_dim,n", [(55, 60), (1015, 70)])
+def test_sharded_runner_on_hip_matches_unsharded(Simulator, ssp_dim, n):
     from sspslam_amd.sharding import ShardedPathIntegration
-    pm = small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2)
+    pm = small_pathint(ssp_dim=ssp_dim, n=n, T=10.0, limit=0.2)
     model = build(pm.model)
     ref = OracleSimulator(model)
     ref.run_steps(300)
-    pm2 = small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2)
+    pm2 = small_pathint(ssp_dim=ssp_dim, n=n, T=10.0, limit=0.2)
     r = ShardedPathIntegration(pm2, 0, 1, dtype="f64", block=128)
     r.prepare(300)
     r.run_steps(300)
