@@ -286,11 +286,11 @@ def test_slamview_f64_matches_oracle(Simulator):
 def test_dft_kernel_matches_the_transform_matrices(Simulator):
     """k_dft (mixed-radix FFT for the circular-convolution transforms, f32 core) against the dense real-DFT
     matrices it replaces (reference binding.py:23-74): in ONE run, the probed output of each transform equals
-    matrix @ probed input.  d = 25 (5*5, repeated radix), 55 (11*5), 217 (31*7); both operand layouts, with and
-    without involution; the inverse transform.  d = 97 (prime) falls back to the matrix."""
+    matrix @ probed input.  d = 25 (5*5, repeated radix), 55 (11*5), 217 (31*7), 1015 (29*7*5, the benchmark's dimension);
+    both operand layouts, with and without involution; the inverse transform.  d = 97 (prime) falls back to the matrix."""
     from sspslam_amd.networks import CircularConvolution
     from sspslam_amd.builder import dft_structure
-    for d, inv_a, inv_b in ((25, False, True), (55, True, False), (217, False, False), (97, False, False)):
+    for d, inv_a, inv_b in ((25, False, True), (55, True, False), (217, False, False), (97, False, False), (1015, True, False)):
         rng = np.random.RandomState(d)
         fa, fb = rng.randn(d) / np.sqrt(d), rng.randn(d) / np.sqrt(d)
         with nengo.Network(seed=1) as m:
