@@ -371,12 +371,30 @@ def test_feedforward_model_runs_fully_batched(Simulator):
         for i, p in enumerate((p1, p2, p3)):
             np.testing.assert_allclose(sim.data[p], ref.probe_data(i), atol=1e-12, rtol=0)
         assert sim.data[p3].shape == (100, 5)
-    # f32: MFMA GEMM and the chunked scan (blocks of >= 256 timesteps) against the same oracle run
+    # f32: the chunked scan (blocks of >= 256 timesteps) against the same oracle run
     ref.run_steps(400)
     with Simulator(None, model=model, dtype="f32", block_steps=512) as sim:
         sim.run_steps(700)
         for i, p in enumerate((p1, p2, p3)):
             np.testing.assert_allclose(sim.data[p], ref.probe_data(i), atol=2e-5, rtol=0)
+    # f32 products large enough for the matrix cores (kb_gemm_mfma_f32: cols >= 64, rows >= 32): ragged tiles - 150 rows
+    # (two full 64-row tiles + 22), 100 columns (three K slabs of 32 + 4), 300-step blocks (four 64-step tiles + 44)
+    T2, T3 = rng.randn(150, 100) / 10, rng.randn(70, 150) / 12
+    with nengo.Network(seed=0) as m2:
+        u = nengo.Node(lambda t: np.sin(np.arange(1, 101) * 3 * t))
+        a = nengo.Node(size_in=150)
+        b = nengo.Node(size_in=70)
+        nengo.Connection(u, a, transform=T2, synapse=0.01)
+        nengo.Connection(a, b, transform=T3, synapse=None)
+        q1, q2 = nengo.Probe(a), nengo.Probe(b, synapse=0.005)
+    model2 = build(m2)
+    ref2 = OracleSimulator(model2)
+    ref2.run_steps(700)
+    with Simulator(None, model=model2, dtype="f32", block_steps=300) as sim:
+        sim.run_steps(700)
+        assert np.abs(ref2.probe_data(1)).max() > 0.05
+        for i, p in enumerate((q1, q2)):
+            np.testing.assert_allclose(sim.data[p], ref2.probe_data(i), atol=3e-6, rtol=0)
 
 
 @pytest.mark.parametrize("ssp_dim,n", [(55, 60), (1015, 70)])
