@@ -147,6 +147,33 @@ def test_dense_product_over_a_long_activity_vector(Simulator, neuron_type, n):
         np.testing.assert_allclose(sim.data[p], want, atol=2e-3, rtol=0)
 
 
+def test_dense_neuron_to_neuron_weights_wider_than_the_lds_stage(Simulator):
+    """A 4200 x 6200 weight matrix between the neurons of two ensembles (rate neurons in front: a dense product): in f64 the
+    6200-element source is wider than k_matvec's LDS stage (6144 doubles) and the matrix is tall enough for four rows per
+    wave - the slab-staged variant of the tall-matrix kernel; f32 takes the one-stage kernel."""
+    W = np.random.RandomState(0).randn(4200, 6200) * 2e-4
+    with nengo.Network(seed=2) as m:
+        u = nengo.Node(lambda t: [np.sin(5 * t), np.cos(3 * t)])
+        a = nengo.Ensemble(6200, 2, neuron_type=nengo.LIFRate())
+        b = nengo.Ensemble(4200, 2)
+        nengo.Connection(u, a, synapse=None)
+        nengo.Connection(a.neurons, b.neurons, transform=W, synapse=0.005)
+        o = nengo.Node(size_in=2)
+        nengo.Connection(b, o, synapse=0.01)
+        p_spikes, p_out = nengo.Probe(b.neurons[:8]), nengo.Probe(o)
+    model = build(m)
+    assert any(x["kind"] == "matvec" and (x["rows"], x["cols"], x["stage"]) == (4200, 6200, 1) for x in model.ops)
+    ref = OracleSimulator(model)
+    ref.run_steps(80)
+    with Simulator(None, model=model, dtype="f64") as sim:
+        sim.run_steps(80)
+        np.testing.assert_array_equal(sim.data[p_spikes], ref.probe_data(0))
+        np.testing.assert_allclose(sim.data[p_out], ref.probe_data(1), atol=1e-9, rtol=0)
+    with Simulator(None, model=model, dtype="f32") as sim:
+        sim.run_steps(80)
+        assert np.abs(sim.data[p_out] - ref.probe_data(1)).max() < 0.02 * np.abs(ref.probe_data(1)).max() + 1e-4
+
+
 def test_config2_size_properties(Simulator):
     """BASELINE config 2 size (508 VCOs x 10 000 neurons) with cheap random decoders: the oracle cannot
     keep up at this size, so check size-independent properties - determinism across graph/eager paths,
