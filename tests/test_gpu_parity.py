@@ -59,6 +59,32 @@ def test_pathint_f32_within_cosine_bar(Simulator, ssp_dim, n):
     assert ce.max() < 1e-3, ce.max()
 
 
+@pytest.mark.parametrize("shape", ["n=50000", "d=4033", "n=12000"])
+def test_pathint_shapes_of_the_large_configurations(Simulator, shape):
+    """Ensembles too large for the whole-block kernel (BASELINE config 4: 50 000 neurons per VCO - the per-timestep
+    k_ensarray over 49 chunks of 1024 neurons; 12 000: just above the block kernel's 10 240) and config 4's dimension
+    d = 4033 (2017 VCOs, n_scales 28 x n_rotates 24) with few neurons: f64 against the oracle, f32 within the cosine bar."""
+    space, n, m_eval = {"n=50000": (H.make_ssp_space(2, 7), 50000, 1500),
+                        "d=4033": (H.make_ssp_space(2, n_scales=28, n_rotates=24), 40, None),
+                        "n=12000": (H.make_ssp_space(2, 55), 12000, 1500)}[shape]
+    assert space.ssp_dim == {"n=50000": 7, "d=4033": 4033, "n=12000": 55}[shape]
+    path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
+    pm = H.make_pathint_model(space, path, vels, n)
+    model = build(pm.model, n_eval_points=m_eval)
+    ref = OracleSimulator(model)
+    ref.run_steps(150)
+    want = ref.probe_data(0)
+    for dtype in ("f64", "f32"):
+        with Simulator(None, model=model, dtype=dtype) as sim:
+            sim.run_steps(150)
+            got = sim.data[pm.probe]
+            assert sim.counters()["launches_per_step"] == (0 if shape == "d=4033" else 1)
+        if dtype == "f64":
+            np.testing.assert_allclose(got, want, atol=1e-9, rtol=0)
+        else:
+            assert H.cosine_error(got[20:], want[20:]).max() < 1e-3
+
+
 def test_steps_per_graph_and_chunked_runs_are_equivalent(Simulator):
     """Graph replay (16 steps), eager remainder, profile mode and step-by-step runs give identical results."""
     pm = small_pathint(ssp_dim=55, n=100, T=10.0, limit=0.2)
