@@ -466,6 +466,54 @@ def test_sharded_runner_on_hip_matches_unsharded(Simulator, ssp_dim, n):
     r.close()
 
 
+SHARD_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import torch.distributed as dist
+from helpers import small_pathint
+from sspslam_amd.sharding import ShardedPathIntegration
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+out = {{}}
+for dtype in ("f64", "f32"):
+    pm = small_pathint(ssp_dim=1015, n=70, T=10.0, limit=0.2)
+    r = ShardedPathIntegration(pm, rank, world, dtype=dtype, block=128)
+    assert r.hi - r.lo == 254
+    r.prepare(300)
+    r.run_steps(300)          # 128 + 128 + 44: ragged last block
+    r.flush()
+    if rank == 0:
+        out[dtype] = r.probe_data()
+    r.close()
+if rank == 0:
+    np.savez({out!r}, **out)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_on_hip_equal_the_unsharded_model(Simulator, tmp_path):
+    """Two ranks (gloo, sharing this GPU: RCCL needs one GPU per rank) each step 254 of the 508 VCOs of a
+    ssp_dim = 1015 path integrator - the 2-GPU shard of BASELINE config 2, whole-block kernel - exchange their
+    decoded oscillator outputs per block, and rank 0 replays the read-out: f64 equal to the oracle's unsharded run."""
+    import subprocess
+    import sys
+    script, out = tmp_path / "worker.py", tmp_path / "probe.npz"
+    script.write_text(SHARD_WORKER.format(root=ROOT, out=str(out)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29672", str(script)],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    got = np.load(out)
+    ref = OracleSimulator(build(small_pathint(ssp_dim=1015, n=70, T=10.0, limit=0.2).model))
+    ref.run_steps(300)
+    want = ref.probe_data(0)
+    np.testing.assert_allclose(got["f64"], want, atol=1e-9, rtol=0)
+    assert H.cosine_error(got["f32"][20:], want[20:]).max() < 1e-3
+
+
 def test_sharded_runner_device_exchange(Simulator):
     """The all-device block exchange (probe -> RCCL all-gather -> read-out table, no host copies) on a
     single-rank RCCL group: same read-out as the oracle."""
