@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSN_ABI_VERSION 2
+#define SSN_ABI_VERSION 3
 
 enum ssn_status {
   SSN_OK = 0,
@@ -162,6 +162,11 @@ typedef struct ssn_counters {
   int64_t dominant_units_per_launch;/* neuron-steps per launch                                    */
   double last_run_ms;               /* device time of the last ssn_run_steps (events)             */
   int64_t device_bytes;             /* device memory held by this simulator                       */
+  /* whole-block kernel (k_ens_block) variant the planner picked; all 0 when the core is stepped per timestep */
+  int32_t block_tpb;                /* workgroup size the variant is compiled for                  */
+  int32_t block_npt;                /* neurons per thread                                         */
+  int32_t block_enc_lds;            /* 1: encoders live in LDS, 0: in registers                   */
+  int32_t block_threads;            /* threads actually launched per workgroup                    */
 } ssn_counters;
 
 typedef struct ssn_sim ssn_sim;

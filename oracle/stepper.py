@@ -114,6 +114,11 @@ class OracleSimulator:
         m, sig, buf, dt = self.model, self.sig, self.buf, self.dt
         self.n_steps += 1
         t = self.n_steps * dt
+        # Probes of learned signals ("weights", "scaled_encoders") read the signal as the step leaves it in nengo, where
+        # `target += delta` is an inc at the START of the next step (Appendix A.7 / A.8): the sample of step t holds the
+        # deltas of steps < t.  The pes / voja operators below add this step's delta at once, so sample first.
+        learned_samples = {i: np.array(buf[self._probe_buffer(p)], dtype=np.float64)
+                           for i, p in enumerate(m.probes) if "src" not in p and self.n_steps % p["every"] == 0}
         for o in m.ops:
             k = o["kind"]
             if k == "fill":
@@ -189,7 +194,10 @@ class OracleSimulator:
             if "src" in p:
                 self.probe_rows[i].append(sig[p["src"]:p["src"] + p["width"]].astype(np.float64))
             else:
-                b = p["buf"]
-                if isinstance(b, tuple):
-                    b = self.model.params[p["ens"]].encoder_buffer
-                self.probe_rows[i].append(np.array(buf[b], dtype=np.float64))
+                self.probe_rows[i].append(learned_samples[i])
+
+    def _probe_buffer(self, p):
+        b = p["buf"]
+        if isinstance(b, tuple):
+            b = self.model.params[p["ens"]].encoder_buffer
+        return b

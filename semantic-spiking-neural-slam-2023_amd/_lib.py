@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSN_HIP_LIB") or os.path.join(_HERE, "libssn_hip.so")     # override: A/B builds of the library
 
-SSN_ABI_VERSION = 2
+SSN_ABI_VERSION = 3
 SSN_F32, SSN_F64 = 0, 1
 SSN_BUF_REAL, SSN_BUF_I32 = 0, 1
 NEURON_CODE = {"lif": 0, "lifrate": 1, "relu": 2}
@@ -48,7 +48,9 @@ class ModelDesc(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("n_steps", C.c_int64), ("launches_per_step", C.c_int64), ("dominant_launches", C.c_int64),
                 ("dominant_ms_total", C.c_double), ("dominant_bytes_per_launch", C.c_double),
-                ("dominant_units_per_launch", C.c_int64), ("last_run_ms", C.c_double), ("device_bytes", C.c_int64)]
+                ("dominant_units_per_launch", C.c_int64), ("last_run_ms", C.c_double), ("device_bytes", C.c_int64),
+                ("block_tpb", C.c_int32), ("block_npt", C.c_int32), ("block_enc_lds", C.c_int32),
+                ("block_threads", C.c_int32)]
 
 
 EXPORTS = {

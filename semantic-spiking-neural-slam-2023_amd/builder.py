@@ -722,8 +722,10 @@ class Builder:
             fake = type("C", (), dict(function=None, solver=fe.LstsqL2(), eval_points=None, size_mid=e.dimensions))()
             full = self.alloc("W", e.dimensions)
             if self._is_local(e):
-                self._request_decoders(fake, e, 0, e.dimensions, 1.0,
-                                       lambda W, e=e, full=full: self._register_rows(e, W, full))
+                def done(W, e=e, full=full, p=p):
+                    self.model.params[p] = BuiltConnection(weights=W, learned_buffer=None)    # identity decoders of the probe
+                    self._register_rows(e, W, full)
+                self._request_decoders(fake, e, 0, e.dimensions, 1.0, done)
         elif k == "neurons":
             e = obj.ensemble
             if id(e) in self.block_of:

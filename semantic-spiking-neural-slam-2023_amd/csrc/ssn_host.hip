@@ -2018,6 +2018,10 @@ struct Sim final : ssn_sim {
     out->dominant_units_per_launch = dom_units;
     out->last_run_ms = last_run_ms;
     out->device_bytes = device_bytes;
+    out->block_tpb = fused_block ? blk.tpb : 0;
+    out->block_npt = fused_block ? blk.npt : 0;
+    out->block_enc_lds = fused_block ? blk.enc_lds : 0;
+    out->block_threads = fused_block ? blk.threads : 0;
     return SSN_OK;
   }
 
@@ -2102,6 +2106,6 @@ int ssn_device_count(void) {
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 const char* ssn_last_error(void) { return g_err.c_str(); }
-const char* ssn_version(void) { return "libssn_hip 0.3 (gfx950, ABI 2)"; }
+const char* ssn_version(void) { return "libssn_hip 0.4 (gfx950, ABI 3)"; }
 
 }  // extern "C"

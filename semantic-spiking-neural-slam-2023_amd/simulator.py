@@ -330,6 +330,13 @@ class Simulator:
         buf_probes = [(k, v[2]) for k, v in self._probe_index.items() if v[0] == "buf"]
         done = 0
         while done < steps:
+            # Probes of learned signals ("weights", "scaled_encoders"): nengo adds a learning rule's delta to its target at
+            # the START of the next timestep (`target += delta` is an inc, the delta an update - SURVEY Appendix A.7 / A.8),
+            # so the sample of timestep t holds the deltas of timesteps < t.  k_pes / k_voja add theirs at once: the buffer
+            # is therefore read BEFORE the timestep whose sample is due.
+            for key, p in buf_probes:
+                if (self.n_steps + 1) % p["every"] == 0:
+                    self._chunks[key].append(self.read_buffer(self._probe_buffer_id(p))[None])
             chunk = steps - done
             worker = None
             if pipelined is not None:
@@ -347,8 +354,9 @@ class Simulator:
                     n_next = min(self.PIPELINE_CHUNK, steps - done - chunk)
                     worker = threading.Thread(target=lambda: box.update(r=self._tabulate_chunk(nxt, n_next)))
                     worker.start()
-            for _, p in buf_probes:
-                chunk = min(chunk, p["every"] - (self.n_steps % p["every"]))
+            for _, p in buf_probes:          # stop before the next timestep whose sample is due (taken at the top of the loop)
+                r = (self.n_steps + 1) % p["every"]
+                chunk = min(chunk, p["every"] - r if r else p["every"])
             self._check(self._lib.ssn_run_steps(self._h, chunk, 1 if profile else 0))
             self.n_steps += chunk
             done += chunk
@@ -359,9 +367,6 @@ class Simulator:
                 pipelined = box["r"]
                 if self.n_steps != pipelined[0]:          # a weight-probe boundary cut the chunk short: re-tabulate from here
                     pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_CHUNK, steps - done))
-            for key, p in buf_probes:
-                if self.n_steps % p["every"] == 0:
-                    self._chunks[key].append(self.read_buffer(self._probe_buffer_id(p))[None])
         self._uncollected = True
         if collect:
             self._collect()

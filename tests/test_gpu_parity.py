@@ -823,3 +823,34 @@ def test_block_kernel_variants_f32(Simulator):
             os.environ.pop("SSN_BLOCK_VARIANT", None)
         ce = H.cosine_error(got[20:], want[20:])
         assert ce.max() < 1e-3, (n, variant, ce.max())
+
+
+@pytest.mark.parametrize("n,steps,variant", [(10000, 400, (512, 20, 1)), (7000, 200, (512, 20, 1)), (10240, 200, (512, 20, 1)),
+                                             (10241, 200, (768, 14, 1)), (10752, 200, (768, 14, 1)), (10753, 200, None)])
+def test_headline_block_variant_matches_oracle(Simulator, n, steps, variant):
+    """The kernel variant behind the headline number, against the ORACLE, on the default plan: VCO ensembles of
+    BASELINE config 2's size (n = 10 000 neurons each; 4 VCOs so that the NumPy oracle follows) must be stepped by
+    k_ens_block<float,3,5,20,512,ENC_LDS> - asserted through the counters - and stay within the 1e-3 cosine bar of
+    the f64 oracle over 400 timesteps.  The other sizes pin the planner's variant boundaries: 10 240 = the capacity of
+    (512, 20), 10 241 .. 10 752 -> (768, 14, LDS), 10 753 -> no block variant fits: per-timestep k_ensarray."""
+    os.environ.pop("SSN_BLOCK_VARIANT", None)
+    pm = small_pathint(ssp_dim=7, n=n, T=10.0, limit=0.2)
+    model = build(pm.model, n_eval_points=1500)
+    ref = OracleSimulator(model)
+    ref.run_steps(steps)
+    want = ref.probe_data(0)
+    with Simulator(None, model=model, dtype="f32") as sim:
+        sim.run_steps(steps)
+        got = sim.data[pm.probe]
+        c = sim.counters()
+    if variant is None:
+        assert c["launches_per_step"] == 1 and c["block_tpb"] == 0
+    else:
+        assert c["launches_per_step"] == 0
+        assert (c["block_tpb"], c["block_npt"], c["block_enc_lds"]) == variant, c
+        assert c["block_threads"] == variant[0]
+    assert got.shape == want.shape
+    ce = H.cosine_error(got[20:], want[20:])
+    assert ce.max() < 1e-3, (n, ce.max())
+    # the decoded oscillators really oscillate (a flat-line output would also have a tiny cosine error to itself only)
+    assert np.abs(want[20:]).max() > 0.05

@@ -1,0 +1,233 @@
+// valu_issue_rate.hip - how many shader cycles does one SIMD of a gfx950 CU need per wave64 VALU instruction,
+// with 1, 2 and 4 resident waves per SIMD?  Settles the peak that the VALU-issue roofline of k_ens_block is
+// priced against: MI355X_MICROARCH.md describes SIMD-32 units with a 2-cycle wave64 issue when a
+// second wave is resident, and a 4-cycle issue for one wave alone.
+//
+// Every wave runs the same unrolled stream of INDEPENDENT instructions (eight accumulators, so that dependent-issue
+// latency never gates) and stamps s_memtime (shader cycles) around it.  One workgroup per CU (LDS-sized so that a
+// second one does not fit); 256 / 512 / 1024 threads = 1 / 2 / 4 waves per SIMD.
+//   build: hipcc -O3 --offload-arch=gfx950 tools/valu_issue_rate.hip -o tools/build/valu_issue_rate
+//   run:   tools/build/valu_issue_rate > profiles/round2_valu_issue_rate.txt
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+enum Kind { FMA = 0, PK_FMA, PK_MUL, PK_ADD, RCP, LOG, MIX, MAX_I32, ADD, CNDMASK, CMP, MED3, MAX_F32, PK_MUL_CLAMP, ADD_DPP, MOV, READLANE, MIX2, N_KINDS };
+static const char* kind_name[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_rcp_f32", "v_log_f32",
+                                  "block-kernel mix (6 pk_fma : 2 pk_mul : 2 pk_add : 1 rcp : 1 log : 4 scalar-f32)", "v_max_i32",
+                                  "v_add_f32", "v_cndmask_b32 (vcc)", "v_cmp_lt_f32 -> sgpr pair", "v_med3_f32", "v_max_f32", "v_pk_mul_f32 clamp",
+                                  "v_add_f32_dpp row_mirror (dependent chain of 8 regs)", "v_mov_b32", "v_readlane_b32",
+                                  "all-packed LIF mix (14 packed : 2 transcendental)"};
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+template <int KIND>
+__global__ __launch_bounds__(1024) void k_stream(float* sink, unsigned long long* cycles, unsigned long long* real, int iters) {
+  extern __shared__ unsigned char pad[];          // only there to keep a second workgroup off the CU
+  float a[8];
+  f32x2 p[8];
+  const float c0 = 1.0000001f, c1 = 1e-9f;
+  const f32x2 q0 = {1.0000001f, 0.9999999f}, q1 = {1e-9f, -1e-9f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = 1.0f + threadIdx.x * 1e-6f + i; p[i] = (f32x2){a[i], a[i] + 0.5f}; }
+  __builtin_amdgcn_s_barrier();
+  unsigned long long t0, r0, t1, r1;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0) :: "memory");
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if constexpr (KIND == FMA) {
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c0), "v"(c1));
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == PK_FMA) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(q0), "v"(q1));
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == PK_MUL) {
+#define X(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(q0));
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == PK_ADD) {
+#define X(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(q1));
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == RCP) {
+#define X(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == LOG) {
+#define X(i) asm volatile("v_log_f32 %0, %0" : "+v"(a[i]));
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == ADD) {
+#define X(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == CNDMASK) {
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c1));
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == CMP) {
+#define X(i) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1" :: "v"(a[i]), "v"(c1) : "s20", "s21");
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == MED3) {
+#define X(i) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c1), "v"(c0));
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == MAX_F32) {
+#define X(i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == PK_MUL_CLAMP) {
+#define X(i) asm volatile("v_pk_mul_f32 %0, %0, %1 clamp" : "+v"(p[i]) : "v"(q0));
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == ADD_DPP) {
+#define X(i) asm volatile("v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == MOV) {
+#define X(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(c1));
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == READLANE) {
+#define X(i) asm volatile("v_readlane_b32 s20, %0, 5" :: "v"(a[i]) : "s20");
+        REP8(X) REP8(X)
+#undef X
+      } else if constexpr (KIND == MIX2) {
+        // the all-packed LIF step in the proportions of 16 pk : 2 transcendental per neuron pair-half
+#define P3(i, j, k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(q0), "v"(q1)); \
+                    asm volatile("v_pk_mul_f32 %0, %0, %1 clamp" : "+v"(p[j]) : "v"(q0)); \
+                    asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[k]) : "v"(q1));
+        P3(0, 1, 2) P3(3, 4, 5)
+        asm volatile("v_rcp_f32 %0, %0" : "+v"(a[0]));
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[6]) : "v"(q0), "v"(q1));
+        P3(7, 0, 1) P3(2, 3, 4)
+        asm volatile("v_log_f32 %0, %0" : "+v"(a[1]));
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[5]) : "v"(q0), "v"(q1));
+#undef P3
+      } else if constexpr (KIND == MAX_I32) {
+#define X(i) asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[i]) : "v"(c1));
+        REP8(X) REP8(X)
+#undef X
+      } else {
+        // 16 instructions in the proportions of the k_ens_block neuron loop
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[0]) : "v"(q0), "v"(q1));
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[1]) : "v"(q0), "v"(q1));
+        asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[2]) : "v"(q0));
+        asm volatile("v_rcp_f32 %0, %0" : "+v"(a[0]));
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[3]) : "v"(q0), "v"(q1));
+        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[4]) : "v"(q1));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[1]) : "v"(c0), "v"(c1));
+        asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[2]) : "v"(c1));
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[5]) : "v"(q0), "v"(q1));
+        asm volatile("v_log_f32 %0, %0" : "+v"(a[3]));
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[6]) : "v"(q0), "v"(q1));
+        asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[7]) : "v"(q0));
+        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[0]) : "v"(q1));
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[1]) : "v"(q0), "v"(q1));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[4]) : "v"(c0), "v"(c1));
+        asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[5]) : "v"(c1));
+      }
+    }
+  }
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += a[i] + p[i].x + p[i].y;
+  if (s == 123.456f) sink[0] = s;                 // keeps the accumulators alive
+  if ((threadIdx.x & 63) == 0) {
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    cycles[w] = t1 - t0;
+    real[w] = r1 - r0;
+  }
+}
+
+__global__ void k_clamp_check(float* io) {
+  if (threadIdx.x < 4) {
+    f32x2 v = {io[2 * threadIdx.x], io[2 * threadIdx.x + 1]};
+    const f32x2 one = {1.0f, 1.0f};
+    asm volatile("v_pk_mul_f32 %0, %0, %1 clamp" : "+v"(v) : "v"(one));
+    io[2 * threadIdx.x] = v.x; io[2 * threadIdx.x + 1] = v.y;
+  }
+}
+
+template <int KIND>
+static void run(int threads, int iters, float* sink, unsigned long long* d_c, unsigned long long* d_r, int n_cu) {
+  const int waves = n_cu * threads / 64;
+  const int per_it = KIND == MIX ? 4 * 16 : 4 * 16;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stream<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k_stream<KIND>), dim3(n_cu), dim3(threads), 96 * 1024, 0, sink, d_c, d_r, iters);      // warm-up
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k_stream<KIND>), dim3(n_cu), dim3(threads), 96 * 1024, 0, sink, d_c, d_r, iters);
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> c(waves), r(waves);
+  hipMemcpy(c.data(), d_c, waves * 8, hipMemcpyDeviceToHost);
+  hipMemcpy(r.data(), d_r, waves * 8, hipMemcpyDeviceToHost);
+  std::sort(c.begin(), c.end());
+  std::sort(r.begin(), r.end());
+  const double n_inst = (double)iters * per_it;
+  const double med = (double)c[waves / 2], medr = (double)r[waves / 2];
+  const int wps = threads / 256;      // waves per SIMD
+  const double mhz = med / medr * 100.0;
+  printf("%-86s waves/SIMD %d  cycles/inst/wave %6.2f  SIMD cycles per wave-instruction %5.2f  clock %4.0f MHz  kernel %.3f ms\n",
+         kind_name[KIND], wps, med / n_inst, med / n_inst / wps, mhz, ms);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
+int main() {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, 0) != hipSuccess) { fprintf(stderr, "no HIP device\n"); return 1; }
+  const int n_cu = prop.multiProcessorCount;
+  printf("# %s, %d CUs; one workgroup per CU; independent instruction streams (8 accumulators)\n", prop.name, n_cu);
+  printf("# 'SIMD cycles per wave-instruction' = what one SIMD spends per wave64 instruction it issues: 4 = SIMD-16-style quad-cycle issue,\n");
+  printf("# 2 = a second resident wave fills the other half of a SIMD-32\n");
+  float* sink; unsigned long long *d_c, *d_r;
+  hipMalloc(&sink, 64);
+  hipMalloc(&d_c, (size_t)n_cu * 16 * 8);
+  hipMalloc(&d_r, (size_t)n_cu * 16 * 8);
+  const int iters = 20000;
+  for (int threads : {256, 512, 768, 1024}) {
+    run<FMA>(threads, iters, sink, d_c, d_r, n_cu);
+    run<PK_FMA>(threads, iters, sink, d_c, d_r, n_cu);
+    run<PK_MUL>(threads, iters, sink, d_c, d_r, n_cu);
+    run<PK_ADD>(threads, iters, sink, d_c, d_r, n_cu);
+    run<MAX_I32>(threads, iters, sink, d_c, d_r, n_cu);
+    run<RCP>(threads, iters, sink, d_c, d_r, n_cu);
+    run<LOG>(threads, iters, sink, d_c, d_r, n_cu);
+    run<MIX>(threads, iters, sink, d_c, d_r, n_cu);
+    run<ADD>(threads, iters, sink, d_c, d_r, n_cu);
+    run<CNDMASK>(threads, iters, sink, d_c, d_r, n_cu);
+    run<CMP>(threads, iters, sink, d_c, d_r, n_cu);
+    run<MED3>(threads, iters, sink, d_c, d_r, n_cu);
+    run<MAX_F32>(threads, iters, sink, d_c, d_r, n_cu);
+    run<PK_MUL_CLAMP>(threads, iters, sink, d_c, d_r, n_cu);
+    run<ADD_DPP>(threads, iters, sink, d_c, d_r, n_cu);
+    run<MOV>(threads, iters, sink, d_c, d_r, n_cu);
+    run<READLANE>(threads, iters, sink, d_c, d_r, n_cu);
+    run<MIX2>(threads, iters, sink, d_c, d_r, n_cu);
+  }
+  // functional check of the VOP3P clamp modifier on packed f32 (used by the branch-free LIF step): clamp to [0, 1], NaN -> 0
+  {
+    float h_in[8] = {-1.5f, 0.25f, 2.0f, __builtin_nanf(""), -0.0f, 1.0f, 1e-30f, 3e38f}, h_out[8];
+    float* d;
+    hipMalloc(&d, 64);
+    hipMemcpy(d, h_in, 32, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_clamp_check, dim3(1), dim3(64), 0, 0, d);
+    hipMemcpy(h_out, d, 32, hipMemcpyDeviceToHost);
+    printf("# v_pk_mul_f32 x, 1.0 clamp:");
+    for (int i = 0; i < 8; ++i) printf("  %g -> %g", h_in[i], h_out[i]);
+    printf("\n");
+  }
+  return 0;
+}
