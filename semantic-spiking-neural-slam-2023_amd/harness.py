@@ -8,7 +8,8 @@ one definition of the benchmark workloads:
 * ``make_pathint_model``    ``run_pathint.py:105-143`` input nodes + PathIntegration + probe
 * ``pathint_metrics``       ``run_pathint.py:168-184`` grid decode, cosine similarity, distance error
 * ``make_slam_model``       ``run_slam.py:95-195``
-* ``map_recall``            ``run_slam.py:263-268``
+* ``map_recall``            ``run_slam.py:263-268``        (definition (i): built encoders)
+* ``map_recall_learned``    ``slam_map_new.py:342-347,447-452``  (definition (ii): Voja-probed encoders)
 """
 import numpy as np
 
@@ -273,3 +274,17 @@ def map_recall(ssp_space, lm_space, built_memory, neuron_type, final_decoders):
     acts = get_activities(built_memory, neuron_type, lm_space.vectors)
     recalled = acts @ np.asarray(final_decoders).T
     return recalled, ssp_space.decode(recalled, "from-set", "grid", 100)
+
+
+def map_recall_learned(ssp_space, lm_space, built_memory, neuron_type, final_scaled_encoders, final_decoders,
+                       num_samples=100):
+    """Definition (ii) of map recall, ``slam_map_new.py:342-347`` / ``:447-452``: the landmark SPs are projected on the
+    FINAL scaled encoders (``Probe(conn_in.learning_rule, "scaled_encoders")[-1]``, i.e. after Voja moved them) and
+    pushed through ``neuron_type.rates(x, gain, bias)``, then through the final PES decoders.
+
+    Reproduced as written, including its quirk: ``scaled_encoders`` already contain
+    ``gain / radius`` and ``rates`` multiplies by ``gain`` once more."""
+    x = np.asarray(lm_space.vectors) @ np.asarray(final_scaled_encoders).T
+    acts = neuron_type.rates(x, built_memory.gain, built_memory.bias)
+    recalled = acts @ np.asarray(final_decoders).T
+    return recalled, ssp_space.decode(recalled, "from-set", "grid", num_samples)

@@ -146,8 +146,9 @@ class ShardedPathIntegration:
             return True
         return self.world > 1 and self.dist.is_initialized() and self.dist.get_backend() == "nccl"
 
-    def _gather_device(self, n):
-        """This rank's last n osc samples (device) -> (n, 3K) device tensor on every rank, one all-gather."""
+    def _stage_send(self, n):
+        """Local half of the device exchange (no collective): this rank's last n oscillator samples, padded to the
+        common shard width, as an (n, 3*per) device tensor."""
         import torch
         tdt = torch.float32 if self.dtype == "f32" else torch.float64
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -156,19 +157,52 @@ class ShardedPathIntegration:
         torch.cuda.current_stream().synchronize()      # the simulator copies on its own stream
         if width:
             have = self.sim.probe_count(self.osc_probe)
+            if have < n:
+                raise nengo.SimulationError(f"rank {self.rank}: {have} oscillator samples on the device, {n} to exchange - "
+                                            "call prepare(total_steps) before run_block on the device-exchange path")
             if width == 3 * self.per:
                 self.sim.read_probe_device(self.osc_probe, send.data_ptr(), have - n, n)
             else:
                 tmp = torch.empty((n, width), dtype=tdt, device=dev)
                 self.sim.read_probe_device(self.osc_probe, tmp.data_ptr(), have - n, n)
                 send[:, :width] = tmp
-        out = torch.empty((self.world, n, 3 * self.per), dtype=tdt, device=dev)
-        if self.dist.is_initialized():
+        return send
+
+    @staticmethod
+    def assemble_gathered(out, K):
+        """(world, n, 3*per) all-gather result -> (n, 3K): rank r's columns follow rank r-1's; the zero padding of the
+        last shard (K not a multiple of the world size) falls off the end."""
+        world, n, w = out.shape
+        return out.permute(1, 0, 2).reshape(n, world * w)[:, :3 * K].contiguous()
+
+    def _gather_device(self, n):
+        """This rank's last n osc samples (device) -> (n, 3K) device tensor on every rank, one all-gather.
+
+        A failure of the local half must not leave this rank outside a collective its peers have entered (they would
+        wait for the RCCL watchdog): every rank first contributes an ok flag to a one-element all-reduce, and either
+        all ranks go on to the all-gather or all ranks raise."""
+        import torch
+        send, err = None, None
+        try:
+            send = self._stage_send(n)
+        except Exception as e:                         # noqa: BLE001 - agreed on collectively below, then re-raised
+            err = e
+        collective = self.world > 1 and self.dist.is_initialized()
+        failed = err is not None
+        if collective:
+            flag = torch.tensor([1.0 if failed else 0.0], device=torch.device("cuda", torch.cuda.current_device()))
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            failed = bool(flag.item() > 0)
+        if failed:
+            raise nengo.SimulationError(f"device-resident block exchange failed on rank {self.rank}" if err is not None else
+                                        "device-resident block exchange failed on another rank") from err
+        out = torch.empty((self.world, n, 3 * self.per), dtype=send.dtype, device=send.device)
+        if collective:
             self.dist.all_gather_into_tensor(out, send)
         else:                                          # no process group (tests): only this rank's slot is filled
             out.zero_()
             out[self.rank] = send
-        full = out.permute(1, 0, 2).reshape(n, self.world * 3 * self.per)[:, :3 * self.K].contiguous()
+        full = self.assemble_gathered(out, self.K)
         torch.cuda.current_stream().synchronize()      # the read-out simulator runs on its own HIP stream
         return full
 
@@ -227,6 +261,10 @@ class ShardedPathIntegration:
     def run_block(self, n=None):
         n = self.block if n is None else int(n)
         if self._device_exchange():
+            if getattr(self.sim, "_prepared_until", 0) < self.sim.n_steps + n:
+                # (an unprepared run_steps would re-reserve the probe storage block by block and drop the samples
+                #  that wait on the device for the next exchange)
+                raise nengo.SimulationError("device-exchange path: call prepare(total_steps) before run_block")
             self.sim.run_steps(n, collect=False)
             self._ungathered += n
             self.n_steps += n
@@ -256,16 +294,7 @@ class ShardedPathIntegration:
             return
         self._ungathered = 0
         first = self.n_steps - n
-        try:
-            full = self._gather_device(n)
-        except Exception as e:                 # (deterministic API errors hit every rank alike: all fall back together)
-            import warnings
-            warnings.warn(f"device-resident block exchange failed ({e!r}); using the host path from here on")
-            self.device_exchange = False
-            self.sim._collect()
-            local = self.sim.probe_tail(self.osc_probe, n) if self.osc_probe is not None else np.zeros((n, 0))
-            self.sim.clear_probe_data()
-            full = self._gather(local) if self.world > 1 else local
+        full = self._gather_device(n)          # raises on every rank alike (see there): no silent change of path mid-run
         if self.readout is None:
             return
         if self.defer_readout > 0:

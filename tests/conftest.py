@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU test")
+    config.addinivalue_line("markers", "needs_nengo: cross-check against the real nengo package (skipped unless it is installed)")
 
 
 @pytest.fixture(scope="session")

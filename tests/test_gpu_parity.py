@@ -545,17 +545,23 @@ def test_sharded_runner_device_exchange(Simulator):
     finally:
         if created:
             dist.destroy_process_group()
-    # a failing device exchange falls back to the host path (and says so)
+    # a failing device exchange raises (no silent switch to another collective while peers may be inside this one)
     pm4 = small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2)
     r = ShardedPathIntegration(pm4, 0, 1, dtype="f64", block=128, device_exchange=True, gather_every=1)
 
     def broken(n):
-        raise RuntimeError("simulated collective failure")
-    r._gather_device = broken
+        raise RuntimeError("simulated failure of the local half")
+    r._stage_send = broken
     r.prepare(300)
-    with pytest.warns(UserWarning, match="host path"):
+    with pytest.raises(nengo.SimulationError, match="block exchange failed on rank 0"):
         r.run_steps(300)
-    np.testing.assert_allclose(r.probe_data(), ref.probe_data(0), atol=1e-9, rtol=0)
+    r._ungathered = 0
+    r.close()
+    # ... and so does stepping without prepare() (the probe storage would be re-reserved block by block)
+    pm5 = small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2)
+    r = ShardedPathIntegration(pm5, 0, 1, dtype="f64", block=128, device_exchange=True)
+    with pytest.raises(nengo.SimulationError, match="prepare"):
+        r.run_block()
     r.close()
     # a last rank with fewer VCOs than the others (28 VCOs over 3 ranks: 10, 10, 8): its samples are padded to the
     # common width before the all-gather; without a process group its slot of the gathered block is checked alone
@@ -570,6 +576,92 @@ def test_sharded_runner_device_exchange(Simulator):
     np.testing.assert_array_equal(full[:, :60], 0.0)                   # the other ranks' slots (nobody filled them)
     np.testing.assert_array_equal(full[:, 60:84], own[:, :24])
     r.close()
+
+
+class _ThreadDist:
+    """torch.distributed stand-in for several ranks living in ONE process (one thread each, sharing the GPU): the
+    collectives meet at a barrier and exchange device tensors directly - the world > 1 code path of the device
+    exchange (padded all_gather_into_tensor, ok-flag all-reduce) without needing one GPU per rank."""
+
+    class ReduceOp:
+        MAX = "max"
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.local = threading.local()
+
+    def is_initialized(self):
+        return True
+
+    def get_backend(self):
+        return "nccl"
+
+    def _meet(self, t):
+        self.slots[self.local.rank] = t
+        self.barrier.wait()
+        got = list(self.slots)
+        self.barrier.wait()
+        return got
+
+    def all_gather_into_tensor(self, out, send):
+        import torch
+        torch.cuda.synchronize()
+        for r, t in enumerate(self._meet(send)):
+            out[r].copy_(t)
+        torch.cuda.synchronize()
+
+    def all_reduce(self, t, op=None):
+        import torch
+        got = self._meet(t.clone())
+        t.copy_(torch.stack(got).max(dim=0).values)
+
+    def all_gather(self, outs, t):
+        for o, g in zip(outs, self._meet(t.clone())):
+            o.copy_(g)
+
+
+def test_device_exchange_with_three_ranks_in_one_process(Simulator):
+    """World size 3 over 28 VCOs (shards of 10, 10 and 8: the last one padded) through the DEVICE exchange path -
+    `_stage_send`, the ok-flag all-reduce, `all_gather_into_tensor`, `assemble_gathered`, gather_every > 1 and the
+    deferred read-out - equal to the unsharded oracle run."""
+    import threading
+    from sspslam_amd.sharding import ShardedPathIntegration
+    ref = OracleSimulator(build(small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2).model))
+    ref.run_steps(320)
+    world = 3
+    fake = _ThreadDist(world)
+    results, errors = {}, []
+    runners = [ShardedPathIntegration(small_pathint(ssp_dim=55, n=60, T=10.0, limit=0.2), rank, world, dtype="f64", block=64,
+                                      device_exchange=True, dist=fake, gather_every=2, defer_readout=2 if rank == 0 else 0)
+               for rank in range(world)]
+    assert [(r.lo, r.hi) for r in runners] == [(0, 10), (10, 20), (20, 28)]
+
+    def work(rank):
+        try:
+            fake.local.rank = rank
+            r = runners[rank]
+            r._warm = True                       # (no communicator to warm up)
+            r.prepare(320)
+            r.run_steps(320)                     # 5 blocks: two exchanges of 2 blocks, flush() gathers the fifth
+            r.flush()
+            if rank == 0:
+                results["out"] = r.probe_data()
+        except BaseException as e:               # noqa: BLE001
+            errors.append((rank, e))
+            fake.barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(rank,)) for rank in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    np.testing.assert_allclose(results["out"], ref.probe_data(0), atol=1e-9, rtol=0)
+    for r in runners:
+        r.close()
 
 
 def test_fused_recurrent_core_equals_generic_path(Simulator):
@@ -854,3 +946,89 @@ def test_headline_block_variant_matches_oracle(Simulator, n, steps, variant):
     assert ce.max() < 1e-3, (n, ce.max())
     # the decoded oscillators really oscillate (a flat-line output would also have a tiny cosine error to itself only)
     assert np.abs(want[20:]).max() > 0.05
+
+
+def test_scaled_encoders_probe_and_map_recall_of_the_learned_encoders(Simulator):
+    """Probe(conn_in.learning_rule, "scaled_encoders") (reference run_slam_map_gif.py:208-209) against the oracle, and
+    map-recall definition (ii) (slam_map_new.py:342-347: landmark SPs through the Voja-moved encoders, double gain
+    as written) from GPU-learned vs oracle-learned state."""
+    import sspslam_amd.frontend as fe
+    sm = _small_slam(weights_every=0.1)
+    am = sm.slam.assomemory
+    with sm.model:
+        p_enc = fe.Probe(am.conn_in.learning_rule, "scaled_encoders", sample_every=0.1)
+    model = build(sm.model)
+    i_enc = [i for i, p in enumerate(model.probes) if p["probe"] is p_enc][0]
+    i_w = [i for i, p in enumerate(model.probes) if p["probe"] is sm.weights_probe][0]
+    ref = OracleSimulator(model)
+    ref.run_steps(500)
+    E_ref, W_ref = ref.probe_data(i_enc), ref.probe_data(i_w)
+    assert E_ref.shape == (5, 300, 55) and np.abs(E_ref[-1] - E_ref[0]).max() > 0.01        # Voja moved the encoders
+    with Simulator(None, model=model, dtype="f64") as sim:
+        sim.run_steps(300)
+        sim.run_steps(200)                                        # a sample boundary inside and between runs
+        E_gpu, W_gpu = sim.data[p_enc], sim.data[sm.weights_probe]
+    assert E_gpu.shape == E_ref.shape
+    np.testing.assert_allclose(E_gpu, E_ref, atol=1e-10, rtol=1e-9)
+    np.testing.assert_allclose(W_gpu, W_ref, atol=1e-12, rtol=1e-9)
+    mem = am.memory
+    rec_g, pos_g = H.map_recall_learned(sm.ssp_space, sm.lm_space, model.params[mem], fe.LIF(), E_gpu[-1], W_gpu[-1])
+    rec_r, pos_r = H.map_recall_learned(sm.ssp_space, sm.lm_space, model.params[mem], fe.LIF(), E_ref[-1], W_ref[-1])
+    np.testing.assert_allclose(rec_g, rec_r, atol=1e-9)
+    np.testing.assert_array_equal(pos_g, pos_r)
+    with Simulator(None, model=model, dtype="f32") as sim:
+        sim.run_steps(500)
+        E32 = sim.data[p_enc]
+    assert np.abs(E32 - E_ref).max() < 2e-3 * np.abs(E_ref).max()
+
+
+def _gridcell_models():
+    """The two grid-cell population options of the reference: PathIntegration(with_gcs=True) (pathintegration.py:150-154)
+    and SLAMNetwork(gc_n_neurons > 0) (slam.py:274-281; encoders from sample_grid_encoders, sspspace.py:733-762)."""
+    import sspslam_amd.frontend as fe
+    from sspslam_amd.networks import PathIntegration, SLAMNetwork, get_slam_input_functions2
+    from sspslam_amd.sspspace import SPSpace
+    from sspslam_amd.utils import Rd_sampling
+    space = H.make_ssp_space(2, 55)
+    path, vels = H.make_random_path(10.0, limit=0.2, seed=1)
+    real_ssp = space.encode(path)
+    scale = 1.0 / np.max(np.abs(space.phase_matrix @ vels.T))
+    with fe.Network(seed=2) as pi_model:
+        vel = fe.Node(H.indexed_rows_node_fn(vels * scale, 0.001))
+        init = fe.Node(H.indexed_rows_node_fn(real_ssp, 0.001, until=0.05))
+        pi = PathIntegration(space, 80, 0.05, scaling_factor=scale, stable=True, with_gcs=True, n_gcs=400)
+        fe.Connection(vel, pi.velocity_input, synapse=None)
+        fe.Connection(init, pi.input, synapse=None)
+        p1 = fe.Probe(pi.output, synapse=0.05)
+        p1s = fe.Probe(pi.output.neurons[:50])
+    lm_space = SPSpace(6, space.ssp_dim, seed=0)
+    obj = 0.9 * 2 * (Rd_sampling(6, 2, seed=0) - 0.5)
+    f = get_slam_input_functions2(space, lm_space, vels, obj[None] - path[:, None], 0.6)
+    with fe.Network(seed=3) as slam_model:
+        nodes = [fe.Node(fn) for fn in (f[0], f[6], f[4], f[2])]
+        init = fe.Node(lambda t: real_ssp[int((t - 0.001) / 0.001)] if t < 0.05 else np.zeros(space.ssp_dim))
+        slam = SLAMNetwork(space, lm_space, 0.6, 6, 60, 150, 30, vel_scaling_factor=f[1], shift_rate=0.2, gc_n_neurons=120,
+                           intercept=0.1, voja_learning_rate=1e-4, pes_learning_rate=5e-3, update_thres=0.2)
+        for n, tgt in zip(nodes, (slam.velocity_input, slam.landmark_vec_ssp, slam.landmark_id_input, slam.no_landmark_in_view)):
+            fe.Connection(n, tgt, synapse=None)
+        fe.Connection(init, slam.pathintegrator.input, synapse=None)
+        p2 = fe.Probe(slam.pathintegrator.output, synapse=0.05)
+        p2g = fe.Probe(slam.gridcells, synapse=0.05)
+    return (pi_model, [p1, p1s]), (slam_model, [p2, p2g])
+
+
+def test_gridcell_populations_match_oracle(Simulator):
+    for net, probes in _gridcell_models():
+        model = build(net)
+        ref = OracleSimulator(model)
+        ref.run_steps(300)
+        idx = {id(p["probe"]): i for i, p in enumerate(model.probes)}
+        with Simulator(None, model=model, dtype="f64") as sim:
+            sim.run_steps(300)
+            for p in probes:
+                want = ref.probe_data(idx[id(p)])
+                assert np.abs(want).max() > 0
+                np.testing.assert_allclose(sim.data[p], want, atol=1e-9, rtol=0)
+        with Simulator(None, model=model, dtype="f32") as sim:
+            sim.run_steps(300)
+            assert H.cosine_error(sim.data[probes[0]][20:], ref.probe_data(idx[id(probes[0])])[20:]).max() < 1e-3

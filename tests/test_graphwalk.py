@@ -92,3 +92,24 @@ def test_weight_probe_samples_exclude_the_delta_of_their_own_step():
     np.testing.assert_allclose(a, b, atol=1e-15, rtol=0)
     np.testing.assert_array_equal(a[0], model.buffers[model.params[c].learned_buffer])
     assert np.abs(a[-1] - a[0]).max() > 0
+
+
+def test_gridcell_population_options_lower_like_the_graph_walk():
+    """with_gcs=True (reference pathintegration.py:150-154: the output is an ensemble with grid-cell encoders) and
+    gc_n_neurons > 0 (slam.py:274-281: clean-up node -> grid-cell ensemble -> binding network through Lowpass(tau))."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("gpu_parity_helpers", os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for net, probes in mod._gridcell_models():
+        model = build(net)
+        assert any(o["kind"] == "neurons" for o in model.ops)
+        ref = OracleSimulator(model)
+        walk = GraphWalkSimulator(net, model)
+        ref.run_steps(250)
+        walk.run_steps(250)
+        for p in probes:
+            a, b = ref.probe_data(_probe_index(model, p)), walk.probe_data(p)
+            assert a.shape == b.shape and np.abs(a).max() > 0
+            np.testing.assert_allclose(a, b, atol=1e-9, rtol=0)

@@ -63,3 +63,19 @@ def test_shard_ranges_cover_all_vcos():
             assert spans[0][0] == 0 and spans[-1][1] == K
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert all(0 <= hi - lo <= shard_range(K, 0, world)[2] for lo, hi in spans)
+
+
+def test_assemble_gathered_with_a_padded_last_shard():
+    """The device exchange pads every rank's block to the common shard width; 28 VCOs over 3 ranks are shards of
+    10, 10 and 8, and the padding of the last one must fall off the end of the assembled block."""
+    import torch
+    from sspslam_amd.sharding import ShardedPathIntegration, shard_range
+    K, world, n = 28, 3, 5
+    full = torch.arange(n * 3 * K, dtype=torch.float64).reshape(n, 3 * K)
+    per = shard_range(K, 0, world)[2]
+    out = torch.zeros((world, n, 3 * per), dtype=torch.float64)
+    for r in range(world):
+        lo, hi, _ = shard_range(K, r, world)
+        out[r, :, :3 * (hi - lo)] = full[:, 3 * lo:3 * hi]
+    got = ShardedPathIntegration.assemble_gathered(out, K)
+    assert got.shape == (n, 3 * K) and torch.equal(got, full)
