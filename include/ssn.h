@@ -169,6 +169,14 @@ typedef struct ssn_counters {
   int32_t block_threads;            /* threads actually launched per workgroup                    */
 } ssn_counters;
 
+/* Per-kernel device time of the generic (one launch per operator) plan, collected by ssn_run_steps(profile = 2):
+ * every launch of the timed timesteps is bracketed with HIP events on the simulator's stream. */
+typedef struct ssn_kernel_time {
+  char name[32];                    /* kernel of the plan item: "k_program", "k_matvec", "k_ensarray", ... */
+  int64_t launches;
+  double ms_total;
+} ssn_kernel_time;
+
 typedef struct ssn_sim ssn_sim;
 
 /* Simulator(network): upload the built model, plan kernels, capture the step graph. */
@@ -189,7 +197,8 @@ int ssn_set_table_device(ssn_sim* sim, int32_t table_id, const void* rows_dev, i
 
 /* Make room for the probe samples of the next n_steps (drops samples already read). */
 int ssn_reserve_probes(ssn_sim* sim, int64_t n_steps);
-/* Simulator.run_steps(n): blocking. profile != 0 times every dominant-kernel launch with events. */
+/* Simulator.run_steps(n): blocking. profile = 1 times every dominant-kernel launch with events; profile = 2 times
+ * every launch of the per-timestep plan (eager launches instead of graph replay) for ssn_get_kernel_times. */
 int ssn_run_steps(ssn_sim* sim, int64_t n, int32_t profile);
 /* Simulator.data[probe]: samples [first, first+count) of the current reservation -> dst[count][width]. */
 int ssn_read_probe(ssn_sim* sim, int32_t probe_id, double* dst, int64_t first, int64_t count);
@@ -204,6 +213,8 @@ int ssn_read_buffer(ssn_sim* sim, int32_t buffer_id, double* dst, int64_t count)
 int ssn_write_buffer(ssn_sim* sim, int32_t buffer_id, const double* src, int64_t count);
 
 int ssn_get_counters(ssn_sim* sim, ssn_counters* out);
+/* Fills at most `capacity` entries; returns the number of kernels with timed launches (or a negative status). */
+int ssn_get_kernel_times(ssn_sim* sim, ssn_kernel_time* out, int32_t capacity);
 int64_t ssn_n_steps(ssn_sim* sim);
 int ssn_device_count(void);
 const char* ssn_last_error(void);

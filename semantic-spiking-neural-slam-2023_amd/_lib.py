@@ -53,6 +53,10 @@ class Counters(C.Structure):
                 ("block_threads", C.c_int32)]
 
 
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("ms_total", C.c_double)]
+
+
 EXPORTS = {
     "ssn_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     "ssn_destroy": (None, [C.c_void_p]),
@@ -69,6 +73,7 @@ EXPORTS = {
     "ssn_read_buffer": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "ssn_write_buffer": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "ssn_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
+    "ssn_get_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int32]),
     "ssn_n_steps": (C.c_int64, [C.c_void_p]),
     "ssn_device_count": (C.c_int, []),
     "ssn_last_error": (C.c_char_p, []),

@@ -276,6 +276,7 @@ class Builder:
         for e in ensembles:
             if id(e) not in self.block_of:
                 self._emit_dense_ensemble(e)
+        self._live = self._live_elements(probes)
         for blk in self.blocks:
             self._emit_block(blk)
         self._finalise()
@@ -656,6 +657,71 @@ class Builder:
             self.op("voja", w=eb, rows=n, cols=d, spk=spk, key=v["key"], learn=v["learn"],
                     lr_dt=v["lr"] * self.dt, scale_buf=self.model.add_buffer(be.gain / be.radius, f"voja_scale_{e.label}"))
 
+    def _live_elements(self, probes):
+        """Which signal elements can influence anything observable (a probe, a neuron, a learning rule)?
+
+        A decoded row of an EnsembleArray member costs registers and arithmetic on every neuron-step, and the reference's
+        graphs contain rows nothing ever looks at: ``PathIntegration`` decodes all three dimensions of every oscillator
+        into ``oscillators.output`` (``pathintegration.py:162-167``) but the read-out ``to_SSP`` has an all-zero column
+        for each frequency dimension (``get_from_Fourier``, ``:824-844``).  Backward data-flow over the lowered
+        operators: an element is live if a probe samples it, if it is an ensemble / neuron / rule / function-node input,
+        or if a live element is computed from it - through a constant matrix only where the column is non-zero.
+        Returns {arena: bool array}; ``_emit_block`` drops the rows whose destination is dead (their value is then never
+        produced; nothing observable changes)."""
+        live = {a: np.zeros(self.arena_size[a], dtype=bool) for a in "RWSCT"}
+
+        def mark(r):
+            live[r.arena][r.off:r.off + r.len] = True
+
+        for p in self.model.probes:
+            if "src" in p:
+                mark(p["src"])
+        for table in (self.ens_in, self.ens_J, self.rule_in):
+            for r in table.values():
+                mark(r)
+        for blk in self.blocks:
+            mark(blk["x"])
+        for o in self.raw_ops:
+            if o["kind"] == "cleanup":
+                mark(Ref(o["src"].arena, o["src"].off, o["cols"]))
+            elif o["kind"] == "gate":
+                mark(Ref(o["src"].arena, o["src"].off, 2 * o["d"] + 1))
+            elif o["kind"] == "voja":
+                mark(Ref(o["key"].arena, o["key"].off, o["cols"]))
+                mark(Ref(o["spk"].arena, o["spk"].off, o["rows"]))
+            elif o["kind"] == "pes":
+                mark(Ref(o["act"].arena, o["act"].off, o["cols"]))
+                mark(Ref(o["err"].arena, o["err"].off, o["rows"]))
+        changed = True
+        while changed:
+            changed = False
+            for o in reversed(self.raw_ops):
+                k = o["kind"]
+                if k in ("axpy", "lowpass"):
+                    d, sr, n = o["dst"], o["src"], o["len"]
+                    need = live[d.arena][d.off:d.off + n]
+                    cur = live[sr.arena][sr.off:sr.off + n]
+                    if np.any(need & ~cur):
+                        cur |= need
+                        changed = True
+                elif k == "matvec":
+                    d, sr = o["dst"], o["src"]
+                    rows_live = live[d.arena][d.off:d.off + o["rows"]]
+                    if not rows_live.any():
+                        continue
+                    if self.model.buffer_meta[o["w"]]["role"] == "param":
+                        need = np.any(self.model.buffers[o["w"]][rows_live] != 0, axis=0)
+                    else:
+                        need = np.ones(o["cols"], dtype=bool)
+                    cur = live[sr.arena][sr.off:sr.off + o["cols"]]
+                    if np.any(need & ~cur):
+                        cur |= need
+                        changed = True
+        return live
+
+    def _row_is_live(self, ref):
+        return bool(self._live[ref.arena][ref.off:ref.off + ref.len].any())
+
     def _emit_block(self, blk):
         ens = blk["ens"]
         K_all = len(ens)
@@ -665,6 +731,11 @@ class Builder:
         K = hi - lo
         if K == 0:
             return
+        n_rows = sum(len(blk["rows"][i]) for i in range(lo, hi))
+        for i in range(lo, hi):
+            blk["rows"][i] = [rw for rw in blk["rows"][i] if self._row_is_live(rw[1])]
+        self.model.stats["dead_decoded_rows"] = self.model.stats.get("dead_decoded_rows", 0) + \
+            n_rows - sum(len(blk["rows"][i]) for i in range(lo, hi))
         dout = max(1, max(len(blk["rows"][i]) for i in range(lo, hi)))
         enc = np.zeros((K, din, n))
         bias = np.zeros((K, n))

@@ -12,13 +12,14 @@
 // bound by VALU issue instead.
 //
 // Per timestep and workgroup:
-//   x[d]   = pre-stage row (block buffer) + alpha[d] * filter_state[xrow[d]]           (uniform, scalar)
+//   x[d]   = pre-stage row (block buffer, staged in LDS) + alpha[d] * filter_state[xrow[d]]
 //   for each of the thread's NPT neurons: J = e.x + bias; LIF step on the packed state word; acc += spike*dec
-//   acc[dout] -> DPP wave reduction -> LDS [parity][dout][wave] -> barrier -> every thread adds the wave sums
-//   in fixed order (deterministic; all threads hold identical totals)
-//   filter_state[r] = a[r]*filter_state[r] + b[r]*total[r]; thread r hands total[r] to the post stage's row.
-// At the end the state words go back to HBM and thread r publishes decoded value / filter state r to the
+//   acc[dout] -> sums over the wave -> LDS [parity][dout][wave] -> ONE barrier -> every wave adds the wave sums in the
+//   same fixed order (deterministic; all waves hold identical totals)
+//   filter_state[r] = a[r]*filter_state[r] + b[r]*total[r]; total[r] is staged for the post stage's row.
+// At the end the state words go back to HBM and the decoded values / filter states of the last step go to the
 // signal vector (what k_ens_finish does after every step of the per-step plan).
+// f32 state words hold -(R - dt) for a refractory neuron (see lif_packed_step_f32x2), f64 ones -R (k_ensarray's fast path).
 #pragma once
 #include <type_traits>
 #include "ssn_launch.hpp"
@@ -73,82 +74,120 @@ __device__ inline void wave_sum_dpp_n(double* v) {
   for (int r = 0; r < N; ++r) v[r] = wave_sum_dpp(v[r]);
 }
 
-// Branch-free f32 LIF step on the packed state word (s >= 0: voltage; s < 0: minus the remaining refractory
-// time), TWO neurons per call in the two halves of 64-bit register pairs so that the multiplies / adds / FMAs
-// issue as packed v_pk_*_f32 (2 flops per lane per issue slot - the kernel is VALU-issue bound).  Value for value
-// the arithmetic of k_ensarray's fast path (-R' = min(s,0) + dt is the exact negation of R - dt, and so on),
-// except expm1's Taylor polynomial stopping one term earlier (below).  The spike branch is evaluated for every
-// lane and selected: at ~4 % spikes per step some lane of a wave takes it for 93 % of the neurons anyway.
-// Requires dt/tau_rc <= 1/8 (Taylor range) and tau_ref >= dt; the host planner checks both.
+// ---- packed f32 arithmetic with the VOP3P clamp modifier: result clamped to [0, 1], NaN -> 0 (DX10 clamp mode) ------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef int i32x2 __attribute__((ext_vector_type(2)));
-struct LifConstF32 { float dt, neg_dt, neg_inv_tau, tau_rc_ln2, tau_ref_dt; };
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ inline f32x2 pk_clamp01(f32x2 x) {
+  f32x2 r;
+  asm("v_pk_mul_f32 %0, %1, 1.0 op_sel_hi:[1,0] clamp" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ inline f32x2 pk_mul_clamp01(f32x2 x, f32x2 y) {
+  f32x2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "s"(y));          // (y: a uniform constant pair)
+  return r;
+}
+__device__ inline f32x2 pk_mul_clamp01_vv(f32x2 x, f32x2 y) {
+  f32x2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ inline f32x2 pk_fma1_clamp01(f32x2 x, f32x2 y) {          // clamp(x * y + 1)
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel_hi:[1,1,0] clamp" : "=v"(r) : "v"(x), "s"(y));
+  return r;
+}
 
-__device__ inline f32x2 lif_packed_step_f32x2(f32x2 J, f32x2& s, const LifConstF32& c) {
-  // min / max against 0 on the bit pattern (negative floats are negative integers): one instruction each,
-  // where fminf / fmaxf cost a NaN-quieting pre-pass in IEEE mode
-  const i32x2 sb = __builtin_bit_cast(i32x2, s);
-  const f32x2 m = __builtin_bit_cast(f32x2, __builtin_elementwise_min(sb, (i32x2)(0)));    // -(remaining refractory time)
-  const f32x2 V0 = __builtin_bit_cast(f32x2, __builtin_elementwise_max(sb, (i32x2)(0)));
-  const f32x2 negR = m + c.dt;                     // -(R - dt)
-  f32x2 delta = negR + c.dt;                       // dt - (R - dt)
-  delta.x = __builtin_amdgcn_fmed3f(delta.x, 0.0f, c.dt);
-  delta.y = __builtin_amdgcn_fmed3f(delta.y, 0.0f, c.dt);
-  const f32x2 x = delta * c.neg_inv_tau;
-  f32x2 q = (f32x2)(1.0f / 120.0f);                // expm1(x)/x to x^4/120: next term < 4e-8 relative at |x| <= 1/8
-  q = __builtin_elementwise_fma(q, x, (f32x2)(1.0f / 24.0f));
-  q = __builtin_elementwise_fma(q, x, (f32x2)(1.0f / 6.0f));
-  q = __builtin_elementwise_fma(q, x, (f32x2)(0.5f));
-  q = __builtin_elementwise_fma(q, x, (f32x2)(1.0f));
-  const f32x2 V = V0 - (J - V0) * (q * x);
+// Branch-free f32 LIF step, TWO neurons per call in the two halves of 64-bit register pairs, built ONLY from packed
+// multiply / add / FMA (v_pk_*_f32: 2 flops per lane per issue slot) plus one v_rcp_f32 and one v_log_f32 per neuron:
+// no compare, no select, no integer min / max.  On gfx950 every non-FMA vector instruction (v_cndmask, v_cmp, v_max_i32,
+// v_med3 ...) costs a full 4-cycle issue slot of its own per NEURON where a packed one serves two (measured:
+// tools/valu_issue_rate.hip, profiles/round2_valu_issue_rate.txt), so the selects of nengo's LIF step (SURVEY
+// Appendix A.4) are rewritten as exact arithmetic on {0, 1} indicators made with the clamp modifier:
+//
+//   state word s:  s >= 0  voltage of a non-refractory neuron (<= 1);  s < 0  -(R - dt), R = refractory time left at the
+//                  start of the next step (> dt; a refractory time <= dt is not stored: the next step integrates for the
+//                  full dt whatever its value)
+//   V0 = clamp(s)                 max(s, 0)
+//   m  = s - V0                   min(s, 0)                                       (exact: one of the two is zero)
+//   t  = m + dt                   dt - (R - dt): what is left of this step after the refractory period (<= dt)
+//   delta = clamp(t)              integration time  (nengo: clip(dt - refractory, 0, dt))
+//   mt = t - delta                min(t, 0): < 0 while the neuron stays refractory beyond the next step - the new state word
+//   em = delta * P(delta)         -expm1(-delta / tau_rc) = x - x^2/2 + x^3/6 - x^4/24, x = delta / tau_rc <= 1/20: the first
+//                                 neglected term is x^4/120 < 5.3e-8 of the result (half an f32 ulp)
+//   V  = V0 + (J - V0) * em
+//   spk = clamp((V - 1) * 2^24)   1 if V > 1 (V - 1 is exact and >= 2^-23 then), else 0;   nspk = clamp(1 - (V - 1) * 2^24)
+//   jm1s = (J - 1) * spk + nspk   J - 1 of a spiking neuron, 1 otherwise: rcp / log never see the junk of silent neurons
+//   u  = -(tau_ref + tau_rc * ln(1 - (V - 1) / jm1s))       new state word of a spiking neuron (tau_ref + t_spike - dt)
+//   Vn = clamp(V * nspk)          voltage of a silent neuron clamped at min_voltage 0 (V <= 1), 0 for a spiking one
+//   s' = spk * u + (mt + Vn)      (spiking: mt = Vn = 0; silent: spk = 0 - exact selects, products with 0 / 1)
+// Requires dt / tau_rc <= 1/20 and tau_ref >= dt (checked by the host planner).
+struct LifConstV2 { float dt, a1, a2, a3, a4, neg_tau_ln2, neg_tau_ref; };
+
+__device__ inline f32x2 lif_packed_step_f32x2(f32x2 J, f32x2& s, const LifConstV2& c, f32x2 big, f32x2 nbig) {
+  const f32x2 V0 = pk_clamp01(s);
+  const f32x2 m = s - V0;
+  const f32x2 t = m + c.dt;
+  const f32x2 delta = pk_clamp01(t);
+  const f32x2 mt = t - delta;
+  // (uniform coefficients as scalar-register pairs: one constant-bus operand per instruction, the first FMA's second
+  //  coefficient lives in a vector register pair)
+  f32x2 P;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(delta), "v"((f32x2)(c.a4)), "s"((f32x2)(c.a3)));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(delta), "v"(P), "s"((f32x2)(c.a2)));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(delta), "v"(P), "s"((f32x2)(c.a1)));
+  const f32x2 em = delta * P;
+  const f32x2 V = __builtin_elementwise_fma(J - V0, em, V0);
   const f32x2 vm1 = V - 1.0f, jm1 = J - 1.0f;
+  const f32x2 spk = pk_mul_clamp01(vm1, big);
+  const f32x2 nspk = pk_fma1_clamp01(vm1, nbig);
+  const f32x2 jm1s = __builtin_elementwise_fma(jm1, spk, nspk);
   f32x2 rc;
-  rc.x = __builtin_amdgcn_rcpf(jm1.x);
-  rc.y = __builtin_amdgcn_rcpf(jm1.y);
-  const f32x2 omu = 1.0f - vm1 * rc;               // 1 - (V - 1) / (J - 1)
+  rc.x = __builtin_amdgcn_rcpf(jm1s.x);
+  rc.y = __builtin_amdgcn_rcpf(jm1s.y);
+  const f32x2 omu = __builtin_elementwise_fma(-vm1, rc, (f32x2)(1.0f));     // 1 - (V - 1) / (J - 1)
   f32x2 lg2;
-  lg2.x = __builtin_amdgcn_logf(omu.x);            // log2; used only where the neuron spiked
+  lg2.x = __builtin_amdgcn_logf(omu.x);
   lg2.y = __builtin_amdgcn_logf(omu.y);
-  const f32x2 Rs = __builtin_elementwise_fma((f32x2)(c.tau_rc_ln2), lg2, (f32x2)(c.tau_ref_dt));   // tau_ref + dt + tau_rc ln(1-u)
-  const f32x2 Vc = __builtin_bit_cast(f32x2, __builtin_elementwise_max(__builtin_bit_cast(i32x2, V), (i32x2)(0)));
-  f32x2 spk;
-  {
-    const float s_ns = negR.x < c.neg_dt ? negR.x : Vc.x;      // still refractory after this step ? -R : V
-    const bool sp = V.x > 1.0f;
-    s.x = sp ? -Rs.x : s_ns;                                   // (tau_ref >= dt: a spike is always followed by a refractory step)
-    spk.x = sp ? 1.0f : 0.0f;
-  }
-  {
-    const float s_ns = negR.y < c.neg_dt ? negR.y : Vc.y;
-    const bool sp = V.y > 1.0f;
-    s.y = sp ? -Rs.y : s_ns;
-    spk.y = sp ? 1.0f : 0.0f;
-  }
+  const f32x2 u = __builtin_elementwise_fma((f32x2)(c.neg_tau_ln2), lg2, (f32x2)(c.neg_tau_ref));
+  const f32x2 Vn = pk_mul_clamp01_vv(V, nspk);
+  s = __builtin_elementwise_fma(spk, u, mt + Vn);
   return spk;
 }
 
+__device__ inline float bits_f(unsigned int x) { return __builtin_bit_cast(float, x); }
+__device__ inline unsigned int f_bits(float x) { return __builtin_bit_cast(unsigned int, x); }
+
 // Neurons are dealt to threads in groups of PK adjacent neurons (PK = 2 for f32: one 64-bit register pair,
 // 1 for f64): neuron index of (group g, thread tid, component c) = (g * nthr + tid) * PK + c - coalesced.
-template <typename T, int DIN, int DOUT, int NPT, int TPB, bool ENC_LDS, bool CLUSTER>
+//
+// Cross-lane sums (f32).  Per timestep a wave owes DOUT sums over its 64 lanes, and every wave then needs the DOUT
+// totals over all waves for the filter update and the next input.  Both steps are kept off the scalar unit and off
+// per-row instruction sequences:
+//   * in the wave: four values at once - two v_permlane32_swap + add fold lanes 32..63 onto 0..31 for two value pairs,
+//     one v_permlane16_swap + add leaves the four values in the four 16-lane rows, four DPP steps finish all four rows
+//     together (gfx950's swap instructions; a fifth value takes the plain six-step DPP sum): 17 instead of 30 steps;
+//   * across waves: wave w leaves value r in LDS slot r * 16 + w; after the one barrier of the timestep lane l of every
+//     wave reads slot l, so a four-step DPP row sum gives row r of EVERY wave the total of value r in fixed order
+//     (identical in all waves: deterministic).  The totals stay "lane-distributed" (row r of a register = decoded row
+//     r): the Lowpass update of the recurrent filter states is ONE v_fma on that register with per-lane constants, and
+//     only the (at most DIN) states the next input needs are broadcast with v_readlane.
+template <typename T, int DIN, int DOUT, int NPT, int TPB, int LDSW>      // LDSW: 0 all parameters in registers | DIN: the encoder rows in LDS
 __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
+  constexpr bool ENC_LDS = LDSW == DIN;
+  // (Encoders AND bias in LDS - rows as long as the padded neuron count, 160 000 of the CU's 163 840 bytes at n = 10 000 -
+  //  were built and measured in round 2: (768, 14) 3.68 ms and (1024, 10) 3.64 ms per 1000 timesteps of config 2 against
+  //  3.49 for (512, 20) with the bias in registers: removed.)
+  static_assert(LDSW == 0 || LDSW == DIN, "LDSW");
   extern __shared__ __align__(16) unsigned char ssn_block_dyn[];
-  T* const e_lds = reinterpret_cast<T*>(ssn_block_dyn);       // ENC_LDS: encoders [DIN][nthr * NPT]
+  T* const e_lds = reinterpret_cast<T*>(ssn_block_dyn);       // ENC_LDS: encoder rows [DIN][cap]
   constexpr bool F32 = sizeof(T) == 4;
   constexpr int PK = F32 ? 2 : 1;
   constexpr int NG = NPT / PK;
   static_assert(NPT % PK == 0, "f32 variants handle neuron pairs");
   using G = typename std::conditional<F32, f32x2, T>::type;   // one group of neurons
   constexpr int DP = DOUT <= 4 ? 4 : 8;
-  // Cluster mode (a.P > 1, few ensembles per GPU): P workgroups share one ensemble's neurons and exchange their
-  // partial sums once per timestep.  Members of a cluster get block indices that are equal mod 8, i.e. land on
-  // one XCD under round-robin placement (a speed bonus for the exchange, never needed for correctness).
-  int k = blockIdx.x, p = 0;
-  if (CLUSTER && a.P > 1) {
-    const int b8 = blockIdx.x / (8 * a.P), rem = blockIdx.x - b8 * 8 * a.P;
-    k = b8 * 8 + (rem & 7);
-    p = rem >> 3;
-    if (k >= a.K) return;                                  // padding of the last group of 8 ensembles
-  }
+  const int k = blockIdx.x;
   const int tid = threadIdx.x;
   const int nthr = NG == 1 ? (int)blockDim.x : TPB;       // variants with more than one group always run full workgroups
   const int lane = tid & 63, wave = tid >> 6;
@@ -158,59 +197,62 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   T* __restrict__ Sp = a.S + (size_t)k * row;
   const NeuronParams<T> np = a.np;
   const LifMath<T> lm(np);
-  const LifConstF32 lc{(float)np.dt, -(float)np.dt, -1.0f / (float)np.tau_rc, (float)np.tau_rc * 0.6931471805599453f,
-                       (float)np.tau_ref + (float)np.dt};
+  const float itau = 1.0f / (float)np.tau_rc;
+  // (float arithmetic runs on the vector unit: readfirstlane moves the uniform results to scalar registers, where the
+  //  packed instructions of the time loop can take them as their one constant-bus operand)
+  auto uni = [](float v) { return bits_f(__builtin_amdgcn_readfirstlane(f_bits(v))); };
+  const LifConstV2 lc{uni((float)np.dt), uni(itau), uni(-0.5f * itau * itau), uni(itau * itau * itau / 6.0f),
+                      uni(-itau * itau * itau * itau / 24.0f), uni(-(float)np.tau_rc * 0.6931471805599453f), uni(-(float)np.tau_ref)};
+  const f32x2 big = {16777216.0f, 16777216.0f}, nbig = {-16777216.0f, -16777216.0f};
 
   // ---- parameters and state of this thread's neurons -> registers ---------------------------------------------
   G e[ENC_LDS ? 1 : NG][DIN], b[NG], s[NG], dc[NG][DOUT];
-  const int cap = nthr * NPT;
-  auto comp = [](G& v, int c) -> T& { if constexpr (F32) return c == 0 ? reinterpret_cast<T*>(&v)[0] : reinterpret_cast<T*>(&v)[1]; else return v; };
+  // LDS rows: as long as the variant's capacity (compile-time strides).
+  constexpr int cap = (NG == 1 ? 1024 : TPB) * NPT;
+  // one LDS base address per parameter row; a group's entry is a compile-time offset from it (the opaque asm keeps the
+  // compiler from hoisting one address register per (group, row) out of the time loop: 28 registers at 7 groups)
+  int lrow[LDSW > 0 ? LDSW : 1];           // (element offsets, not pointers: a pointer that went through the asm would be
+#pragma unroll                             //  dereferenced with flat loads - 64-bit addresses, and the LDS aperture check)
+  for (int d = 0; d < (LDSW > 0 ? LDSW : 1); ++d) {
+    lrow[d] = d * cap + tid * PK;
+    asm volatile("" : "+v"(lrow[d]));
+  }
+  auto lds_group = [&](int d, int g) -> const G* {
+    return reinterpret_cast<const G*>(e_lds + lrow[d] + g * nthr * PK);
+  };
+  // Straight-line loads, no per-neuron branches (which cost the register allocator its view of the long live ranges):
+  // rows are zero-padded to n_pad (a multiple of 4 elements) on upload, so a whole group is read whenever it starts
+  // inside the padded row; groups past it read group 0 and are multiplied by 0.
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
+    const int i0 = (g * nthr + tid) * PK;
+    const bool in = i0 < a.n_pad;
+    const int ii = in ? i0 : 0;
+    const T msk = in ? T(1) : T(0);
+    auto ld = [&](const T* p) -> G { if constexpr (F32) return *reinterpret_cast<const f32x2*>(p) * msk; else return *p * msk; };
 #pragma unroll
-    for (int c = 0; c < PK; ++c) {
-      const int li = (g * nthr + tid) * PK + c;          // index inside this workgroup's share
-      const int i = p * cap + li;
-      const bool ok = i < a.n;
-#pragma unroll
-      for (int d = 0; d < DIN; ++d) {
-        const T ev = ok ? enc[d * row + i] : T(0);
-        if constexpr (ENC_LDS) e_lds[d * cap + li] = ev; else comp(e[g][d], c) = ev;
-      }
-      comp(b[g], c) = ok ? bias[i] : T(0);
-      comp(s[g], c) = ok ? Sp[i] : T(0);
-      if (a.dec_neuron_major) {
-        const T* dp = a.dec + ((size_t)k * row + i) * DP;
-#pragma unroll
-        for (int r = 0; r < DOUT; ++r) comp(dc[g][r], c) = ok ? dp[r] : T(0);
-      } else {
-        const T* dp = a.dec + (size_t)k * DOUT * row + i;
-#pragma unroll
-        for (int r = 0; r < DOUT; ++r) comp(dc[g][r], c) = ok ? dp[r * row] : T(0);
-      }
+    for (int d = 0; d < DIN; ++d) {
+      const G ev = ld(enc + d * row + ii);
+      if constexpr (ENC_LDS) *reinterpret_cast<G*>(e_lds + d * cap + i0) = ev; else e[g][d] = ev;
     }
-  }
-
-  // ---- per-row constants (uniform) -------------------------------------------------------------------------
-  T fs[DOUT], la[DOUT], lb[DOUT], xa[DIN];
-  int xr[DIN];
+    b[g] = ld(bias + ii);
+    s[g] = ld(Sp + ii);
+    if (a.dec_neuron_major) {
+      const T* dp = a.dec + ((size_t)k * row + ii) * DP;
 #pragma unroll
-  for (int r = 0; r < DOUT; ++r) {
-    const long long i = (long long)k * DOUT + r;
-    const int st = a.lp_state[i];
-    fs[r] = st >= 0 ? a.sig[st] : T(0);
-    la[r] = st >= 0 ? a.lp_a[i] : T(0);
-    lb[r] = st >= 0 ? a.lp_b[i] : T(0);
-  }
+      for (int r = 0; r < DOUT; ++r) {
+        if constexpr (F32) dc[g][r] = (f32x2){dp[r], dp[DP + r]} * msk; else dc[g][r] = dp[r] * msk;
+      }
+    } else {
+      const T* dp = a.dec + (size_t)k * DOUT * row + ii;
 #pragma unroll
-  for (int d = 0; d < DIN; ++d) {
-    xr[d] = a.xrow[(long long)k * DIN + d];
-    xa[d] = a.xalpha[(long long)k * DIN + d];
+      for (int r = 0; r < DOUT; ++r) dc[g][r] = ld(dp + r * row);
+    }
   }
 
   // ---- LDS: wave sums (two parities), and the block-buffer traffic of CH timesteps at a time so that no global
   //      memory operation sits inside the time loop (a workgroup barrier waits for every outstanding one) ----
-  constexpr int CH = 128;                    // timesteps per input/output chunk
+  constexpr int CH = 32;                     // timesteps per input/output chunk (static LDS stays under 2 KB)
   constexpr int XP = 4;                      // words per timestep of inputs (DIN <= 4): one 16-byte LDS read
   constexpr int RW = DOUT <= 4 ? 64 : 128;   // wave-sum slots per parity: [r][16 waves]
   __shared__ __align__(16) T red[2][RW];
@@ -218,20 +260,65 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   __shared__ T os[CH][DOUT];
   __shared__ int s_dst[DOUT];
   __shared__ int s_out[DOUT];
-  constexpr int PMAX = 4;                    // largest cluster
-  constexpr int GV = sizeof(T) / 4;          // 32-bit payload words per value (exchange granule = {payload, tag})
-  __shared__ unsigned int xt[2][CLUSTER ? PMAX * DOUT * GV : 1];
   for (int i = tid; i < 2 * RW; i += nthr) (&red[0][0])[i] = T(0);     // waves that do not exist add 0
   if (tid < DOUT) { s_dst[tid] = a.didx[(long long)k * DOUT + tid]; s_out[tid] = a.rowout[(long long)k * DOUT + tid] ? 1 : 0; }
   const T* __restrict__ xbase = a.xrows + (size_t)a.row0 * a.n_sig + a.x_off + (long long)k * DIN;
-  T tot[DOUT];
-#pragma unroll
-  for (int r = 0; r < DOUT; ++r) tot[r] = T(0);
 
-  G en[DIN];                                 // ENC_LDS: encoders of the group about to be processed
+  // ---- per-row constants.  f32: lane-distributed - register 0 holds decoded row (lane >> 4), register 1 row 4 -----
+  //      f64 (parity / small ensembles): uniform arrays, as the per-timestep kernel computes them
+  T fs[F32 ? 1 : DOUT], la[F32 ? 1 : DOUT], lb[F32 ? 1 : DOUT], tot[F32 ? 1 : DOUT];
+  float F0 = 0.0f, F1 = 0.0f, la0 = 0.0f, lb0 = 0.0f, la1 = 0.0f, lb1 = 0.0f, v0 = 0.0f, v1 = 0.0f;
+  T xa[DIN];
+  int xr[DIN];
+#pragma unroll
+  for (int d = 0; d < DIN; ++d) {
+    xr[d] = a.xrow[(long long)k * DIN + d];
+    xa[d] = xr[d] >= 0 ? a.xalpha[(long long)k * DIN + d] : T(0);
+  }
+  if constexpr (F32) {
+    const int r0 = lane >> 4;
+    if (r0 < DOUT) {
+      const long long i = (long long)k * DOUT + r0;
+      const int st = a.lp_state[i];
+      if (st >= 0) { F0 = a.sig[st]; la0 = a.lp_a[i]; lb0 = a.lp_b[i]; }
+    }
+    if (DOUT > 4) {
+      const long long i = (long long)k * DOUT + 4;
+      const int st = a.lp_state[i];
+      if (st >= 0) { F1 = a.sig[st]; la1 = a.lp_a[i]; lb1 = a.lp_b[i]; }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < DOUT; ++r) {
+      const long long i = (long long)k * DOUT + r;
+      const int st = a.lp_state[i];
+      fs[r] = st >= 0 ? a.sig[st] : T(0);
+      la[r] = st >= 0 ? a.lp_a[i] : T(0);
+      lb[r] = st >= 0 ? a.lp_b[i] : T(0);
+      tot[r] = T(0);
+    }
+  }
+  // f32: where this lane's wave sums go (slot r * 16 + wave) and which filter states feed the inputs
+  int wslot = -1;
+  if constexpr (F32) {
+    if constexpr (DOUT >= 4) {
+      // after the swap reduction the rows of the 4-value register hold values 0, 2, 1, 3; value 4 sits in lane 63
+      const int rv = (lane >> 4) == 1 ? 2 : ((lane >> 4) == 2 ? 1 : (lane >> 4));
+      if ((lane & 15) == 0) wslot = rv * 16 + wave;
+      if (DOUT == 5 && lane == 63) wslot = 64 + wave;
+    }
+  }
+
+#ifndef SSN_BLOCK_IL
+#define SSN_BLOCK_IL 2
+#endif
+  constexpr int ILE = F32 ? (SSN_BLOCK_IL < NG ? SSN_BLOCK_IL : NG) : 1;      // groups stepped side by side (see the time loop)
+  G en[ILE][LDSW > 0 ? LDSW : 1];            // ENC_LDS: encoders (and bias) of the groups about to be processed
   if constexpr (ENC_LDS) {
 #pragma unroll
-    for (int d = 0; d < DIN; ++d) en[d] = *reinterpret_cast<const G*>(e_lds + d * cap + tid * PK);
+    for (int u = 0; u < ILE; ++u)
+#pragma unroll
+      for (int d = 0; d < LDSW; ++d) en[u][d] = *lds_group(d, u);
   }
   for (int j0 = 0; j0 < a.B; j0 += CH) {
     const int cn = min(CH, a.B - j0);
@@ -239,7 +326,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
     if (j0 > 0) {                            // hand the previous chunk's decoded rows to the post stage
       for (int i = tid; i < CH * DOUT; i += nthr) {
         const int jj = i / DOUT, r = i - jj * DOUT;
-        if (s_out[r] && p == 0) a.bsig[(size_t)(a.row0 + j0 - CH + jj) * a.n_sig + s_dst[r]] = os[jj][r];
+        if (s_out[r]) a.bsig[(size_t)(a.row0 + j0 - CH + jj) * a.n_sig + s_dst[r]] = os[jj][r];
       }
     }
     for (int i = tid; i < cn * DIN; i += nthr) {
@@ -253,99 +340,149 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
       if constexpr (sizeof(T) == 4) *(float4*)xin = *(const float4*)xs[jj];
       else { *(double2*)xin = *(const double2*)xs[jj]; *(double2*)(xin + 2) = *(const double2*)(xs[jj] + 2); }
       T x[DIN];
+      if constexpr (F32) {
+        // the filter states the inputs read: row xr[d] of the lane-distributed registers (uniform lane index)
+        const float f1 = bits_f(__builtin_amdgcn_readlane(f_bits(F1), 0));
 #pragma unroll
-      for (int d = 0; d < DIN; ++d) {
-        T st = T(0);
+        for (int d = 0; d < DIN; ++d) {
+          const float f0 = bits_f(__builtin_amdgcn_readlane(f_bits(F0), (xr[d] & 3) << 4));
+          const float st = xr[d] >= 4 ? f1 : f0;
+          x[d] = __builtin_fmaf(xa[d], st, xin[d]);                 // (xa = 0 where no state feeds the input)
+        }
+      } else {
 #pragma unroll
-        for (int r = 0; r < DOUT; ++r) st = xr[d] == r ? fs[r] : st;
-        x[d] = xr[d] >= 0 ? xin[d] + xa[d] * st : xin[d];
+        for (int d = 0; d < DIN; ++d) {
+          T st = T(0);
+#pragma unroll
+          for (int r = 0; r < DOUT; ++r) st = xr[d] == r ? fs[r] : st;
+          x[d] = xr[d] >= 0 ? xin[d] + xa[d] * st : xin[d];
+        }
       }
       G accg[DOUT];
 #pragma unroll
       for (int r = 0; r < DOUT; ++r) accg[r] = G(0);
       // ENC_LDS: a thread reads back only the entries it wrote itself (no barrier needed); the next group's
-      // encoders are requested one group ahead so the LDS latency hides under this group's arithmetic (with two
-      // waves per SIMD an exposed ds_read stalls the SIMD)
-      G nx[DIN];
+      // encoders are requested one group ahead so the LDS latency hides under this group's arithmetic
+      // Groups are stepped IL at a time: each group's LIF step is one long dependent chain (~30 packed operations, a
+      // reciprocal and a logarithm), and with two or three waves per SIMD the hardware alone does not cover its latency -
+      // measured 6.8 cycles per vector instruction with one chain per wave against 4.4 issue-bound.  Beyond IL the chains
+      // are kept apart (scheduling barrier): more interleaving only costs registers.
+      constexpr int IL = ILE;
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        if constexpr (ENC_LDS) {          // (the last group requests group 0 again: the next timestep's first operands)
-          const int gn = g + 1 < NG ? g + 1 : 0;
+      for (int g0 = 0; g0 < NG; g0 += IL) {
+        G J[IL], spk[IL];
 #pragma unroll
-          for (int d = 0; d < DIN; ++d) nx[d] = *reinterpret_cast<const G*>(e_lds + d * cap + (gn * nthr + tid) * PK);
-        }
-        G J = b[g];
+        for (int u = 0; u < IL; ++u) {
+          const int g = g0 + u < NG ? g0 + u : NG - 1;       // (a last, partial round: the surplus slots repeat its last group and are discarded)
+          J[u] = b[g];
 #pragma unroll
-        for (int d = 0; d < DIN; ++d) {
-          if constexpr (ENC_LDS) J += en[d] * x[d];
-          else J += e[g][d] * x[d];
+          for (int d = 0; d < DIN; ++d) {
+            if constexpr (ENC_LDS) J[u] += en[u][d] * x[d];
+            else J[u] += e[g][d] * x[d];
+          }
         }
         if constexpr (ENC_LDS) {
+          // the groups' LDS operands are consumed: request the next groups' into the same registers now - they arrive
+          // under this round's neuron arithmetic (the last round requests round 0: the next timestep's first operands)
 #pragma unroll
-          for (int d = 0; d < DIN; ++d) en[d] = nx[d];
-        }
-        G spk;
-        if constexpr (F32) spk = lif_packed_step_f32x2(J, s[g], lc);
-        else {
-          // packed state word -> nengo's LIF step, operation for operation k_ensarray's fast path
-          const T sw = s[g];
-          T V = sw < T(0) ? T(0) : sw;
-          T R = (sw < T(0) ? -sw : T(0)) - np.dt;
-          T delta = np.dt - R;
-          delta = delta < T(0) ? T(0) : (delta > np.dt ? np.dt : delta);
-          V = V - (J - V) * lm.decay(delta);
-          spk = T(0);
-          if (V > T(1)) {
-            const T t_spike = np.dt + np.tau_rc * lm.spike_time_term(V, J);
-            R = np.tau_ref + t_spike;
-            V = T(0);
-            spk = T(1);
-          } else if (V < T(0)) {
-            V = T(0);
+          for (int u = 0; u < IL; ++u) {
+            if (g0 + u >= NG) continue;
+            asm volatile("" : "+v"(J[u]));
+            const int gn = g0 + IL + u < NG ? g0 + IL + u : (g0 + IL + u) % IL;
+#pragma unroll
+            for (int d = 0; d < LDSW; ++d) en[u][d] = *lds_group(d, gn);
           }
-          s[g] = R > np.dt ? -R : V;
         }
 #pragma unroll
-        for (int r = 0; r < DOUT; ++r) {           // spk is 0 or 1: exact add
-          if constexpr (F32) accg[r] = __builtin_elementwise_fma(spk, dc[g][r], accg[r]);
-          else accg[r] = fma(spk, dc[g][r], accg[r]);
+        for (int u = 0; u < IL; ++u) {
+          const int g = g0 + u;
+          if (g >= NG) continue;
+          if constexpr (F32) {
+            spk[u] = lif_packed_step_f32x2(J[u], s[g], lc, big, nbig);
+          } else {
+            // packed state word -> nengo's LIF step, operation for operation k_ensarray's fast path
+            const T sw = s[g];
+            T V = sw < T(0) ? T(0) : sw;
+            T R = (sw < T(0) ? -sw : T(0)) - np.dt;
+            T delta = np.dt - R;
+            delta = delta < T(0) ? T(0) : (delta > np.dt ? np.dt : delta);
+            V = V - (J[u] - V) * lm.decay(delta);
+            spk[u] = T(0);
+            if (V > T(1)) {
+              const T t_spike = np.dt + np.tau_rc * lm.spike_time_term(V, J[u]);
+              R = np.tau_ref + t_spike;
+              V = T(0);
+              spk[u] = T(1);
+            } else if (V < T(0)) {
+              V = T(0);
+            }
+            s[g] = R > np.dt ? -R : V;
+          }
         }
-      }
-      T acc[DOUT];
 #pragma unroll
-      for (int r = 0; r < DOUT; ++r) {
-        if constexpr (F32) acc[r] = accg[r].x + accg[r].y; else acc[r] = accg[r];
+        for (int u = 0; u < IL; ++u) {
+          const int g = g0 + u;
+          if (g >= NG) continue;
+          // the state word is final HERE: without this the compiler sinks the rcp / log half of every group's step to the
+          // end of the timestep and keeps its operands live until then
+          if constexpr (F32) asm volatile("" : "+v"(s[g]));
+#pragma unroll
+          for (int r = 0; r < DOUT; ++r) {           // spk is 0 or 1: exact add
+            if constexpr (F32) accg[r] = __builtin_elementwise_fma(spk[u], dc[g][r], accg[r]);
+            else accg[r] = fma(spk[u], dc[g][r], accg[r]);
+          }
+        }
+#ifndef SSN_BLOCK_NO_SCHED_BARRIER
+        if constexpr (F32) __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       const int par = jj & 1;
-#if defined(SSN_BLOCK_EXPERIMENT) && SSN_BLOCK_EXPERIMENT == 1      /* timing bisection only: no reduction (wrong results) */
+      if constexpr (F32) {
+        float acc[DOUT];
 #pragma unroll
-      for (int r = 0; r < DOUT; ++r) tot[r] = acc[r] * T(1e-30);
-#else
-      // the DOUT wave reductions are independent: all sums first (their DPP stages interleave and fill each
-      // other's wait states), then one predicated store block
-      T wsum[DOUT];
+        for (int r = 0; r < DOUT; ++r) acc[r] = accg[r].x + accg[r].y;
+        if constexpr (DOUT >= 4) {
+          const auto p01 = __builtin_amdgcn_permlane32_swap(f_bits(acc[0]), f_bits(acc[1]), false, false);
+          const auto p23 = __builtin_amdgcn_permlane32_swap(f_bits(acc[2]), f_bits(acc[3]), false, false);
+          const float s01 = bits_f(p01[0]) + bits_f(p01[1]);       // lanes 0..31: value 0, 32..63: value 1
+          const float s23 = bits_f(p23[0]) + bits_f(p23[1]);
+          const auto q = __builtin_amdgcn_permlane16_swap(f_bits(s01), f_bits(s23), false, false);
+          float t4 = bits_f(q[0]) + bits_f(q[1]);                  // rows: values 0, 2, 1, 3
+          t4 = row_sum_dpp(t4);
+          if constexpr (DOUT == 5) {
+            const float w4 = wave_sum_dpp(acc[4]);                 // lane 63
+            if (wslot >= 0) red[par][wslot] = lane == 63 ? w4 : t4;
+          } else {
+            if (wslot >= 0) red[par][wslot] = t4;
+          }
+        } else {
+          wave_sum_dpp_n<DOUT>(acc);
+          if (lane == 63) {
 #pragma unroll
-      for (int r = 0; r < DOUT; ++r) wsum[r] = acc[r];
-      wave_sum_dpp_n<DOUT>(wsum);
-      if (lane == 63) {
-#pragma unroll
-        for (int r = 0; r < DOUT; ++r) red[par][r * 16 + wave] = wsum[r];
-      }
-      __syncthreads();
-      if constexpr (sizeof(T) == 4) {
-        // slot r*16 + w sits in lane r*16 + w: a 16-lane DPP row reduction adds the waves, readlane makes the
-        // totals scalar (identical in every wave: same inputs, same fixed order)
-        float v0 = red[par][lane];
-        v0 = row_sum_dpp(v0);
-#pragma unroll
-        for (int r = 0; r < (DOUT < 4 ? DOUT : 4); ++r) tot[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), r * 16));
+            for (int r = 0; r < DOUT; ++r) red[par][r * 16 + wave] = acc[r];
+          }
+        }
+        __syncthreads();
+        v0 = row_sum_dpp(red[par][lane]);                          // row r of every wave: total of decoded row r
+        F0 = __builtin_fmaf(la0, F0, lb0 * v0);                    // rows without a filter: la = lb = 0
         if constexpr (DOUT > 4) {
-          float v1 = red[par][64 + lane];
-          v1 = row_sum_dpp(v1);
-#pragma unroll
-          for (int r = 4; r < DOUT; ++r) tot[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v1), (r - 4) * 16));
+          v1 = row_sum_dpp(red[par][64 + lane]);
+          F1 = __builtin_fmaf(la1, F1, lb1 * v1);
+        }
+        if (wave == 0) {
+          if ((lane & 15) == 0 && (lane >> 4) < DOUT) os[jj][lane >> 4] = v0;
+          if (DOUT > 4 && lane == 0) os[jj][4] = v1;
         }
       } else {
+        T acc[DOUT];
+#pragma unroll
+        for (int r = 0; r < DOUT; ++r) acc[r] = accg[r];
+        wave_sum_dpp_n<DOUT>(acc);
+        if (lane == 63) {
+#pragma unroll
+          for (int r = 0; r < DOUT; ++r) red[par][r * 16 + wave] = acc[r];
+        }
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < DOUT; ++r) {
           T t = T(0);
@@ -353,59 +490,14 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
           for (int w = 0; w < 16; ++w) t += red[par][r * 16 + w];
           tot[r] = t;
         }
-      }
-#endif
-      if (CLUSTER && a.P > 1) {
-        // ---- cluster exchange: publish this workgroup's partial sums as 8-byte {payload, tag = step} granules
-        //      (one atomic store each: data and flag arrive together), collect the P partials of the step, add
-        //      them in member order - every member ends up with bit-identical totals.  Two parities of slots:
-        //      a member can only publish step t+2 after every other member has read its step-t granules.
-        const unsigned int tag = (unsigned int)(a.step0 + j0 + jj + 1);
-        unsigned long long* slot = a.xch + (((size_t)k * 2 + par) * PMAX) * (DOUT * GV);
-        const int nmine = DOUT * GV, nall = a.P * DOUT * GV;
-        if (wave == 0) {
-          if (lane < nmine) {
-            const int r = lane / GV, w = lane - r * GV;
-            T v = T(0);
 #pragma unroll
-            for (int q = 0; q < DOUT; ++q) v = r == q ? tot[q] : v;
-            unsigned int bits;
-            if constexpr (GV == 1) bits = __builtin_bit_cast(unsigned int, v);
-            else { const unsigned long long u = __builtin_bit_cast(unsigned long long, v); bits = w ? (unsigned int)(u >> 32) : (unsigned int)u; }
-            __hip_atomic_store(slot + p * nmine + lane, ((unsigned long long)tag << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          if (lane < nall) {
-            unsigned long long gr = 0;
-            int spins = 0;
-            for (;;) {
-              gr = __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if ((unsigned int)(gr >> 32) == tag) break;
-              if (++spins > (1 << 22)) { *a.err = 1; break; }          // a missing member: give up, the host reports it
-              __builtin_amdgcn_s_sleep(1);
-            }
-            xt[par][lane] = (unsigned int)gr;
-          }
+        for (int r = 0; r < DOUT; ++r) fs[r] = la[r] * fs[r] + lb[r] * tot[r];    // rows without a filter: la = lb = 0
+        if (tid < DOUT) {
+          T v = T(0);
+#pragma unroll
+          for (int r = 0; r < DOUT; ++r) v = tid == r ? tot[r] : v;
+          os[jj][tid] = v;
         }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < DOUT; ++r) {
-          T t = T(0);
-          for (int q = 0; q < a.P; ++q) {
-            T v;
-            if constexpr (GV == 1) v = __builtin_bit_cast(T, xt[par][q * nmine + r]);
-            else v = __builtin_bit_cast(T, ((unsigned long long)xt[par][q * nmine + r * GV + 1] << 32) | xt[par][q * nmine + r * GV]);
-            t += v;
-          }
-          tot[r] = t;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < DOUT; ++r) fs[r] = la[r] * fs[r] + lb[r] * tot[r];    // rows without a filter: la = lb = 0
-      if (tid < DOUT) {
-        T v = T(0);
-#pragma unroll
-        for (int r = 0; r < DOUT; ++r) v = tid == r ? tot[r] : v;
-        os[jj][tid] = v;
       }
     }
   }
@@ -414,7 +506,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
     const int j0 = (a.B - 1) / CH * CH, cn = a.B - j0;
     for (int i = tid; i < cn * DOUT; i += nthr) {
       const int jj = i / DOUT, r = i - jj * DOUT;
-      if (s_out[r] && p == 0) a.bsig[(size_t)(a.row0 + j0 + jj) * a.n_sig + s_dst[r]] = os[jj][r];
+      if (s_out[r]) a.bsig[(size_t)(a.row0 + j0 + jj) * a.n_sig + s_dst[r]] = os[jj][r];
     }
   }
 
@@ -423,58 +515,77 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   asm volatile("" : "+v"(tid2));      // fresh addresses: keeps NPT pointers from staying live across the time loop
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-#pragma unroll
-    for (int c = 0; c < PK; ++c) {
-      const int i = p * cap + (g * nthr + tid2) * PK + c;
-      if (i < a.n) Sp[i] = comp(s[g], c);
-    }
+    const int i0 = (g * nthr + tid2) * PK;
+    if (i0 < a.n_pad) *reinterpret_cast<G*>(Sp + i0) = s[g];       // (padding elements of the row are never read back)
   }
-  if (tid < DOUT && a.B > 0 && p == 0) {
-    T v = T(0), f = T(0);
+  if (a.B > 0) {
+    if constexpr (F32) {
+      if (wave == 0 && (lane & 15) == 0 && (lane >> 4) < DOUT) {
+        const int r = lane >> 4;
+        a.sig_w[s_dst[r]] = v0;
+        const int st = a.lp_state[(long long)k * DOUT + r];
+        if (st >= 0) a.sig_w[st] = F0;
+      }
+      if (DOUT > 4 && tid == 0) {
+        a.sig_w[s_dst[4]] = v1;
+        const int st = a.lp_state[(long long)k * DOUT + 4];
+        if (st >= 0) a.sig_w[st] = F1;
+      }
+    } else if (tid < DOUT) {
+      T v = T(0), f = T(0);
 #pragma unroll
-    for (int r = 0; r < DOUT; ++r) { v = tid == r ? tot[r] : v; f = tid == r ? fs[r] : f; }
-    a.sig_w[s_dst[tid]] = v;
-    const int st = a.lp_state[(long long)k * DOUT + tid];
-    if (st >= 0) a.sig_w[st] = f;
+      for (int r = 0; r < DOUT; ++r) { v = tid == r ? tot[r] : v; f = tid == r ? fs[r] : f; }
+      a.sig_w[s_dst[tid]] = v;
+      const int st = a.lp_state[(long long)k * DOUT + tid];
+      if (st >= 0) a.sig_w[st] = f;
+    }
   }
 }
 
-// (workgroup size, neurons per thread, encoders in LDS) variants.  The register budget of a wave is
-// 512 / (waves per SIMD): 1024 threads -> 128 registers, 512 -> 256, 256 -> 512 (incl. AGPRs); a neuron needs
-// din + dout + 2 persistent words (10 at din 3, dout 5), 7 with the encoders in LDS.
-template <typename T, int DIN, int DOUT, int NPT, int TPB, bool ENC_LDS, bool CLUSTER = false>
+constexpr int BLOCK_LDS_BYTES = 160 * 1024, BLOCK_STATIC_LDS = 2560;     // CU capacity; bound on the kernel's static arrays
+
+template <typename T, int DIN, int DOUT, int NPT, int TPB, int LDSW>
 static hipError_t launch_block_variant(hipStream_t s, const BlockArgs<T>& a) {
-  // cluster mode is compiled only for the variants a shard of a big ensemble lands on (and the f64 test sizes)
-  constexpr bool HAS_CLUSTER = !ENC_LDS && ((sizeof(T) == 8) || (TPB == 512 && (NPT == 6 || NPT == 10)) || (TPB == 1024 && NPT <= 4));
-  if constexpr (!CLUSTER && HAS_CLUSTER) {
-    if (a.P > 1) return launch_block_variant<T, DIN, DOUT, NPT, TPB, ENC_LDS, true>(s, a);
-  }
-  if (!CLUSTER && a.P > 1) return hipErrorInvalidValue;
-  const int lds = ENC_LDS ? DIN * a.threads * NPT * (int)sizeof(T) : 0;
+  const int lds = LDSW * a.threads * NPT * (int)sizeof(T);
   static bool configured = false;
-  if (ENC_LDS && !configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ens_block<T, DIN, DOUT, NPT, TPB, ENC_LDS, CLUSTER>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, DIN * TPB * NPT * (int)sizeof(T));
+  if (LDSW > 0 && !configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ens_block<T, DIN, DOUT, NPT, TPB, LDSW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, BLOCK_LDS_BYTES - BLOCK_STATIC_LDS);
     if (e != hipSuccess) return e;
     configured = true;
   }
-  const unsigned grid = a.P > 1 ? (unsigned)((a.K + 7) / 8 * 8 * a.P) : (unsigned)a.K;
-  hipLaunchKernelGGL((k_ens_block<T, DIN, DOUT, NPT, TPB, ENC_LDS, CLUSTER>), dim3(grid), dim3((unsigned)a.threads), lds, s, a);
+  hipLaunchKernelGGL((k_ens_block<T, DIN, DOUT, NPT, TPB, LDSW>), dim3((unsigned)a.K), dim3((unsigned)a.threads), lds, s, a);
   return hipGetLastError();
 }
 
+// (workgroup size, neurons per thread, parameter rows in LDS) variants, in the order the planner tries them.  A wave's
+// register budget is 512 / (waves per SIMD): 1024 threads -> 128, 768 -> 168, 512 -> 256; a neuron keeps
+// din + dout + 2 words (9 at din 3, dout 4) of which the LDS rows take 3.  Measured on MI355X at n = 10 000
+// (tools/bench_block.py, profiles/round2_block_variants.txt): (512, 20, LDS) 3.49 ms per 1000 timesteps of config 2,
+// (768, 14, LDS) 3.68 - more waves per SIMD do not pay: every wave repeats the per-timestep reductions.
+struct BlockVariant { int tpb, npt, ldsw; };
+template <typename T> struct BlockVariants;
+template <> struct BlockVariants<float> {
+  static constexpr int N = 7;
+  static constexpr BlockVariant v[N] = {{1024, 2, 0}, {1024, 4, 0}, {512, 6, 0}, {1024, 6, 0}, {512, 10, 0}, {512, 20, 3}, {768, 14, 3}};
+};
+template <> struct BlockVariants<double> {
+  static constexpr int N = 3;
+  static constexpr BlockVariant v[N] = {{1024, 1, 0}, {1024, 2, 0}, {1024, 4, 0}};
+};
+
 template <typename T, int DIN, int DOUT>
 static hipError_t launch_block_npt(hipStream_t s, const BlockArgs<T>& a) {
-  const int key = (a.tpb * 100 + a.npt) * 2 + (a.enc_lds ? 1 : 0);
+  const int key = (a.tpb * 100 + a.npt) * 8 + a.enc_lds;
   switch (key) {
-#define SSN_CASE(TPB, N, L) case (TPB * 100 + N) * 2 + L: return launch_block_variant<T, DIN, DOUT, N, TPB, (L != 0)>(s, a);
+#define SSN_CASE(TPB, N, L) case (TPB * 100 + N) * 8 + L: return launch_block_variant<T, DIN, DOUT, N, TPB, L>(s, a);
     SSN_CASE(1024, 2, 0) SSN_CASE(1024, 4, 0)
 #undef SSN_CASE
-#define SSN_CASE(TPB, N, L) case (TPB * 100 + N) * 2 + L: if constexpr (sizeof(T) == 8) return launch_block_variant<T, DIN, DOUT, N, TPB, (L != 0)>(s, a); else return hipErrorInvalidValue;
+#define SSN_CASE(TPB, N, L) case (TPB * 100 + N) * 8 + L: if constexpr (sizeof(T) == 8) return launch_block_variant<T, DIN, DOUT, N, TPB, L>(s, a); else return hipErrorInvalidValue;
     SSN_CASE(1024, 1, 0)
 #undef SSN_CASE
-#define SSN_CASE(TPB, N, L) case (TPB * 100 + N) * 2 + L: if constexpr (sizeof(T) == 4) return launch_block_variant<T, DIN, DOUT, N, TPB, (L != 0)>(s, a); else return hipErrorInvalidValue;
-    SSN_CASE(1024, 6, 0) SSN_CASE(512, 6, 0) SSN_CASE(512, 10, 0) SSN_CASE(1024, 10, 1) SSN_CASE(768, 14, 1) SSN_CASE(512, 16, 0) SSN_CASE(512, 20, 0) SSN_CASE(512, 20, 1) SSN_CASE(256, 40, 0)
+#define SSN_CASE(TPB, N, L) case (TPB * 100 + N) * 8 + L: if constexpr (sizeof(T) == 4) return launch_block_variant<T, DIN, DOUT, N, TPB, L>(s, a); else return hipErrorInvalidValue;
+    SSN_CASE(1024, 6, 0) SSN_CASE(512, 6, 0) SSN_CASE(512, 10, 0) SSN_CASE(512, 20, 3) SSN_CASE(768, 14, 3)
 #undef SSN_CASE
     default: return hipErrorInvalidValue;
   }
@@ -483,19 +594,18 @@ static hipError_t launch_block_npt(hipStream_t s, const BlockArgs<T>& a) {
 template <typename T>
 bool ens_block_supported(int din, int dout, int n, int* threads, int* tpb, int* npt, int* enc_lds) {
   if (!(din == 3 && dout >= 3 && dout <= 5)) return false;
-  struct V { int tpb, npt, lds; };
-  const V f32v[] = {{1024, 2, 0}, {1024, 4, 0}, {512, 6, 0}, {1024, 6, 0}, {512, 10, 0}, {512, 20, 1}, {1024, 10, 1}, {768, 14, 1}, {256, 40, 0}, {512, 16, 0}, {512, 20, 0}};
-  const V f64v[] = {{1024, 1, 0}, {1024, 2, 0}, {1024, 4, 0}};
-  const V* vs = sizeof(T) == 4 ? f32v : f64v;
-  const int nv = sizeof(T) == 4 ? 11 : 3;
   int want_tpb = 0, want_npt = 0, want_lds = 0;
   if (const char* env = getenv("SSN_BLOCK_VARIANT")) sscanf(env, "%d,%d,%d", &want_tpb, &want_npt, &want_lds);   // tuning knob
-  for (int i = 0; i < nv; ++i) {
-    if (want_tpb && (vs[i].tpb != want_tpb || vs[i].npt != want_npt || vs[i].lds != want_lds)) continue;
-    int th = vs[i].tpb;
-    const int pk = sizeof(T) == 4 ? 2 : 1;         // neurons per group; single-group variants run n / pk threads
-    if (vs[i].npt == pk && n < th * pk) th = std::max(64, ((n + pk - 1) / pk + 63) / 64 * 64);
-    if ((int64_t)th * vs[i].npt >= n) { *threads = th; *tpb = vs[i].tpb; *npt = vs[i].npt; *enc_lds = vs[i].lds; return true; }
+  const int pk = sizeof(T) == 4 ? 2 : 1;         // neurons per group; single-group variants run n / pk threads
+  for (int i = 0; i < BlockVariants<T>::N; ++i) {
+    const BlockVariant v = BlockVariants<T>::v[i];
+    if (want_tpb && (v.tpb != want_tpb || v.npt != want_npt || v.ldsw != want_lds)) continue;
+    int th = v.tpb;
+    if (v.npt == pk && n < th * pk) th = std::max(64, ((n + pk - 1) / pk + 63) / 64 * 64);
+    if ((int64_t)th * v.npt < n) continue;
+    if ((int64_t)v.ldsw * th * v.npt * (int64_t)sizeof(T) > BLOCK_LDS_BYTES - BLOCK_STATIC_LDS) continue;
+    *threads = th; *tpb = v.tpb; *npt = v.npt; *enc_lds = v.ldsw;
+    return true;
   }
   return false;
 }

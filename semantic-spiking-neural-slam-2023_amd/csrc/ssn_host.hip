@@ -87,6 +87,7 @@ struct ssn_sim {
   virtual int rw_signal(int64_t off, int64_t count, double* dst, const double* src) = 0;
   virtual int rw_buffer(int id, double* dst, const double* src, int64_t count) = 0;
   virtual int counters(ssn_counters* out) = 0;
+  virtual int kernel_times(ssn_kernel_time* out, int capacity) = 0;
   virtual int64_t n_steps() = 0;
 };
 
@@ -137,7 +138,6 @@ struct Sim final : ssn_sim {
   ssn::FinishArgs<T> fin_begin, fin_flush;
   bool fused_block = false;                   // ... stepped a whole block per launch: [k_ens_block] (ssn_block.hpp)
   ssn::BlockArgs<T> blk;
-  int64_t blk_xch_bytes = 0;
   std::vector<void*> fused_bufs;
   std::set<int> sparse_w;                     // decoder buffers multiplied with a LIF spike vector
   std::vector<std::pair<int64_t, std::pair<int*, int*>>> spike_lists;   // spike signal offset -> (list, count)
@@ -190,6 +190,9 @@ struct Sim final : ssn_sim {
   double dom_bytes = 0.0;
   int64_t dom_units = 0;
   int launches_per_step = 0;
+  static constexpr int N_ITEM_TYPES = 16;
+  double type_ms[N_ITEM_TYPES] = {};             // profile = 2: device time per plan-item type
+  int64_t type_launches[N_ITEM_TYPES] = {};
 
   ~Sim() override {
     hipSetDevice(device);
@@ -308,7 +311,8 @@ struct Sim final : ssn_sim {
       if (e == hipSuccess) e = ssn::launch_dec_pack<T>(stream, (const T*)b.d, tmp, b.dec_K, b.dec_dout, b.dec_n, (int)b.ld, b.dec_DP, 1);
     } else {
       const T* words = (const T*)(b.packed == 2 ? bufs[b.partner].d : b.d);
-      e = ssn::launch_state_unpack<T>(stream, words, tmp, b.rows * b.ld, b.packed == 2);
+      // (the f32 whole-block kernel keeps -(R - dt) in the state word of a refractory neuron, every other kernel -R)
+      e = ssn::launch_state_unpack<T>(stream, words, tmp, b.rows * b.ld, b.packed == 2, (fused_block && sizeof(T) == 4) ? (T)dt : T(0));
     }
     int rc = e == hipSuccess ? download(tmp, dst, b.rows, b.cols, b.ld) : SSN_OK;
     hipFree(tmp);
@@ -672,26 +676,12 @@ struct Sim final : ssn_sim {
     }
     // ---- plan A: the ensembles are independent inside a block -> one k_ens_block launch per block -----
     int blk_threads = 0, blk_tpb = 0, blk_npt = 0, blk_lds = 0;
-    // cluster size: with few ensembles per GPU (multi-GPU shards) P workgroups could split one ensemble's neurons
-    // (every workgroup of the grid must then be resident at once: they wait for each other every timestep)
-    int blk_P = 1;
-    {
-      hipDeviceProp_t prop;
-      int n_cu = 256;
-      if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-      const int64_t k8 = (K + 7) / 8 * 8;
-      // Measured on MI355X (tools/bench_shard.py, 127- and 64-VCO shards of config 2): one workgroup per VCO
-      // 2.95 us/step, P = 2: 3.3, P = 4: 3.6 - the per-step exchange (~1.6 us) costs more than the halved neuron
-      // work saves, so clusters are never chosen automatically.
-      if (const char* env = getenv("SSN_BLOCK_CLUSTER")) {           // experiment / test knob
-        const int want = atoi(env);
-        if ((want == 1 || want == 2 || want == 4) && k8 * want <= n_cu) blk_P = want;
-      }
-    }
-    const int pk = sizeof(T) == 4 ? 2 : 1;
-    const int n_share = (int)(((eo.i[2] + blk_P - 1) / blk_P + pk - 1) / pk * pk);
-    if (defer && !(flags & 128) && ens_fast(eo) && (sizeof(T) == 8 || (dt <= 0.125 * eo.f[0] && eo.f[1] >= dt)) &&
-        ssn::ens_block_supported<T>((int)din, (int)dout, n_share, &blk_threads, &blk_tpb, &blk_npt, &blk_lds)) {
+    // (One workgroup steps one ensemble.  Splitting an ensemble over P workgroups that exchange partial sums through L2
+    //  every timestep was built and measured in round 1 - 3.3 us per timestep at P = 2 and 3.6 at P = 4 against 2.95 for
+    //  one workgroup on 127- / 64-VCO shards: a cross-CU round trip costs ~1.6 us, more than halving the neuron work
+    //  saves - and removed in round 2: DESIGN.md section 5.)
+    if (defer && !(flags & 128) && ens_fast(eo) && (sizeof(T) == 8 || (dt <= 0.05 * eo.f[0] && eo.f[1] >= dt)) &&
+        ssn::ens_block_supported<T>((int)din, (int)dout, (int)eo.i[2], &blk_threads, &blk_tpb, &blk_npt, &blk_lds)) {
       const int64_t nr = K * dout;
       int* d_lp = nullptr; T* d_a = nullptr; T* d_b = nullptr; unsigned char* d_ro = nullptr; int* d_xrow = nullptr; T* d_xalpha = nullptr;
       if ((*rc = dmalloc(&d_lp, nr * 4)) != SSN_OK) return true;
@@ -719,18 +709,6 @@ struct Sim final : ssn_sim {
       blk.B = 0; blk.row0 = 1; blk.threads = blk_threads; blk.tpb = blk_tpb; blk.npt = blk_npt; blk.enc_lds = blk_lds;
       blk.dec_neuron_major = ea.fast == 1 ? 1 : 0;
       blk.np = ea.np;
-      blk.P = blk_P; blk.step0 = 0;
-      if (blk_P > 1 && (int64_t)blk_threads * blk_npt * blk_P < ea.n) return false;      // (single-group variants shrink the workgroup)
-      {
-        const int64_t xb = (int64_t)K * 2 * 4 * dout * (int64_t)(sizeof(T) / 4) * 8;
-        unsigned long long* d_x = nullptr; int* d_err = nullptr;
-        if ((*rc = dmalloc(&d_x, xb)) != SSN_OK) return true;
-        if ((*rc = dmalloc(&d_err, 64)) != SSN_OK) return true;
-        hipMemset(d_x, 0, (size_t)xb);
-        hipMemset(d_err, 0, 64);
-        fused_bufs.insert(fused_bufs.end(), {(void*)d_x, (void*)d_err});
-        blk.xch = d_x; blk.err = d_err; blk_xch_bytes = xb;
-      }
       dom_units = (int64_t)ea.K * ea.n * block;
       dom_bytes = (double)dom_units * (ea.din + ea.dout + 5) * sizeof(T);
       fused_core = fused_block = true;
@@ -1813,8 +1791,11 @@ struct Sim final : ssn_sim {
     int n_dom = 0;
     for (auto& it : items) n_dom += it.dominant ? 1 : 0;
     size_t ev_used = 0;
+    std::vector<int> ev_types;                  // profile = 2: plan-item type of each event pair
+    if (profile == 2 && (fused_block || core_empty)) profile = 1;
     if (profile) {
-      const size_t need = fused_block ? (size_t)(2 * (n / std::max(1, block) + 2)) : (size_t)(2 * n * std::max(1, n_dom));
+      const size_t need = fused_block ? (size_t)(2 * (n / std::max(1, block) + 2))
+                                      : (size_t)(2 * n * (profile == 2 ? (int)items.size() : std::max(1, n_dom)));
       if (need > 400000) return fail(SSN_EINVAL, "profile run too long (%lld steps): at most 200000 timed launches", (long long)n);
       while (ev_pool.size() < need) {
         hipEvent_t ev;
@@ -1837,7 +1818,6 @@ struct Sim final : ssn_sim {
       if (fused_block) {
         const bool timed = profile && B == block && ev_used + 2 <= ev_pool.size();
         blk.B = (int)B;
-        blk.step0 = step0;
         if (timed) HIPCHK(hipEventRecord(ev_pool[ev_used], stream));
         HIPCHK(ssn::launch_ens_block<T>(stream, blk));
         if (timed) { HIPCHK(hipEventRecord(ev_pool[ev_used + 1], stream)); ev_used += 2; }
@@ -1847,6 +1827,19 @@ struct Sim final : ssn_sim {
         // nothing is stepped one timestep at a time (purely feed-forward model): just advance the clock
         hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, (long long)B);
         HIPCHK(hipGetLastError());
+      } else if (profile == 2) {
+        // every launch of every timestep between its own event pair (plain eager launches, no graph)
+        for (int64_t s = 0; s < B; ++s) {
+          for (auto& it : items) {
+            if (it.merged) continue;
+            HIPCHK(hipEventRecord(ev_pool[ev_used], stream));
+            HIPCHK(launch_item(it, nullptr, nullptr));
+            HIPCHK(hipEventRecord(ev_pool[ev_used + 1], stream));
+            ev_types.push_back(it.type);
+            ev_used += 2;
+          }
+          if (fused_defer) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, 1LL); HIPCHK(hipGetLastError()); }
+        }
       } else if (profile) {
         for (int64_t s = 0; s < B; ++s) {
           for (auto& it : items) {
@@ -1873,6 +1866,12 @@ struct Sim final : ssn_sim {
     for (size_t j = 0; j < ev_used; j += 2) {
       float ms = 0.f;
       HIPCHK(hipEventElapsedTime(&ms, ev_pool[j], ev_pool[j + 1]));
+      if (profile == 2) {
+        const int ty = ev_types[j / 2];
+        type_ms[ty] += ms;
+        type_launches[ty] += 1;
+        continue;
+      }
       dom_ms += ms;
       dom_launches += 1;
     }
@@ -1883,11 +1882,6 @@ struct Sim final : ssn_sim {
     ssn::StepCtx ctx;
     HIPCHK(hipMemcpy(&ctx, d_ctx, sizeof ctx, hipMemcpyDeviceToHost));
     if (ctx.step != steps_done) return fail(SSN_EHIP, "device step counter %lld != host %lld", (long long)ctx.step, (long long)steps_done);
-    if (fused_block && blk.P > 1) {
-      int err = 0;
-      HIPCHK(hipMemcpy(&err, blk.err, 4, hipMemcpyDeviceToHost));
-      if (err) return fail(SSN_EHIP, "k_ens_block: a workgroup of a %d-workgroup cluster never arrived (grid not fully resident?)", blk.P);
-    }
     if (ctx.probe_overflow) return fail(SSN_EINVAL, "probe storage overflow: call ssn_reserve_probes before ssn_run_steps");
     return SSN_OK;
   }
@@ -1899,13 +1893,13 @@ struct Sim final : ssn_sim {
     for (auto& b : bufs)
       if (b.keep) CHK(upload_buf(b, b.host.data()));
     HIPCHK(hipMemset(d_ctx, 0, sizeof(ssn::StepCtx)));
-    if (fused_block && blk.xch) HIPCHK(hipMemset(blk.xch, 0, (size_t)blk_xch_bytes));     // exchange tags restart with the clock
     CHK(init_bsig());
     steps_done = 0;
     reserve_first = reserve_n = 0;
     for (auto& s : pslots) { s.base_slot = 0; s.capacity = 0; }
     if (!pslots.empty()) HIPCHK(hipMemcpy(d_pslots, pslots.data(), pslots.size() * sizeof(ssn::ProbeSlot), hipMemcpyHostToDevice));
     dom_launches = 0; dom_ms = 0.0;
+    for (int t = 0; t < N_ITEM_TYPES; ++t) { type_ms[t] = 0.0; type_launches[t] = 0; }
     return SSN_OK;
   }
 
@@ -2025,6 +2019,23 @@ struct Sim final : ssn_sim {
     return SSN_OK;
   }
 
+  int kernel_times(ssn_kernel_time* out, int capacity) override {
+    static const char* names[N_ITEM_TYPES] = {"k_program", "k_ensarray", "k_matvec", "k_neurons", "k_pes", "k_voja", "k_matvec_ordered",
+                                              "k_ens_finish", "k_spmv_partial", "k_neurons_compact", "k_dft", "k_spmv_rows", "k_vecops",
+                                              "k_grid_lhs", "k_gemm_nt_mfma_f32", "k_argmax_partial"};
+    int n = 0;
+    for (int t = 0; t < N_ITEM_TYPES; ++t) {
+      if (!type_launches[t]) continue;
+      if (n < capacity) {
+        snprintf(out[n].name, sizeof out[n].name, "%s", names[t]);
+        out[n].launches = type_launches[t];
+        out[n].ms_total = type_ms[t];
+      }
+      ++n;
+    }
+    return n;
+  }
+
   int64_t n_steps() override { return steps_done; }
 };
 
@@ -2099,6 +2110,10 @@ int ssn_write_buffer(ssn_sim* sim, int32_t id, const double* src, int64_t count)
 int ssn_get_counters(ssn_sim* sim, ssn_counters* out) {
   if (!sim || !out) return fail(SSN_EINVAL, "null argument");
   return sim->counters(out);
+}
+int ssn_get_kernel_times(ssn_sim* sim, ssn_kernel_time* out, int32_t capacity) {
+  if (!sim || (!out && capacity > 0) || capacity < 0) return fail(SSN_EINVAL, "null argument");
+  return sim->kernel_times(out, capacity);
 }
 int64_t ssn_n_steps(ssn_sim* sim) { return sim ? sim->n_steps() : -1; }
 int ssn_device_count(void) {

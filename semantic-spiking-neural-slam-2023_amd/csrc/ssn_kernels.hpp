@@ -332,18 +332,19 @@ hipError_t launch_dec_pack(hipStream_t s, const T* src, T* dst, int K, int dout,
   return hipGetLastError();
 }
 
-// packed LIF state word -> (voltage, refractory time) for ssn_read_buffer
+// packed LIF state word -> (voltage, refractory time) for ssn_read_buffer; r_offset: what a negative word leaves out of
+// the refractory time (0, or dt for the f32 whole-block kernel's words)
 template <typename T>
-__global__ void k_state_unpack(const T* __restrict__ s, T* __restrict__ out, int64_t n, int want_refractory) {
+__global__ void k_state_unpack(const T* __restrict__ s, T* __restrict__ out, int64_t n, int want_refractory, T r_offset) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const T v = s[i];
-  out[i] = want_refractory ? (v < T(0) ? -v : T(0)) : (v < T(0) ? T(0) : v);
+  out[i] = want_refractory ? (v < T(0) ? r_offset - v : T(0)) : (v < T(0) ? T(0) : v);
 }
 template <typename T>
-hipError_t launch_state_unpack(hipStream_t s, const T* src, T* out, int64_t n, int want_refractory) {
+hipError_t launch_state_unpack(hipStream_t s, const T* src, T* out, int64_t n, int want_refractory, T r_offset) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL((k_state_unpack<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, out, n, want_refractory);
+  hipLaunchKernelGGL((k_state_unpack<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, out, n, want_refractory, r_offset);
   return hipGetLastError();
 }
 
@@ -1674,7 +1675,7 @@ namespace ssn {
   template hipError_t launch_ensarray<T>(hipStream_t, const EnsArgs<T>&);                                    \
   template hipError_t launch_ensarray_batch<T>(hipStream_t, const EnsBatch<T>&, int);                        \
   template hipError_t launch_dec_pack<T>(hipStream_t, const T*, T*, int, int, int, int, int, int);           \
-  template hipError_t launch_state_unpack<T>(hipStream_t, const T*, T*, int64_t, int);                       \
+  template hipError_t launch_state_unpack<T>(hipStream_t, const T*, T*, int64_t, int, T);                    \
   template hipError_t launch_program<T>(hipStream_t, const MicroOp<T>*, const ProgDesc*, int, const ProgSeg*, int, T*, StepCtx*); \
   template hipError_t program_set_max_lds<T>(int);                                                          \
   template hipError_t launch_vecops<T>(hipStream_t, const MicroOp<T>*, int, int, T*, const StepCtx*);        \

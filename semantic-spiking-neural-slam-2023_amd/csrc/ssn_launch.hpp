@@ -107,10 +107,6 @@ struct BlockArgs {
   int threads, tpb, npt;   // workgroup size, kernel variant (launch bound, neurons per thread): threads * npt >= n
   int dec_neuron_major;
   int enc_lds;         // kernel variant keeps the encoders in LDS instead of registers
-  int P;               // workgroups per ensemble (cluster mode when > 1; n <= P * threads * npt)
-  long long step0;     // absolute number of the launch's first timestep (exchange tags)
-  unsigned long long* xch;   // cluster exchange granules [K][2][4][dout * sizeof(T)/4]
-  int* err;            // set to 1 when a cluster member never showed up
   NeuronParams<T> np;
 };
 
@@ -203,7 +199,7 @@ template <typename T> hipError_t launch_batch_elementwise(hipStream_t, const Bat
 template <typename T> hipError_t launch_ensarray(hipStream_t, const EnsArgs<T>&);
 template <typename T> hipError_t launch_ensarray_batch(hipStream_t, const EnsBatch<T>&, int count);   // equal din / dout / variant
 template <typename T> hipError_t launch_dec_pack(hipStream_t, const T* src, T* dst, int K, int dout, int n, int n_pad, int DP, int unpack);
-template <typename T> hipError_t launch_state_unpack(hipStream_t, const T* src, T* out, int64_t n, int want_refractory);
+template <typename T> hipError_t launch_state_unpack(hipStream_t, const T* src, T* out, int64_t n, int want_refractory, T r_offset);
 template <typename T> hipError_t launch_ens_finish(hipStream_t, const FinishArgs<T>&);
 template <typename T> hipError_t launch_dft(hipStream_t, const DftBatch&, int count);   // (T only selects the translation unit)
 template <typename T> hipError_t launch_ens_block(hipStream_t, const BlockArgs<T>&);

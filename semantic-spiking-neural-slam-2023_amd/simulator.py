@@ -357,7 +357,7 @@ class Simulator:
             for _, p in buf_probes:          # stop before the next timestep whose sample is due (taken at the top of the loop)
                 r = (self.n_steps + 1) % p["every"]
                 chunk = min(chunk, p["every"] - r if r else p["every"])
-            self._check(self._lib.ssn_run_steps(self._h, chunk, 1 if profile else 0))
+            self._check(self._lib.ssn_run_steps(self._h, chunk, int(profile)))
             self.n_steps += chunk
             done += chunk
             if worker is not None:
@@ -447,6 +447,14 @@ class Simulator:
         c = _lib.Counters()
         self._check(self._lib.ssn_get_counters(self._h, C.byref(c)))
         return {f: getattr(c, f) for f, _ in c._fields_}
+
+    def kernel_times(self):
+        """{kernel name: (launches, total ms)} of the launches timed by ``run_steps(..., profile=2)``."""
+        arr = (_lib.KernelTime * 32)()
+        n = self._lib.ssn_get_kernel_times(self._h, arr, 32)
+        if n < 0:
+            self._check(n)
+        return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].ms_total)) for i in range(min(n, 32))}
 
     def reset(self, seed=None):
         self._check(self._lib.ssn_reset(self._h))

@@ -276,10 +276,24 @@ def stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=Tru
         probe_stage.append(max(st) if st else POST)
     probe_need = _merge_ranges([(p["src"], p["src"] + p["width"]) for p, s in zip(model.probes, probe_stage)
                                 if "src" in p and s == POST])
+    all_w = sig_ranges(lambda o: True, (0, 1, 3))
+
+    def bridge(ranges):
+        """Join neighbouring ranges across gaps nobody ever writes (decoded rows dropped as dead, builder._live_elements):
+        handing such constant elements over with their neighbours is harmless, and the device copies one range, not one
+        per ensemble."""
+        out_r = []
+        for lo, hi in ranges:
+            if out_r and not _intersect([(out_r[-1][1], lo)], all_w):
+                out_r[-1] = (out_r[-1][0], hi)
+            else:
+                out_r.append((lo, hi))
+        return out_r
+
     model.stage_info = {
         "enabled": bool(enable and any(o["stage"] != CORE for o in out)),
-        "pre_to_core": _intersect(pre_w, core_need),
-        "core_to_post": _intersect(core_w, _merge_ranges(post_need + probe_need)),
+        "pre_to_core": bridge(_intersect(pre_w, core_need)),
+        "core_to_post": bridge(_intersect(core_w, _merge_ranges(post_need + probe_need))),
         "probe_stage": probe_stage,
         "n_pre": sum(o["stage"] == PRE for o in out), "n_core": sum(o["stage"] == CORE for o in out),
         "n_post": sum(o["stage"] == POST for o in out),

@@ -22,12 +22,25 @@ def test_pi_lowers_to_a_handful_of_merged_ops(pi_model):
     assert kinds.count("ensarray") == 1 and kinds.count("matvec") == 3       # to_Fourier, velocity (stacked), to_SSP
     assert len(m.ops) <= 40 and m.stats["n_raw_ops"] > 100                    # 27 VCOs' worth of ops merged
     ens = next(o for o in m.ops if o["kind"] == "ensarray")
-    assert (ens["K"], ens["n"], ens["din"], ens["dout"]) == (28, 40, 3, 5)
+    assert (ens["K"], ens["n"], ens["din"], ens["dout"]) == (28, 40, 3, 4)
     vel = [o for o in m.ops if o["kind"] == "matvec" and o["cols"] == 2]
     assert len(vel) == 1 and vel[0]["rows"] == 81                            # 27 stacked 3x2 velocity transforms
-    # the third (omega) row of the feedback function is identically zero and was dropped
+    # the third (omega) row of the feedback function is identically zero and was dropped; so was the omega row of the
+    # identity output: to_SSP (reference get_from_Fourier, pathintegration.py:824-844) has a zero column for it and
+    # nothing else reads or probes it (dead decoded rows, builder._live_elements)
     dec = m.buffers[ens["dec"]]
-    assert dec.shape == (28, 5, 40) and np.all(dec[0, 3:] == 0) and np.any(dec[1, 4] != 0)
+    assert dec.shape == (28, 4, 40) and np.all(dec[0, 1:] == 0) and np.any(dec[1, 3] != 0)
+    assert m.stats["dead_decoded_rows"] == 29            # 28 frequency rows + the imaginary part of the zero-frequency VCO
+
+
+def test_a_probed_or_used_decoded_row_stays(pi_model):
+    """The frequency dimension of oscillators.output is dropped only while nothing can observe it."""
+    pm = small_pathint(ssp_dim=55, n=40, T=10.0, limit=0.2)
+    with pm.model:
+        nengo.Probe(pm.pathintegrator.oscillators.output[3:6], synapse=None)
+    m = build(pm.model)
+    ens = next(o for o in m.ops if o["kind"] == "ensarray")
+    assert ens["dout"] == 5 and m.stats["dead_decoded_rows"] == 28
 
 
 def test_schedule_respects_set_inc_read_update(pi_model):
@@ -65,7 +78,8 @@ def test_stage_partition_of_pathintegration(pi_model):
     assert [o["stage"] for o in m.ops] == sorted(o["stage"] for o in m.ops)          # stage-major order
     ens = next(o for o in m.ops if o["kind"] == "ensarray")
     assert info["pre_to_core"] == [(ens["x"], ens["x"] + 84)]                           # the VCO inputs
-    assert len(info["core_to_post"]) == 1 and info["core_to_post"][0][1] - info["core_to_post"][0][0] == 84
+    # (one range although the dead frequency rows leave holes in what the core writes; the last VCO's hole is cut off)
+    assert len(info["core_to_post"]) == 1 and info["core_to_post"][0][1] - info["core_to_post"][0][0] == 83
     assert info["probe_stage"] == [2]
     # batched order is a permutation; pre-update state reads are flagged
     for st in (pre, post):

@@ -2,7 +2,7 @@
 
 usage: isa_loop_count.py [--asm FILE | --src ssn_f32.hip] --kernel <mangled-name-substring> [--npt N] [--json OUT] [-- extra hipcc flags]
 
-The time loop is found structurally: the innermost loop (a label and a later branch back to it) of the kernel that
+The time loop is found structurally: the innermost loop - by the compiler's block annotations - of the kernel that
 contains the LIF step's `v_log_f32` instructions.  (Round 1's version bracketed the loop by the workgroup barriers
 around the first / last `v_log`; after a kernel change the second barrier lay outside the time loop and the count
 came out as 301 instead of 608 issue slots - VERDICT r1, roofline item.)
@@ -18,6 +18,9 @@ import subprocess
 import sys
 
 TRANS = ("v_rcp", "v_log", "v_exp", "v_rsq", "v_sqrt", "v_sin", "v_cos")
+# plain (one value per lane) f32 multiply / add / FMA: the only vector instructions a SIMD issues at its full SIMD-32 rate when
+# a second wave is resident (tools/valu_issue_rate.hip); everything else takes a quad-cycle slot
+PLAIN_FMA = ("v_fma_f32", "v_fmac_f32", "v_add_f32_e", "v_sub_f32_e", "v_mul_f32_e", "v_mac_f32")
 
 
 def classify(op):
@@ -25,6 +28,8 @@ def classify(op):
         return "trans"
     if op.startswith("v_pk_"):
         return "packed"
+    if op.startswith(PLAIN_FMA):
+        return "plain_fma"
     if op.startswith("v_"):
         return "plain"
     if op.startswith("ds_"):
@@ -36,28 +41,37 @@ def classify(op):
     return "other"
 
 
-def find_loop(body):
-    """(lo, hi) line range of the innermost loop that contains a v_log_f32."""
-    labels = {}
-    for i, l in enumerate(body):
-        m = re.match(r"^(\.LBB\d+_\d+):", l)
+def loop_lines(body):
+    """Lines of the innermost loop that contains the LIF step's v_log_f32, by the compiler's own block annotations
+    ('=>This Inner Loop Header' / 'in Loop: Header=BBx_y'): block layout need not be contiguous (the latch block of a
+    rotated loop is often placed in front of its header)."""
+    blocks = []          # (block id, loop header id or None, [lines])
+    cur = None
+    for l in body:
+        m = re.match(r"^(?:\.LBB\d+_(\d+):|; %bb\.(\d+):)(.*)$", l)
         if m:
-            labels[m.group(1)] = i
-    loops = []
-    for i, l in enumerate(body):
-        m = re.match(r"^\s+s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
-        if m and m.group(1) in labels and labels[m.group(1)] < i:
-            loops.append((labels[m.group(1)], i))
-    logs = [i for i, l in enumerate(body) if "v_log_f32" in l]
-    if not logs:
+            cur = [m.group(1) or m.group(2), None, []]
+            blocks.append(cur)
+            l_rest = m.group(3)
+        else:
+            l_rest = l
+        if cur is None:
+            continue
+        h = re.search(r"in Loop: Header=BB\d+_(\d+) Depth=(\d+)", l_rest)
+        if h:
+            cur[1] = h.group(1)
+        elif re.search(r"=>\s*This (Inner )?Loop Header", l_rest):
+            cur[1] = cur[0]
+        if not m:
+            cur[2].append(l)
+    with_log = [b for b in blocks if any("v_log_f32" in x for x in b[2])]
+    if not with_log:
         raise SystemExit("no v_log_f32 in the kernel: not an f32 LIF block kernel")
-    best = None
-    for lo, hi in loops:
-        if lo <= logs[0] and logs[-1] <= hi and (best is None or hi - lo < best[1] - best[0]):
-            best = (lo, hi)
-    if best is None:
-        raise SystemExit("no loop encloses the LIF step")
-    return best
+    heads = {b[1] for b in with_log}
+    if len(heads) != 1 or None in heads:
+        raise SystemExit(f"the LIF step is spread over loops {heads}")
+    head = heads.pop()
+    return head, [x for b in blocks if b[1] == head for x in b[2]]
 
 
 def main():
@@ -67,6 +81,8 @@ def main():
     ap.add_argument("--kernel", required=True)
     ap.add_argument("--npt", type=int, default=0, help="neurons per lane of the variant (for per-neuron figures)")
     ap.add_argument("--json")
+    ap.add_argument("--merge-into", help="JSON file {'variants': {key: counts}} to update under --variant-key")
+    ap.add_argument("--variant-key", help="'tpb,npt,ldsw' as ssn_counters reports the variant")
     ap.add_argument("extra", nargs="*")
     a = ap.parse_args()
     if a.asm:
@@ -80,9 +96,9 @@ def main():
     start = starts[0]
     end = [i for i in range(start, len(asm)) if "s_endpgm" in asm[i]][0]
     body = asm[start:end]
-    lo, hi = find_loop(body)
+    head, lines = loop_lines(body)
     c = collections.Counter()
-    for l in body[lo:hi + 1]:
+    for l in lines:
         l = l.strip()
         if not l or l[0] in ";." or l.endswith(":"):
             continue
@@ -90,10 +106,10 @@ def main():
     by_class = collections.Counter()
     for op, n in c.items():
         by_class[classify(op)] += n
-    valu = by_class["trans"] + by_class["packed"] + by_class["plain"]
-    slots4 = by_class["packed"] + by_class["plain"] + 2 * by_class["trans"]      # 4-cycle issue slots, transcendentals 2
+    valu = by_class["trans"] + by_class["packed"] + by_class["plain"] + by_class["plain_fma"]
+    slots4 = by_class["packed"] + by_class["plain"] + by_class["plain_fma"] + 2 * by_class["trans"]      # 4-cycle issue slots, transcendentals 2
     out = {
-        "kernel": a.kernel, "loop_label_line": lo, "loop_branch_line": hi,
+        "kernel": a.kernel, "loop_header_block": head,
         "instructions_per_wave_timestep": sum(c.values()), "valu_instructions": valu,
         "by_class": dict(by_class), "issue_slots_4cycle_model": slots4,
         "scratch_ops": sum(n for op, n in c.items() if op.startswith("scratch")),
@@ -109,6 +125,17 @@ def main():
     if a.json:
         with open(a.json, "w") as f:
             json.dump(out, f, indent=1)
+    if a.merge_into:
+        import os
+        doc = {"what": "instruction mix of the per-timestep loop of k_ens_block variants (tools/isa_loop_count.py on the gfx950 assembly "
+                       "of csrc/ssn_f32.hip); bench.py prices the VALU-issue roofline with it", "variants": {}}
+        if os.path.exists(a.merge_into):
+            with open(a.merge_into) as f:
+                doc = json.load(f)
+        doc["variants"][a.variant_key] = {k: v for k, v in out.items() if k != "top"}
+        doc["variants"][a.variant_key]["top"] = dict(c.most_common(25))
+        with open(a.merge_into, "w") as f:
+            json.dump(doc, f, indent=1)
 
 
 if __name__ == "__main__":
