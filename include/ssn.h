@@ -118,39 +118,31 @@ typedef struct ssn_model_desc {
   const ssn_range* pre_to_core;
   const ssn_range* core_to_post;
   int32_t block_steps;                /* timesteps per time-batched block; 0 = library default (1024, or 256 for very wide models) */
-  int32_t flags;                      /* debug / A-B switches: 1 = no fused recurrent-array core (generic programs),
+  int32_t flags;                      /* debug / A-B switches (default 0; tests check that every alternative plan gives the same results):
+                                         1 = no fused recurrent-array core (generic programs),
                                          2 = no LIF fast path (unpacked state, dense row-major decoders),
                                          4 = LIF fast path with dense decoders (no spike-sparse gather),
                                          8 = dense decoder products for dense ensembles (no k_spmv_partial),
-                                         16 = fused recurrent-array core always with a separate finish kernel,
-                                         (default: finish deferred into the next step's prologue, 1 launch per step),
-                                         32 = single-workgroup neuron kernel that also emits the spike list for
-                                              k_spmv_partial (experiment, measured 2 % slower on SLAM config 3),
+                                         16 = fused recurrent-array core always with a separate finish kernel
+                                              (default: finish deferred into the next step's prologue, 1 launch per step),
                                          128 = no whole-block kernel for a recurrent array of independent ensembles
                                               (k_ens_block): step it once per timestep (k_ensarray) instead,
                                          256 = generic plan: fork the independent branches of a timestep over several
                                               streams inside the step graph (data-hazard analysis in the planner),
-                                         1048576 = programs stay where the operator order put them (no sinking of a program
-                                              into the next one past operators that do not depend on it),
-                                         524288 = clean-up similarities always from the pass over the table (no factored grid),
-                                         262144 = one launch per element-wise operator of the time-batched stages (no batching),
-                                         131072 = the head program of a timestep is kept whole (its long first level is otherwise run
-                                              grid-wide by k_vecops, giving up the tail / head fusion),
-                                         65536 = a workgroup barrier at every level change inside a program (no barrier elision for
-                                              element-aligned dependencies between element-wise operators),
-                                         32768 = parallel branches inside the step graph: independent big operators of one scheduling
-                                              round fork over side streams during capture (experiment, measured 9 % slower),
-                                         16384 = rows-owned sparse decoder product in one launch (k_spmv_rows; experiment, measured
-                                              14 % slower on SLAM config 3 than chunk partial sums + a reduce program),
+                                         512 = no FFT kernel for DFT-structured matvecs (always multiply by the matrix),
+                                         1024 = k_spmv_partial rebuilds the spike list itself (no segmented list from k_neurons),
+                                         4096 = one launch per operator (adjacent independent operators of one kind are not batched),
                                          8192 = ensemble arrays always leave partial sums for a finish operator (no direct write
                                               when one workgroup covers an ensemble),
-                                         4096 = one launch per operator (adjacent independent operators of one kind are not batched),
-                                         2048 = chunk reduction fused into k_spmv_partial (last workgroup per row block; experiment,
-                                              measured 20 % slower on SLAM config 3: device-scope fences),
-                                         1024 = k_spmv_partial rebuilds the spike list itself (no segmented list from k_neurons),
-                                         512 = no FFT kernel for DFT-structured matvecs (always multiply by the matrix),
-                                         64 = programs stage their signal ranges through LDS (experiment, measured
-                                              5 % slower on SLAM config 3 than operating on global memory)          */
+                                         65536 = a workgroup barrier at every level change inside a program (no barrier elision for
+                                              element-aligned dependencies between element-wise operators),
+                                         131072 = the head program of a timestep is kept whole (its long first level is otherwise run
+                                              grid-wide by k_vecops, giving up the tail / head fusion),
+                                         262144 = one launch per element-wise operator of the time-batched stages (no batching),
+                                         524288 = clean-up similarities always from the pass over the table (no factored grid),
+                                         1048576 = programs stay where the operator order put them (no sinking of a program
+                                              into the next one past operators that do not depend on it).
+                                         (Round 1's opt-in experiments 32, 64, 2048, 16384, 32768 - all measured slower - were removed.) */
 } ssn_model_desc;
 
 typedef struct ssn_counters {
@@ -167,6 +159,8 @@ typedef struct ssn_counters {
   int32_t block_npt;                /* neurons per thread                                         */
   int32_t block_enc_lds;            /* 1: encoders live in LDS, 0: in registers                   */
   int32_t block_threads;            /* threads actually launched per workgroup                    */
+  int32_t fft_transforms;           /* DFT-structured matvecs of a timestep that run as k_dft (FFT) instead of the matrix */
+  int32_t fft_bluestein;            /* ... of which through Bluestein's convolution (a prime factor > 32)           */
 } ssn_counters;
 
 /* Per-kernel device time of the generic (one launch per operator) plan, collected by ssn_run_steps(profile = 2):

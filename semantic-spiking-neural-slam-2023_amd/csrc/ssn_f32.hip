@@ -1,3 +1,7 @@
 // float instantiation of the step-loop kernels: the fast mode (FMA contraction allowed).
 #include "ssn_kernels.hpp"
 namespace ssn { SSN_INSTANTIATE(float) }
+
+#ifdef SSN_PROGRAM_STAMPS
+extern "C" int ssn_debug_program_stamps(unsigned long long* out, int n) { return (int)ssn::read_program_stamps(out, n); }
+#endif

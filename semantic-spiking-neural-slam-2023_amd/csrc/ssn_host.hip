@@ -9,6 +9,7 @@
 // Every kernel reads the current step from device memory (StepCtx), which is what makes the
 // captured graph step-invariant.  There is no CPU fallback: without a HIP device ssn_create fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -71,7 +72,7 @@ struct Buf {
   int64_t ldt = 0;
 };
 
-enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_NEURONS_COMPACT, IT_DFT, IT_SPMV_ROWS, IT_VECOPS, IT_GRID_LHS, IT_GRID_GEMM, IT_ARGMAX_PART };
+enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_DFT, IT_VECOPS, IT_GRID_LHS, IT_GRID_GEMM, IT_ARGMAX_PART };
 
 }  // namespace
 
@@ -112,7 +113,6 @@ struct Sim final : ssn_sim {
     ssn::NeuronParams<T> np;
     int* list = nullptr; int* count = nullptr;     // spike list (k_neurons_compact -> k_spmv_partial)
     int seg = 0;                                   // > 0: segmented spike list (k_neurons), segments per spmv chunk
-    T* out = nullptr; unsigned int* tickets = nullptr;   // spmv with the chunk reduction fused in (writes the signal itself)
     int level = -1;                                // scheduling round of the operator (builder): equal level = independent
     int batch = 1;                                 // this item and the next batch-1 items (same kind, independent) share one launch
     bool merged = false;                           // launched by the item that leads its batch
@@ -149,11 +149,7 @@ struct Sim final : ssn_sim {
   std::vector<MOp> mops;                     // [head][middle programs...][tail][head copy]
   MOp* d_mops = nullptr;
   std::vector<ssn::ProgDesc> prog_descs;     // one per program (+ a copy of the head behind the tail)
-  std::vector<ssn::ProgSeg> prog_segs;
-  std::vector<int> prog_lds;                 // dynamic LDS bytes per program launch
   ssn::ProgDesc* d_progs = nullptr;
-  ssn::ProgSeg* d_segs = nullptr;
-  static constexpr int LDS_CAP = 128 * 1024;
   std::vector<std::pair<const void*, std::pair<const int32_t*, int64_t>>> host_idx;   // device idx ptr -> host copy
   int head_begin = 0, head_count = 0, tail_begin = 0, tail_count = 0;
   bool can_fuse = false;
@@ -164,8 +160,6 @@ struct Sim final : ssn_sim {
   std::vector<MOp> vecops_host;               // operators of the grid-wide first level (IT_VECOPS), host copy
   std::vector<hipStream_t> side_streams;
   std::vector<hipEvent_t> dag_events;
-  bool capturing_rounds = false;              // launch_steps: fork independent big operators of one round over side streams
-  size_t round_ev = 0;
   ssn::StepCtx* d_ctx = nullptr;
   std::vector<ssn::TableSlot> tables;
   ssn::TableSlot* d_tables = nullptr;
@@ -193,6 +187,8 @@ struct Sim final : ssn_sim {
   static constexpr int N_ITEM_TYPES = 16;
   double type_ms[N_ITEM_TYPES] = {};             // profile = 2: device time per plan-item type
   int64_t type_launches[N_ITEM_TYPES] = {};
+  std::vector<double> item_ms;                   // ... and per plan item (printed under SSN_DEBUG_PLAN)
+  std::vector<int64_t> item_n;
 
   ~Sim() override {
     hipSetDevice(device);
@@ -215,7 +211,6 @@ struct Sim final : ssn_sim {
     if (bsig) hipFree(bsig);
     if (d_mops) hipFree(d_mops);
     if (d_progs) hipFree(d_progs);
-    if (d_segs) hipFree(d_segs);
     if (d_ctx) hipFree(d_ctx);
     if (d_tables) hipFree(d_tables);
     if (d_pslots) hipFree(d_pslots);
@@ -373,7 +368,7 @@ struct Sim final : ssn_sim {
       for (int i = 0; i < m->n_ops; ++i) {
         const ssn_op_desc& o = m->ops[i];
         if (o.kind != SSN_OP_MATVEC || o.stage != 1 || is_micro(o) || o.i[3] < 128) continue;
-        if (o.i[3] > 15000 && (flags & (32 | 1024))) continue;      // (the in-kernel / single-workgroup spike lists live in LDS)
+        if (o.i[3] > 15000 && (flags & 1024)) continue;      // (a spike list rebuilt inside k_spmv_partial lives in LDS)
         for (int j = 0; j < m->n_ops; ++j) {
           const ssn_op_desc& q = m->ops[j];
           if (q.kind == SSN_OP_NEURONS && q.i[5] == SSN_LIF && q.i[1] == o.i[1] && q.i[2] == o.i[3]) sparse_w.insert((int)o.i[4]);
@@ -554,30 +549,98 @@ struct Sim final : ssn_sim {
     ens_chunking(a);
   }
 
-  // FFT plan of a DFT-structured matvec: radices (<= 32 each) and the twiddle table; N = 0 when d has a larger
-  // prime factor (97, 1801, ... : the matrix is used then).
+  // FFT plan of a DFT-structured matvec: radices (<= 32 each; runs of small primes are merged into radices <= 16, one
+  // stage and one workgroup barrier each) and the twiddle table.  A length with a prime factor > 32 (97, 1801,
+  // 2049 = 3 * 683) is planned as Bluestein's convolution of smooth length M >= 2d - 1.  N = 0 when no plan fits
+  // (LDS: 24 B per point of the longest transform, 32-bit index products) - the matrix is used then.
+  static std::vector<int> smooth_radices(int L) {
+    std::vector<int> primes;
+    int rest = L;
+    for (int p = 2; p <= 32 && rest > 1; ++p)
+      while (rest % p == 0) { primes.push_back(p); rest /= p; }
+    if (rest != 1) return {};
+    std::sort(primes.begin(), primes.end());
+    std::vector<int> rad;
+    for (size_t i = 0; i < primes.size();) {           // greedy merge of ascending primes while the product stays <= 16
+      int r = primes[i++];
+      while (i < primes.size() && r * primes[i] <= 16) r *= primes[i++];
+      rad.push_back(r);
+    }
+    std::sort(rad.rbegin(), rad.rend());
+    return rad;
+  }
+
+  int dft_table(int key, const std::vector<float2>& h, float2** out) {
+    for (auto& t : dft_tables) if (t.first == key) { *out = t.second; return SSN_OK; }
+    float2* d = nullptr;
+    CHK(dmalloc(&d, (int64_t)h.size() * (int64_t)sizeof(float2)));
+    HIPCHK(hipMemcpy(d, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice));
+    scratch_bufs.push_back(d);
+    dft_tables.push_back({key, d});
+    *out = d;
+    return SSN_OK;
+  }
+
+  static std::vector<float2> twiddles(int L) {
+    std::vector<float2> h((size_t)L);
+    for (int k = 0; k < L; ++k) {
+      const double ang = -2.0 * M_PI * (double)k / (double)L;
+      h[(size_t)k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    return h;
+  }
+
   int plan_dft(const ssn_op_desc& o, ssn::DftArgs* a) {
     const int kind = (int)o.i[6];
     const int d = kind == 5 ? (int)o.i[2] : (int)o.i[3];
     *a = ssn::DftArgs{};
-    std::vector<int> rad;
-    int rest = d;
-    for (int p = 2; p <= 32 && rest > 1; ++p)
-      while (rest % p == 0) { rad.push_back(p); rest /= p; }
-    if (rest != 1 || rad.size() > 12 || d < 8 || d > 6400) return SSN_OK;      // (6400: LDS 24 B per point, 32-bit index products)
-    std::sort(rad.rbegin(), rad.rend());
-    float2* tw = nullptr;
-    for (auto& t : dft_tables) if (t.first == d) tw = t.second;
-    if (!tw) {
-      std::vector<float2> h((size_t)d);
-      for (int k = 0; k < d; ++k) {
-        const double ang = -2.0 * M_PI * (double)k / (double)d;
-        h[(size_t)k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    if (d < 8 || d > 6400) return SSN_OK;
+    std::vector<int> rad = smooth_radices(d);
+    int L = d, M = 0;
+    if (rad.empty()) {
+      for (M = 2 * d - 1; M <= 6400 && smooth_radices(M).empty(); ++M) {}
+      if (M > 6400) return SSN_OK;
+      // prefer 2^a 3^b 5^c lengths (few, small radices): the next such length within 12 % is taken instead
+      for (int c = M; c <= 6400 && c <= M + M / 8; ++c) {
+        int r = c;
+        for (int p : {2, 3, 5}) while (r % p == 0) r /= p;
+        if (r == 1) { M = c; break; }
       }
-      CHK(dmalloc(&tw, (int64_t)d * (int64_t)sizeof(float2)));
-      HIPCHK(hipMemcpy(tw, h.data(), (size_t)d * sizeof(float2), hipMemcpyHostToDevice));
-      scratch_bufs.push_back(tw);
-      dft_tables.push_back({d, tw});
+      rad = smooth_radices(M);
+      L = M;
+    }
+    if (rad.empty() || rad.size() > 12) return SSN_OK;
+    float2* tw = nullptr;
+    CHK(dft_table(L, twiddles(L), &tw));
+    if (M > 0) {
+      // chirp w_n = exp(-i pi n^2 / d) with the phase reduced exactly (n^2 mod 2d), and the spectrum of its wrapped conjugate
+      std::vector<float2> w((size_t)d);
+      std::vector<double> br((size_t)M, 0.0), bi((size_t)M, 0.0);
+      for (int n = 0; n < d; ++n) {
+        const long long q = ((long long)n * n) % (2LL * d);
+        const double ang = -M_PI * (double)q / (double)d;
+        w[(size_t)n] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        br[(size_t)n] = std::cos(ang); bi[(size_t)n] = -std::sin(ang);
+        if (n) { br[(size_t)(M - n)] = std::cos(ang); bi[(size_t)(M - n)] = -std::sin(ang); }
+      }
+      std::vector<float2> fb((size_t)M);
+      std::vector<double> cs((size_t)M), sn((size_t)M);
+      for (int k = 0; k < M; ++k) { cs[(size_t)k] = std::cos(-2.0 * M_PI * k / M); sn[(size_t)k] = std::sin(-2.0 * M_PI * k / M); }
+      std::vector<int> nzn;
+      for (int n = 0; n < M; ++n) if (br[(size_t)n] != 0.0 || bi[(size_t)n] != 0.0) nzn.push_back(n);
+      for (int k = 0; k < M; ++k) {                     // plain O(M d) double DFT, once per length at build time (M <= 6400)
+        double sr = 0.0, si = 0.0;
+        for (int n : nzn) {
+          const size_t q = (size_t)(((long long)k * n) % M);
+          sr += br[(size_t)n] * cs[q] - bi[(size_t)n] * sn[q];
+          si += br[(size_t)n] * sn[q] + bi[(size_t)n] * cs[q];
+        }
+        fb[(size_t)k] = make_float2((float)(sr / M), (float)(si / M));
+      }
+      float2* dw = nullptr; float2* dfb = nullptr;
+      CHK(dft_table(-d, w, &dw));
+      CHK(dft_table(-(1 << 20) - d, fb, &dfb));
+      a->M = M; a->chirp = dw; a->fb = dfb;
     }
     a->src = (const float*)(sig + o.i[1]); a->dst = (float*)(sig + o.i[0]); a->tw = tw; a->N = d; a->kind = kind;
     a->set = (int)o.i[5]; a->nr = (int)rad.size();
@@ -781,83 +844,6 @@ struct Sim final : ssn_sim {
     return true;
   }
 
-  // LDS staging plan of one program: collect the signal ranges its operators touch, lay them out in LDS,
-  // translate the operators' offsets.  Leaves the program in global-memory mode (no segments) when the ranges
-  // do not fit or there is nothing to gain.
-  int stage_program(std::vector<MOp>& ops, std::vector<ssn::ProgSeg>& segs_out, int* lds_bytes) {
-    *lds_bytes = 0;
-    if (!(flags & 64)) return SSN_OK;   // measured slower than global-memory programs on SLAM config 3: opt-in
-    struct Rg { int64_t lo, hi; bool w; };
-    std::vector<Rg> rs;
-    int levels = 0;
-    for (auto& op : ops) {
-      levels += op.barrier ? 1 : 0;
-      switch (op.kind) {
-        case ssn::M_FILL: case ssn::M_TABLE: case ssn::M_ARGMAX_GATHER: case ssn::M_REDUCE_SET: case ssn::M_REDUCE_INC: case ssn::M_ROW_IN:
-          rs.push_back({op.dst, op.dst + op.len, true}); break;
-        case ssn::M_AXPY_INC: case ssn::M_AXPY_SET: case ssn::M_LOWPASS:
-          rs.push_back({op.dst, op.dst + op.len, true}); rs.push_back({op.src, op.src + op.len, false}); break;
-        case ssn::M_MATVEC_INC: case ssn::M_MATVEC_SET:
-          rs.push_back({op.dst, op.dst + op.len, true}); rs.push_back({op.src, op.src + op.i0, false}); break;
-        case ssn::M_GATE:
-          rs.push_back({op.dst, op.dst + op.len, true}); rs.push_back({op.src, op.src + 2 * op.len + 1, false}); break;
-        case ssn::M_PROBE: case ssn::M_ROW_OUT:
-          rs.push_back({op.src, op.src + op.len, false}); break;
-        case ssn::M_ENS_FINISH: {
-          const int32_t* hi = nullptr; int64_t n = 0;
-          for (auto& h : host_idx) if (h.first == op.p1) { hi = h.second.first; n = h.second.second; }
-          if (!hi) return SSN_OK;
-          for (int64_t j = 0; j < n; ++j) rs.push_back({hi[j], (int64_t)hi[j] + 1, true});
-          break;
-        }
-        default: break;
-      }
-    }
-    if (rs.empty() || ops.size() < 3 || levels < 1) return SSN_OK;
-    std::sort(rs.begin(), rs.end(), [](const Rg& a, const Rg& b) { return a.lo < b.lo; });
-    std::vector<Rg> mg;
-    for (auto& r : rs) {
-      if (!mg.empty() && r.lo <= mg.back().hi) { mg.back().hi = std::max(mg.back().hi, r.hi); mg.back().w = mg.back().w || r.w; }
-      else mg.push_back(r);
-    }
-    int64_t total = 0;
-    std::vector<int64_t> loff(mg.size());
-    for (size_t i = 0; i < mg.size(); ++i) { loff[i] = total; total += (mg[i].hi - mg[i].lo + 3) / 4 * 4; }
-    if (total * (int64_t)sizeof(T) > LDS_CAP - 1024 || mg.size() > 4096) return SSN_OK;
-    auto tr = [&](int64_t off) -> int64_t {
-      size_t lo = 0, hi = mg.size();
-      while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (mg[mid].lo <= off) lo = mid; else hi = mid; }
-      return loff[lo] + (off - mg[lo].lo);
-    };
-    for (auto& op : ops) {
-      switch (op.kind) {
-        case ssn::M_FILL: case ssn::M_TABLE: case ssn::M_ARGMAX_GATHER: case ssn::M_REDUCE_SET: case ssn::M_REDUCE_INC: case ssn::M_ROW_IN:
-          op.dst = tr(op.dst); break;
-        case ssn::M_AXPY_INC: case ssn::M_AXPY_SET: case ssn::M_LOWPASS: case ssn::M_MATVEC_INC: case ssn::M_MATVEC_SET: case ssn::M_GATE:
-          op.dst = tr(op.dst); op.src = tr(op.src); break;
-        case ssn::M_PROBE: case ssn::M_ROW_OUT:
-          op.src = tr(op.src); break;
-        case ssn::M_ENS_FINISH: {
-          const int32_t* hi = nullptr; int64_t n = 0;
-          for (auto& h : host_idx) if (h.first == op.p1) { hi = h.second.first; n = h.second.second; }
-          std::vector<int32_t> t((size_t)n);
-          for (int64_t j = 0; j < n; ++j) t[(size_t)j] = (int32_t)tr(hi[j]);
-          int32_t* d = nullptr;
-          CHK(dmalloc(&d, n * 4));
-          scratch_bufs.push_back(d);
-          HIPCHK(hipMemcpy(d, t.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-          op.p1 = d;
-          break;
-        }
-        default: break;
-      }
-    }
-    for (size_t i = 0; i < mg.size(); ++i)
-      segs_out.push_back(ssn::ProgSeg{mg[i].lo, (int)loff[i], (int)(mg[i].hi - mg[i].lo), mg[i].w ? 1 : 0, 0});
-    *lds_bytes = (int)(total * (int64_t)sizeof(T));
-    return SSN_OK;
-  }
-
   int plan(const ssn_model_desc* m) {
     int frc = SSN_OK;
     const bool fused = !(flags & 1) && try_fused_core(m, &frc);
@@ -1008,28 +994,7 @@ struct Sim final : ssn_sim {
             Item it; it.type = IT_SPMV; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.dst = partial;
             it.rows = (int)o.i[2]; it.cols = (int)o.i[3]; it.ld = (int)w.ldt; it.n = chunks; it.seg = seg;
             for (auto& sl : spike_lists) if (sl.first == o.i[1]) { it.list = sl.second.first; it.count = sl.second.second; }
-            if (seg > 0 && (flags & 16384)) {
-              // opt-in experiment: rows-owned product, no partial sums and no reduce program behind it.  Measured SLOWER
-              // on SLAM config 3 (393 vs 345 us per timestep at 27 vs 33 launches): 64 workgroups with three dependent
-              // load levels per spike-list segment lose more than the six saved launches give back.
-              Item it; it.type = IT_SPMV_ROWS; it.Wm = (T*)w.d; it.src = sig + o.i[1]; it.out = sig + o.i[0]; it.set = (int)o.i[5];
-              it.rows = (int)o.i[2]; it.cols = (int)o.i[3]; it.ld = (int)w.ldt;
-              for (auto& sl : spike_lists) if (sl.first == o.i[1]) { it.list = sl.second.first; it.count = sl.second.second; }
-              items.push_back(it);
-              force_barrier = true;
-              break;
-            }
-            if (seg > 0 && (flags & 2048) && (o.i[2] + 255) / 256 <= 64) {
-              // opt-in experiment: the last workgroup of each row block adds the chunk sums itself (no reduce program
-              // behind the product).  Measured SLOWER on SLAM config 3 (446 vs 372 us per timestep, 37 vs 42 launches):
-              // the device-scope fences every workgroup needs cost more than the five launches they save.
-              CHK(dmalloc(&it.tickets, 64 * 4));
-              HIPCHK(hipMemset(it.tickets, 0, 64 * 4));
-              scratch_bufs.push_back(it.tickets);
-              it.out = sig + o.i[0]; it.set = (int)o.i[5];
-              items.push_back(it);
-              force_barrier = true;
-            } else {
+            {
               // the chunk reduction is deferred past any sparse products that follow directly (they read spike vectors,
               // never a reduction's output): the products then sit next to each other and share a launch, and their
               // reductions share one program
@@ -1079,7 +1044,7 @@ struct Sim final : ssn_sim {
             const ssn_op_desc& q = m->ops[j];
             if (q.kind == SSN_OP_MATVEC && q.stage == 1 && q.i[1] == o.i[1] && q.i[3] == o.i[2] && bufs[q.i[4]].transposed) feeds_sparse = true;
           }
-          if (feeds_sparse && !(flags & 32) && !(flags & 1024)) {
+          if (feeds_sparse && !(flags & 1024)) {
             // segmented spike list: every 256-neuron workgroup of k_neurons leaves its spikes as an ordered index list
             const int n_seg = ((int)o.i[2] + 255) / 256;
             CHK(dmalloc(&it.list, (int64_t)n_seg * 256 * 4));
@@ -1088,13 +1053,6 @@ struct Sim final : ssn_sim {
             scratch_bufs.push_back(it.list); scratch_bufs.push_back(it.count);
             spike_lists.push_back({o.i[1], {it.list, it.count}});
             seg_spikes.push_back(o.i[1]);
-          } else if (feeds_sparse && (flags & 32) && o.i[5] == SSN_LIF && o.i[2] <= 16384) {   // measured slower: opt-in
-            it.type = IT_NEURONS_COMPACT;
-            CHK(dmalloc(&it.list, (o.i[2] + 16) * 4));
-            CHK(dmalloc(&it.count, 64));
-            HIPCHK(hipMemset(it.count, 0, 64));
-            scratch_bufs.push_back(it.list); scratch_bufs.push_back(it.count);
-            spike_lists.push_back({o.i[1], {it.list, it.count}});
           }
           items.push_back(it);
           break;
@@ -1255,7 +1213,6 @@ struct Sim final : ssn_sim {
       }
     }
     // micro-op storage: programs in order, then a copy of the head behind the tail for the fused launch.
-    // Each program gets an LDS staging plan when the signals it touches fit (see stage_program).
     // Long first level of the head program -> its own grid-wide launch (k_vecops).  The head then no longer starts the
     // timestep, so the tail / head fusion is given up: worth it from ~16 k elements on (SLAM config 3: 42 -> ~23 us).
     std::vector<MOp>& vec_ops = vecops_host;
@@ -1294,17 +1251,10 @@ struct Sim final : ssn_sim {
     int n_prog = (int)programs.size();
     mops.clear();
     prog_descs.clear();
-    prog_segs.clear();
-    prog_lds.assign(n_prog + 1, 0);
     for (int p = 0; p < n_prog; ++p) {
       ssn::ProgDesc pd{};
       pd.op_begin = (int)mops.size(); pd.op_count = (int)programs[p].size();
-      pd.seg_begin = (int)prog_segs.size();
-      std::vector<MOp> ops = programs[p];
-      int rc_stage = stage_program(ops, prog_segs, &prog_lds[p]);
-      CHK(rc_stage);
-      pd.seg_count = (int)prog_segs.size() - pd.seg_begin;
-      mops.insert(mops.end(), ops.begin(), ops.end());
+      mops.insert(mops.end(), programs[p].begin(), programs[p].end());
       prog_descs.push_back(pd);
     }
     int pi = 0;
@@ -1319,14 +1269,10 @@ struct Sim final : ssn_sim {
       mops[(size_t)hb].barrier = 1;
       hd.op_begin = hb;
       prog_descs.push_back(hd);
-      prog_lds[n_prog] = std::max(prog_lds[n_prog - 1], prog_lds[0]);
       tail_begin = n_prog - 1;
     }
     CHK(dmalloc(&d_progs, (int64_t)std::max<size_t>(1, prog_descs.size()) * (int64_t)sizeof(ssn::ProgDesc)));
-    CHK(dmalloc(&d_segs, (int64_t)std::max<size_t>(1, prog_segs.size()) * (int64_t)sizeof(ssn::ProgSeg)));
     if (!prog_descs.empty()) HIPCHK(hipMemcpy(d_progs, prog_descs.data(), prog_descs.size() * sizeof(ssn::ProgDesc), hipMemcpyHostToDevice));
-    if (!prog_segs.empty()) HIPCHK(hipMemcpy(d_segs, prog_segs.data(), prog_segs.size() * sizeof(ssn::ProgSeg), hipMemcpyHostToDevice));
-    ssn::program_set_max_lds<T>(LDS_CAP);
     if (!vec_ops.empty()) {
       items.front().op_begin = (int)mops.size(); items.front().op_count = (int)vec_ops.size();
       mops.insert(mops.end(), vec_ops.begin(), vec_ops.end());
@@ -1441,10 +1387,6 @@ struct Sim final : ssn_sim {
           sg(a, it.src - sig, it.cols, false); pt(a, it.Wm, false);
           if (it.dst >= sig && it.dst < sig + n_sig) sg(a, it.dst - sig, it.rows, true); else pt(a, it.dst, true);
           break;
-        case IT_SPMV_ROWS:
-          sg(a, it.src - sig, it.cols, false); pt(a, it.Wm, false); pt(a, it.list, false); pt(a, it.count, false);
-          sg(a, it.out - sig, it.rows, true);
-          break;
         case IT_GRID_LHS:
           pt(a, it.src, false); pt(a, it.aux0, false); pt(a, it.dst, true);
           break;
@@ -1456,9 +1398,8 @@ struct Sim final : ssn_sim {
           break;
         case IT_SPMV:
           sg(a, it.src - sig, it.cols, false); pt(a, it.Wm, false); pt(a, it.list, false); pt(a, it.count, false); pt(a, it.dst, true);
-          if (it.out) sg(a, it.out - sig, it.rows, true);
           break;
-        case IT_NEURONS: case IT_NEURONS_COMPACT:
+        case IT_NEURONS:
           sg(a, it.src - sig, it.n, false); sg(a, it.dst - sig, it.n, true); pt(a, it.V, true); pt(a, it.R, true);
           pt(a, it.list, true); pt(a, it.count, true);
           break;
@@ -1542,7 +1483,7 @@ struct Sim final : ssn_sim {
     if (it.merged) return hipSuccess;               // its batch leader launched it
     const Item* g = &it;                            // (batch members are adjacent in `items`)
     switch (it.type) {
-      case IT_PROGRAM: return ssn::launch_program<T>(stream, d_mops, d_progs + it.op_begin, 1, d_segs, prog_lds[it.op_begin], sig, d_ctx);
+      case IT_PROGRAM: return ssn::launch_program<T>(stream, d_mops, d_progs + it.op_begin, 1, sig, d_ctx);
       case IT_VECOPS: return ssn::launch_vecops<T>(stream, d_mops + it.op_begin, it.op_count, it.n, sig, d_ctx);
       case IT_ENS: {
         if (e0) { hipError_t e = hipEventRecord(e0, stream); if (e != hipSuccess) return e; }
@@ -1570,18 +1511,15 @@ struct Sim final : ssn_sim {
         for (int q = 0; q < it.batch; ++q) b.a[q] = g[q].dft;
         return ssn::launch_dft<T>(stream, b, it.batch);
       }
-      case IT_SPMV_ROWS: return ssn::launch_spmv_rows<T>(stream, it.Wm, it.ld, it.src, it.cols, it.rows, it.list, it.count, it.out, it.set);
       case IT_ARGMAX_PART: return ssn::launch_argmax_partial<T>(stream, it.src, (long long)it.rows, it.dst, it.n, std::max(1, it.seg));
       case IT_GRID_LHS: return ssn::launch_grid_lhs<T>(stream, it.src, it.aux0, it.ld, it.dst, it.cols, it.rows, it.cols / 2);
       case IT_GRID_GEMM: return ssn::launch_gemm_nt<T>(stream, it.src, it.cols, it.Wm, it.ld, it.dst, it.n, it.rows, it.n, it.cols, std::max(1, it.seg));
       case IT_SPMV: {
         ssn::SpmvBatch<T> b{};
         for (int q = 0; q < it.batch; ++q)
-          b.a[q] = ssn::SpmvArgs<T>{g[q].Wm, g[q].ld, g[q].src, g[q].cols, g[q].rows, g[q].dst, g[q].ld, g[q].n, g[q].list, g[q].count, g[q].seg,
-                                    g[q].out, g[q].set, g[q].tickets};
+          b.a[q] = ssn::SpmvArgs<T>{g[q].Wm, g[q].ld, g[q].src, g[q].cols, g[q].rows, g[q].dst, g[q].ld, g[q].n, g[q].list, g[q].count, g[q].seg};
         return ssn::launch_spmv_partial<T>(stream, b, it.batch);
       }
-      case IT_NEURONS_COMPACT: return ssn::launch_neurons_compact<T>(stream, it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count);
       case IT_NEURONS: {
         ssn::NeuronsBatch<T> b{};
         for (int q = 0; q < it.batch; ++q)
@@ -1612,51 +1550,8 @@ struct Sim final : ssn_sim {
         const Item& it = items[i];
         hipError_t e = hipSuccess;
         if (fused && can_fuse && i == 0 && s > 0) continue;               // head already ran with the previous tail
-        if (capturing_rounds && it.type != IT_PROGRAM && !it.merged) {
-          // a run of big operators of one scheduling round (independent of each other): the first stays on this
-          // stream, the others fork onto side streams and join before whatever follows - inside the captured graph
-          // they become parallel branches
-          int j = i + 1, leaders = 1;
-          while (j < n_items && items[(size_t)j].type != IT_PROGRAM && (items[(size_t)j].merged || items[(size_t)j].level == it.level)) {
-            bool indep = true;
-            if (!items[(size_t)j].merged)
-              for (int d : item_deps[(size_t)j]) if (d >= i && d < j) indep = false;
-            if (!indep) break;
-            leaders += items[(size_t)j].merged ? 0 : 1;
-            ++j;
-          }
-          if (leaders >= 2) {
-            hipStream_t main_stream = stream;
-            hipEvent_t fork = dag_events[round_ev++];
-            if ((e = hipEventRecord(fork, main_stream)) != hipSuccess) return e;
-            int q = 0;
-            std::vector<int> used;
-            for (int t = i; t < j; ++t) {
-              if (items[(size_t)t].merged) continue;
-              if (q > 0) {
-                const int sidx = (q - 1) % (int)side_streams.size();
-                if (std::find(used.begin(), used.end(), sidx) == used.end()) {
-                  if ((e = hipStreamWaitEvent(side_streams[(size_t)sidx], fork, 0)) != hipSuccess) return e;
-                  used.push_back(sidx);
-                }
-                stream = side_streams[(size_t)sidx];
-              }
-              e = launch_item(items[(size_t)t], nullptr, nullptr);
-              stream = main_stream;
-              if (e != hipSuccess) return e;
-              ++q;
-            }
-            for (int sidx : used) {
-              hipEvent_t done = dag_events[round_ev++];
-              if ((e = hipEventRecord(done, side_streams[(size_t)sidx])) != hipSuccess) return e;
-              if ((e = hipStreamWaitEvent(main_stream, done, 0)) != hipSuccess) return e;
-            }
-            i = j - 1;
-            continue;
-          }
-        }
         if (fused && can_fuse && i == n_items - 1 && s + 1 < count)
-          e = ssn::launch_program<T>(stream, d_mops, d_progs + tail_begin, 2, d_segs, prog_lds[tail_begin + 1], sig, d_ctx);
+          e = ssn::launch_program<T>(stream, d_mops, d_progs + tail_begin, 2, sig, d_ctx);
         else
           e = launch_item(it, nullptr, nullptr);
         if (e != hipSuccess) return e;
@@ -1725,7 +1620,7 @@ struct Sim final : ssn_sim {
       }
     if (tr) fprintf(stderr, "OP L -1\n");
     if (can_fuse && !last)
-      return ssn::launch_program<T>(main_stream, d_mops, d_progs + tail_begin, 2, d_segs, prog_lds[tail_begin + 1], sig, d_ctx);
+      return ssn::launch_program<T>(main_stream, d_mops, d_progs + tail_begin, 2, sig, d_ctx);
     return on(main_stream, items[(size_t)(n_items - 1)]);
   }
 
@@ -1763,20 +1658,8 @@ struct Sim final : ssn_sim {
       if (dbg) fprintf(stderr, "[ssn] graph instantiated\n");
       return SSN_OK;
     }
-    // opt-in experiment (measured SLOWER on SLAM config 3: 350 vs 320 us per timestep - a fork / join between streams
-    // inside the graph costs more than the overlap of 5-30 us kernels gives back)
-    const bool rounds = (flags & 32768) && !fused_core && item_deps.size() == items.size() && items.size() >= 4;
-    if (rounds) {
-      side_streams.resize(3);
-      for (auto& st : side_streams) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-      dag_events.resize((size_t)steps_per_graph * (2 * items.size() + 8));
-      for (auto& ev : dag_events) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
     HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    capturing_rounds = rounds;
-    round_ev = 0;
     hipError_t e = launch_steps(steps_per_graph, true);
-    capturing_rounds = false;
     hipError_t e2 = hipStreamEndCapture(stream, &graph);
     HIPCHK(e);
     HIPCHK(e2);
@@ -1791,7 +1674,7 @@ struct Sim final : ssn_sim {
     int n_dom = 0;
     for (auto& it : items) n_dom += it.dominant ? 1 : 0;
     size_t ev_used = 0;
-    std::vector<int> ev_types;                  // profile = 2: plan-item type of each event pair
+    std::vector<int> ev_types, ev_items;        // profile = 2: plan-item type / index of each event pair
     if (profile == 2 && (fused_block || core_empty)) profile = 1;
     if (profile) {
       const size_t need = fused_block ? (size_t)(2 * (n / std::max(1, block) + 2))
@@ -1836,6 +1719,7 @@ struct Sim final : ssn_sim {
             HIPCHK(launch_item(it, nullptr, nullptr));
             HIPCHK(hipEventRecord(ev_pool[ev_used + 1], stream));
             ev_types.push_back(it.type);
+            ev_items.push_back((int)(&it - items.data()));
             ev_used += 2;
           }
           if (fused_defer) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, 1LL); HIPCHK(hipGetLastError()); }
@@ -1870,11 +1754,38 @@ struct Sim final : ssn_sim {
         const int ty = ev_types[j / 2];
         type_ms[ty] += ms;
         type_launches[ty] += 1;
+        if (item_ms.size() != items.size()) { item_ms.assign(items.size(), 0.0); item_n.assign(items.size(), 0); }
+        item_ms[(size_t)ev_items[j / 2]] += ms; item_n[(size_t)ev_items[j / 2]] += 1;
         continue;
       }
       dom_ms += ms;
       dom_launches += 1;
     }
+    if (profile == 2 && getenv("SSN_DEBUG_PLAN")) {
+      // diagnostic build (F32_EXTRA=-DSSN_PROGRAM_STAMPS): shader cycles each operator of each program took in the last timestep
+      typedef int (*stamp_fn)(unsigned long long*, int);
+      if (stamp_fn fn = (stamp_fn)dlsym(RTLD_DEFAULT, "ssn_debug_program_stamps")) {
+        std::vector<unsigned long long> st(2048, 0);
+        if (fn(st.data(), 2048) == 0)
+          for (size_t p = 0; p < prog_descs.size(); ++p) {
+            const ssn::ProgDesc& pd = prog_descs[p];
+            if (pd.op_begin + pd.op_count > 1024) continue;
+            unsigned long long prev = st[(size_t)(1024 + pd.op_begin)];
+            fprintf(stderr, "[ssn] program %zu (%d ops) cycles per operator [kind/len:cycles]:", p, pd.op_count);
+            for (int o = 0; o < pd.op_count; ++o) {
+              const unsigned long long t = st[(size_t)(pd.op_begin + o)];
+              if (!t) { fprintf(stderr, " %d/%lld:-", mops[(size_t)(pd.op_begin + o)].kind, (long long)mops[(size_t)(pd.op_begin + o)].len); continue; }
+              fprintf(stderr, " %d/%lld:%lld", mops[(size_t)(pd.op_begin + o)].kind, (long long)mops[(size_t)(pd.op_begin + o)].len, (long long)(t - prev));
+              prev = t;
+            }
+            fprintf(stderr, "\n");
+          }
+      }
+    }
+    if (profile == 2 && getenv("SSN_DEBUG_PLAN"))
+      for (size_t i = 0; i < item_ms.size(); ++i)
+        if (item_n[i]) fprintf(stderr, "[ssn] item %2zu type %2d batch %d: %8.2f us avg over %lld launches\n", i, items[i].type, items[i].batch,
+                               1e3 * item_ms[i] / item_n[i], (long long)item_n[i]);
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, ev_run0, ev_run1));
     last_run_ms = ms;
@@ -2016,13 +1927,15 @@ struct Sim final : ssn_sim {
     out->block_npt = fused_block ? blk.npt : 0;
     out->block_enc_lds = fused_block ? blk.enc_lds : 0;
     out->block_threads = fused_block ? blk.threads : 0;
+    out->fft_transforms = 0; out->fft_bluestein = 0;
+    for (auto& it : items) if (it.type == IT_DFT) { out->fft_transforms += 1; out->fft_bluestein += it.dft.M > 0 ? 1 : 0; }
     return SSN_OK;
   }
 
   int kernel_times(ssn_kernel_time* out, int capacity) override {
     static const char* names[N_ITEM_TYPES] = {"k_program", "k_ensarray", "k_matvec", "k_neurons", "k_pes", "k_voja", "k_matvec_ordered",
-                                              "k_ens_finish", "k_spmv_partial", "k_neurons_compact", "k_dft", "k_spmv_rows", "k_vecops",
-                                              "k_grid_lhs", "k_gemm_nt_mfma_f32", "k_argmax_partial"};
+                                              "k_ens_finish", "k_spmv_partial", "k_dft", "k_vecops", "k_grid_lhs", "k_gemm_nt_mfma_f32",
+                                              "k_argmax_partial", "", ""};
     int n = 0;
     for (int t = 0; t < N_ITEM_TYPES; ++t) {
       if (!type_launches[t]) continue;

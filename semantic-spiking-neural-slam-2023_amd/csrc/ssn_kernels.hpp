@@ -437,38 +437,21 @@ hipError_t launch_ensarray(hipStream_t s, const EnsArgs<T>& a) {
 // Forward kinds write the 4-slot layout [Re,Im,Re,Im] (A) / [Re,Im,Im,Re] (B) per half-spectrum bin, conjugated
 // for the inverted operand; the inverse kind recombines the four product slots (Re = s0 - s1, Im = s2 + s3),
 // completes the Hermitian spectrum and transforms back (1/d included).  f32 only: the f64 parity mode multiplies
-// by the matrix like the oracle.
+// by the matrix like the oracle.  A length with a prime factor > 32 (97, 1801, 2049 = 3 * 683) goes through Bluestein's
+// chirp-z form: X_k = w_k sum_n (x_n w_n) conj(w_{k-n}), w_n = exp(-i pi n^2 / N) - a circular convolution of smooth
+// length M >= 2N - 1, i.e. two Stockham transforms of length M around a pointwise product with a precomputed spectrum.
 // ---------------------------------------------------------------------------------------------
-template <int DUMMY>
-__global__ __launch_bounds__(1024) void k_dft(DftBatch batch) {
-  const DftArgs& a = batch.a[blockIdx.x];       // (a reference: the radix list is indexed dynamically - a copy would live in scratch)
-  extern __shared__ __align__(16) unsigned char ssn_dft_dyn[];
-  const int N = a.N, H = N / 2 + 1, tid = threadIdx.x, nthr = blockDim.x;
-  float2* x = reinterpret_cast<float2*>(ssn_dft_dyn);
-  float2* y = x + N;
-  float2* tw = y + N;
-  for (int i = tid; i < N; i += nthr) {
-    tw[i] = a.tw[i];
-    if (a.kind != 5) x[i] = make_float2(a.src[i], 0.0f);
-    else {
-      const int w = i < H ? i : N - i;
-      const float* p = a.src + 4 * w;
-      float re = p[0] - p[1], im = p[2] + p[3];
-      if (w == 0 || 2 * w == N) im = 0.0f;            // purely real bins (their imaginary slots carry no signal)
-      // Z[i] = Y_w (i <= N/2) or conj(Y_w) (i > N/2); the inverse transform is conj(FFT(conj Z)): load conj Z
-      x[i] = make_float2(re, i < H ? -im : im);
-    }
-  }
-  __syncthreads();
-  int n = N, s = 1;
-  for (int st = 0; st < a.nr; ++st) {
-    const unsigned r = (unsigned)a.radix[st], m = (unsigned)n / r, fn = (unsigned)(N / n), fr = (unsigned)N / r;
-    for (int o = tid; o < N; o += nthr) {
-      // (all products below stay under 2^32: p j fn <= N * 32 * N / n... with N <= 6400, see plan_dft)
+// One mixed-radix Stockham pass structure over L points held in LDS (x -> result returned; y is scratch)
+__device__ inline float2* dft_stockham(float2* x, float2* y, const float2* tw, int L, const int* radix, int nr, int tid, int nthr) {
+  int n = L, s = 1;
+  for (int st = 0; st < nr; ++st) {
+    const unsigned r = (unsigned)radix[st], m = (unsigned)n / r, fn = (unsigned)(L / n), fr = (unsigned)L / r;
+    for (int o = tid; o < L; o += nthr) {
+      // (all products below stay under 2^32: p j fn < L * 32, L <= 6400, see plan_dft)
       const unsigned uo = (unsigned)o, us = (unsigned)s;
       const unsigned q = uo % us, u = uo / us, j = u % r, p = u / r;
-      int idx = (int)((p * j * fn) % (unsigned)N);
-      const int step = (int)((j * fr) % (unsigned)N);
+      int idx = (int)((p * j * fn) % (unsigned)L);
+      const int step = (int)((j * fr) % (unsigned)L);
       const float2* xi = x + q + s * p;
       float2 acc = make_float2(0.0f, 0.0f);
       for (int k = 0; k < (int)r; ++k) {
@@ -476,13 +459,62 @@ __global__ __launch_bounds__(1024) void k_dft(DftBatch batch) {
         acc.x = fmaf(v.x, t.x, fmaf(-v.y, t.y, acc.x));
         acc.y = fmaf(v.x, t.y, fmaf(v.y, t.x, acc.y));
         idx += step;
-        if (idx >= N) idx -= N;
+        if (idx >= L) idx -= L;
       }
       y[o] = acc;
     }
     __syncthreads();
     float2* t2 = x; x = y; y = t2;
     n = (int)m; s *= (int)r;
+  }
+  return x;
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(1024) void k_dft(DftBatch batch) {
+  const DftArgs& a = batch.a[blockIdx.x];       // (a reference: the radix list is indexed dynamically - a copy would live in scratch)
+  extern __shared__ __align__(16) unsigned char ssn_dft_dyn[];
+  const int N = a.N, H = N / 2 + 1, tid = threadIdx.x, nthr = blockDim.x;
+  const int L = a.M > 0 ? a.M : N;              // length of the transforms actually run
+  float2* x = reinterpret_cast<float2*>(ssn_dft_dyn);
+  float2* y = x + L;
+  float2* tw = y + L;
+  for (int i = tid; i < L; i += nthr) {
+    tw[i] = a.tw[i];
+    float2 v = make_float2(0.0f, 0.0f);
+    if (i < N) {
+      if (a.kind != 5) v = make_float2(a.src[i], 0.0f);
+      else {
+        const int w = i < H ? i : N - i;
+        const float* p = a.src + 4 * w;
+        float re = p[0] - p[1], im = p[2] + p[3];
+        if (w == 0 || 2 * w == N) im = 0.0f;            // purely real bins (their imaginary slots carry no signal)
+        // Z[i] = Y_w (i <= N/2) or conj(Y_w) (i > N/2); the inverse transform is conj(FFT(conj Z)): load conj Z
+        v = make_float2(re, i < H ? -im : im);
+      }
+      if (a.M > 0) {                                    // Bluestein: a_n = x_n w_n
+        const float2 c = a.chirp[i];
+        v = make_float2(v.x * c.x - v.y * c.y, v.x * c.y + v.y * c.x);
+      }
+    }
+    x[i] = v;
+  }
+  __syncthreads();
+  x = dft_stockham(x, y, tw, L, a.radix, a.nr, tid, nthr);
+  if (a.M > 0) {
+    // X_k = w_k * (a (*) conj(w))_k: multiply the spectra, transform back (conj . FFT . conj; 1 / M folded into fb)
+    y = x == reinterpret_cast<float2*>(ssn_dft_dyn) ? x + L : reinterpret_cast<float2*>(ssn_dft_dyn);
+    for (int i = tid; i < L; i += nthr) {
+      const float2 v = x[i], f = a.fb[i];
+      x[i] = make_float2(v.x * f.x - v.y * f.y, -(v.x * f.y + v.y * f.x));
+    }
+    __syncthreads();
+    x = dft_stockham(x, y, tw, L, a.radix, a.nr, tid, nthr);
+    for (int i = tid; i < N; i += nthr) {
+      const float2 v = make_float2(x[i].x, -x[i].y), c = a.chirp[i];
+      x[i] = make_float2(v.x * c.x - v.y * c.y, v.x * c.y + v.y * c.x);
+    }
+    __syncthreads();
   }
   if (a.kind != 5) {
     const bool conj = a.kind >= 3, slotB = a.kind == 2 || a.kind == 4;
@@ -505,8 +537,14 @@ __global__ __launch_bounds__(1024) void k_dft(DftBatch batch) {
 template <typename T>
 hipError_t launch_dft(hipStream_t s, const DftBatch& b, int count) {
   int N = 0;
-  for (int i = 0; i < count; ++i) N = std::max(N, b.a[i].N);
+  for (int i = 0; i < count; ++i) N = std::max(N, b.a[i].M > 0 ? b.a[i].M : b.a[i].N);
   const int threads = N >= 1024 ? 1024 : (N + 63) / 64 * 64;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 6400 * 3 * (int)sizeof(float2));
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
   hipLaunchKernelGGL((k_dft<0>), dim3(count), dim3(threads), (size_t)N * 3 * sizeof(float2), s, b);
   return hipGetLastError();
 }
@@ -535,10 +573,26 @@ __device__ inline void vec4_loop(int tid, long long len, L load, S store) {
   else vecn_loop<T, 4>(tid, (int)len, load, store);
 }
 
+#ifdef SSN_PROGRAM_STAMPS
+// diagnostic build only (make F32_EXTRA=-DSSN_PROGRAM_STAMPS): shader-clock stamp after every operator of every program,
+// indexed like the micro-operator array; tools/experiments/plan_dump.py prints the per-operator cycles
+__device__ unsigned long long g_prog_stamps[2048];
+inline hipError_t read_program_stamps(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prog_stamps), sizeof(unsigned long long) * (size_t)std::min(n, 2048));
+}
+#define SSN_STAMP(i)                                                                                   \
+  do {                                                                                                 \
+    unsigned long long t__;                                                                            \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); \
+    if (threadIdx.x == 0 && (i) < 2048) g_prog_stamps[i] = t__;                                        \
+  } while (0)
+#else
+#define SSN_STAMP(i) do {} while (0)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__ all_ops, const ProgDesc* __restrict__ progs, int n_progs,
-                                                  const ProgSeg* __restrict__ segs, T* __restrict__ gsig, StepCtx* __restrict__ ctx) {
-  extern __shared__ __align__(16) unsigned char lds_raw[];
+                                                  T* __restrict__ gsig, StepCtx* __restrict__ ctx) {
   __shared__ T sred[16];
   __shared__ int sidx[16];
   const int tid = threadIdx.x;
@@ -547,16 +601,9 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
   const ProgDesc pd = progs[pi];
   const MicroOp<T>* ops = all_ops + pd.op_begin;
   const int n_ops = pd.op_count;
-  T* sig = gsig;
-  if (pd.seg_count > 0) {              // stage this program's signals in LDS
-    sig = (T*)lds_raw;
-    if (pi > 0) __syncthreads();
-    for (int sgi = 0; sgi < pd.seg_count; ++sgi) {
-      const ProgSeg sg = segs[pd.seg_begin + sgi];
-      for (int i = tid; i < sg.len; i += 1024) sig[sg.loff + i] = gsig[sg.goff + i];
-    }
-    __syncthreads();
-  }
+  T* const sig = gsig;
+  if (pi > 0) __syncthreads();
+  SSN_STAMP(1024 + pd.op_begin);           // (program entry: stamps of the first operator are measured from here)
   for (int o = 0; o < n_ops; ++o) {
     const MicroOp<T> op = ops[o];
     if (op.barrier) __syncthreads();
@@ -719,14 +766,7 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
       default:
         break;
     }
-  }
-  if (pd.seg_count > 0) {              // write the ranges this program modified back to the signal vector
-    __syncthreads();
-    for (int sgi = 0; sgi < pd.seg_count; ++sgi) {
-      const ProgSeg sg = segs[pd.seg_begin + sgi];
-      if (!sg.dirty) continue;
-      for (int i = tid; i < sg.len; i += 1024) gsig[sg.goff + i] = sig[sg.loff + i];
-    }
+    SSN_STAMP(pd.op_begin + o);
   }
  }
 }
@@ -779,15 +819,9 @@ hipError_t launch_vecops(hipStream_t s, const MicroOp<T>* ops, int n_ops, int wg
 }
 
 template <typename T>
-hipError_t launch_program(hipStream_t s, const MicroOp<T>* d_ops, const ProgDesc* progs, int n_progs, const ProgSeg* segs, int lds_bytes,
-                          T* sig, StepCtx* ctx) {
-  hipLaunchKernelGGL((k_program<T>), dim3(1), dim3(1024), (size_t)lds_bytes, s, d_ops, progs, n_progs, segs, sig, ctx);
+hipError_t launch_program(hipStream_t s, const MicroOp<T>* d_ops, const ProgDesc* progs, int n_progs, T* sig, StepCtx* ctx) {
+  hipLaunchKernelGGL((k_program<T>), dim3(1), dim3(1024), 0, s, d_ops, progs, n_progs, sig, ctx);
   return hipGetLastError();
-}
-
-template <typename T>
-hipError_t program_set_max_lds(int bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_program<T>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -924,9 +958,6 @@ __global__ __launch_bounds__(256) void k_spmv_partial(SpmvBatch<T> batch) {
   const int* __restrict__ glist = sa.list;
   const int* __restrict__ gcount = sa.count;
   const int seg = sa.seg;
-  T* __restrict__ out = sa.out;
-  const int out_set = sa.out_set;
-  unsigned int* __restrict__ tickets = sa.tickets;
   if ((int)blockIdx.x * 256 >= rows || (int)blockIdx.y >= chunks) return;      // (grid sized for the largest product of a batch)
   extern __shared__ unsigned char smem[];
   __shared__ int counts[257];
@@ -976,35 +1007,6 @@ __global__ __launch_bounds__(256) void k_spmv_partial(SpmvBatch<T> batch) {
         for (; i < e; ++i) { const int j = sl[i]; acc += spikes[j] * Wt[(size_t)j * ldt + r]; }
       }
     if (r < rows) partial[(size_t)c * rows_pad + r] = acc;
-    if (out) {
-      // fused chunk reduction: the last workgroup of a row block to arrive adds the chunk sums in chunk order
-      // (same order as the M_REDUCE_* micro-operator it replaces - and one kernel launch less per product)
-      __shared__ int s_last;
-      __threadfence();
-      __syncthreads();
-      if (tid == 0) {
-        const unsigned int t = atomicAdd(&tickets[blockIdx.x], 1u);
-        s_last = t == (unsigned int)chunks - 1u;
-        if (s_last) tickets[blockIdx.x] = 0u;         // ready for the next launch (stream-ordered)
-      }
-      __syncthreads();
-      if (s_last) {
-        __threadfence();
-        if (r < rows) {
-          T sum = T(0);
-          int q = 0;
-          for (; q + 8 <= chunks; q += 8) {
-            T v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(partial + (size_t)(q + u) * rows_pad + r);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) sum += v[u];
-          }
-          for (; q < chunks; ++q) sum += __builtin_nontemporal_load(partial + (size_t)q * rows_pad + r);
-          if (out_set) out[r] = sum; else out[r] += sum;
-        }
-      }
-    }
     return;
   }
   const int b = (int)((long long)m * c / chunks), e = (int)((long long)m * (c + 1) / chunks);
@@ -1021,53 +1023,6 @@ __global__ __launch_bounds__(256) void k_spmv_partial(SpmvBatch<T> batch) {
   }
 }
 
-// k_spmv_rows: the same product with NO partial sums in memory.  A workgroup owns 16 output rows; its 256 threads
-// are 16 row lanes x 16 spike lanes: spike lane l walks the spike-list segments l, l + 16, l + 32, ... (eight row
-// reads in flight), the 16 spike-lane sums of a row are added in lane order through LDS, and the row is written
-// to the signal vector directly - one launch per product instead of product + reduce program.
-template <typename T>
-__global__ __launch_bounds__(256) void k_spmv_rows(const T* __restrict__ Wt, int ldt, const T* __restrict__ spikes, int n, int rows,
-                                                   const int* __restrict__ glist, const int* __restrict__ gcount,
-                                                   T* __restrict__ out, int out_set) {
-  __shared__ T part[16][17];
-  const int tid = threadIdx.x, rl = tid & 15, sl = tid >> 4;
-  const int r = blockIdx.x * 16 + rl;
-  const int rr = min(r, rows - 1);
-  const int n_seg = (n + 255) / 256;
-  T acc = T(0);
-  for (int sgm = sl; sgm < n_seg; sgm += 16) {
-    const int* l = glist + sgm * 256;
-    const int e = gcount[sgm];
-    int i = 0;
-    for (; i + 8 <= e; i += 8) {
-      int j[8]; T w[8], sv[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) j[q] = l[i + q];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { w[q] = Wt[(size_t)j[q] * ldt + rr]; sv[q] = spikes[j[q]]; }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) acc += sv[q] * w[q];
-    }
-    for (; i < e; ++i) { const int j = l[i]; acc += spikes[j] * Wt[(size_t)j * ldt + rr]; }
-  }
-  part[sl][rl] = acc;
-  __syncthreads();
-  if (tid < 16 && blockIdx.x * 16 + tid < rows) {
-    T s = T(0);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) s += part[q][tid];
-    T* d = out + blockIdx.x * 16 + tid;
-    if (out_set) *d = s; else *d += s;
-  }
-}
-
-template <typename T>
-hipError_t launch_spmv_rows(hipStream_t s, const T* Wt, int ldt, const T* spikes, int n, int rows, const int* list, const int* count,
-                            T* out, int out_set) {
-  hipLaunchKernelGGL((k_spmv_rows<T>), dim3((rows + 15) / 16), dim3(256), 0, s, Wt, ldt, spikes, n, rows, list, count, out, out_set);
-  return hipGetLastError();
-}
-
 template <typename T>
 hipError_t launch_spmv_partial(hipStream_t s, const SpmvBatch<T>& b, int count) {
   int rows = 0, chunks = 0;
@@ -1077,50 +1032,6 @@ hipError_t launch_spmv_partial(hipStream_t s, const SpmvBatch<T>& b, int count) 
     if (!b.a[i].list) lds = std::max(lds, (size_t)b.a[i].n * sizeof(int));
   }
   hipLaunchKernelGGL((k_spmv_partial<T>), dim3((rows + 255) / 256, chunks, count), dim3(256), lds, s, b);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_neurons_compact: neuron step of a dense ensemble (n <= 16384) by ONE 1024-thread workgroup that also
-// leaves the ascending list of spiking neurons for the spike-sparse decoder products.  Each thread owns a
-// contiguous block of neurons, so a workgroup-wide exclusive scan of the per-thread spike counts gives
-// every thread its place in the list.
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(1024) void k_neurons_compact(NeuronParams<T> np, const T* __restrict__ J, T* __restrict__ out,
-                                                          T* __restrict__ V, T* __restrict__ R, int n, T amp,
-                                                          int* __restrict__ list, int* __restrict__ count) {
-  __shared__ int wave_tot[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (n + 1023) / 1024;            // <= 16
-  const int lo = min(n, tid * per), hi = min(n, lo + per);
-  unsigned mask = 0;
-  for (int i = lo; i < hi; ++i) {
-    T v = V[i], r = R[i];
-    const T a = neuron_step(np, J[i], v, r);
-    V[i] = v; R[i] = r;
-    out[i] = amp * a;
-    if (a != T(0)) mask |= 1u << (i - lo);
-  }
-  const int cnt = __popc(mask);
-  int incl = cnt;                                // inclusive scan inside the wave
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += t;
-  }
-  if (lane == 63) wave_tot[wave] = incl;
-  __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wave; ++w) base += wave_tot[w];
-  int pos = base + incl - cnt;
-  for (int i = lo; i < hi; ++i) if (mask & (1u << (i - lo))) list[pos++] = i;
-  if (tid == 1023) count[0] = base + incl;
-}
-
-template <typename T>
-hipError_t launch_neurons_compact(hipStream_t s, const NeuronParams<T>& np, const T* J, T* out, T* V, T* R, int n, T amp, int* list, int* count) {
-  hipLaunchKernelGGL((k_neurons_compact<T>), dim3(1), dim3(1024), 0, s, np, J, out, V, R, n, amp, list, count);
   return hipGetLastError();
 }
 
@@ -1676,15 +1587,12 @@ namespace ssn {
   template hipError_t launch_ensarray_batch<T>(hipStream_t, const EnsBatch<T>&, int);                        \
   template hipError_t launch_dec_pack<T>(hipStream_t, const T*, T*, int, int, int, int, int, int);           \
   template hipError_t launch_state_unpack<T>(hipStream_t, const T*, T*, int64_t, int, T);                    \
-  template hipError_t launch_program<T>(hipStream_t, const MicroOp<T>*, const ProgDesc*, int, const ProgSeg*, int, T*, StepCtx*); \
-  template hipError_t program_set_max_lds<T>(int);                                                          \
+  template hipError_t launch_program<T>(hipStream_t, const MicroOp<T>*, const ProgDesc*, int, T*, StepCtx*); \
   template hipError_t launch_vecops<T>(hipStream_t, const MicroOp<T>*, int, int, T*, const StepCtx*);        \
   template hipError_t launch_ens_finish<T>(hipStream_t, const FinishArgs<T>&);                               \
   template hipError_t launch_matvec<T>(hipStream_t, const MatvecBatch<T>&, int);            \
   template hipError_t launch_matvec_ordered<T>(hipStream_t, const T*, const T*, T*, int, int, int);         \
   template hipError_t launch_spmv_partial<T>(hipStream_t, const SpmvBatch<T>&, int); \
-  template hipError_t launch_spmv_rows<T>(hipStream_t, const T*, int, const T*, int, int, const int*, const int*, T*, int);  \
-  template hipError_t launch_neurons_compact<T>(hipStream_t, const NeuronParams<T>&, const T*, T*, T*, T*, int, T, int*, int*);     \
   template hipError_t launch_transpose<T>(hipStream_t, const T*, T*, int, int, int, int);                   \
   template hipError_t launch_neurons<T>(hipStream_t, const NeuronsBatch<T>&, int); \
   template hipError_t launch_pes<T>(hipStream_t, T*, const T*, const T*, int, int, int, T);                 \

@@ -119,7 +119,12 @@ struct DftArgs {
   int kind;              // 1 A, 2 B, 3 A conj, 4 B conj (forward, 4 slots per half-spectrum bin); 5 inverse
   int set;               // 1: dst = result, 0: dst += result
   int nr;                // number of radices
-  int radix[12];         // product = N, each <= 32
+  int radix[12];         // product = N (or M), each <= 32
+  // Bluestein (N has a prime factor > 32 - 97, 1801, 2049 = 3 * 683): the length-N DFT as a circular convolution of
+  // length M >= 2N - 1 (M = 2^a 3^b 5^c, `radix` then factors M and `tw` has M entries)
+  int M;                 // 0: N is transformed directly
+  const float2* chirp;   // w_n = exp(-i pi n^2 / N), n = 0..N-1
+  const float2* fb;      // FFT_M of the wrapped conjugate chirp, divided by M
 };
 
 // Independent operators of one kind that the scheduler placed next to each other share one launch
@@ -131,7 +136,7 @@ template <typename T> struct NeuronsArgs { NeuronParams<T> np; const T* J; T* ou
 template <typename T> struct NeuronsBatch { NeuronsArgs<T> a[MAX_BATCH]; };
 struct DftBatch { DftArgs a[MAX_BATCH]; };
 template <typename T> struct SpmvArgs { const T* Wt; int ldt; const T* spikes; int n, rows; T* partial; int rows_pad, chunks; const int* list; const int* count;
-                                       int seg; T* out; int out_set; unsigned int* tickets; };
+                                       int seg; };
 template <typename T> struct SpmvBatch { SpmvArgs<T> a[MAX_BATCH]; };
 constexpr int MAX_ENS_BATCH = 2;
 template <typename T> struct EnsBatch { EnsArgs<T> a[MAX_ENS_BATCH]; };
@@ -152,10 +157,7 @@ struct MicroOp {
   long long i0, i1;
 };
 
-// LDS-staged programs: the signal ranges a program touches are loaded into LDS once, its operators run there
-// (their offsets are pre-translated by the host), dirty ranges are written back once.
-struct ProgSeg { long long goff; int loff; int len; int dirty; int pad; };
-struct ProgDesc { int op_begin, op_count, seg_begin, seg_count; };
+struct ProgDesc { int op_begin, op_count; };
 
 struct TableSlot {     // lives in device memory; re-pointed by ssn_set_table without re-planning
   const void* rows;    // [n_rows][width] in simulator dtype
@@ -204,18 +206,12 @@ template <typename T> hipError_t launch_ens_finish(hipStream_t, const FinishArgs
 template <typename T> hipError_t launch_dft(hipStream_t, const DftBatch&, int count);   // (T only selects the translation unit)
 template <typename T> hipError_t launch_ens_block(hipStream_t, const BlockArgs<T>&);
 template <typename T> bool ens_block_supported(int din, int dout, int n, int* threads, int* tpb, int* npt, int* enc_lds);
-template <typename T> hipError_t launch_program(hipStream_t, const MicroOp<T>* ops, const ProgDesc* progs, int n_progs, const ProgSeg* segs,
-                                               int lds_bytes, T* sig, StepCtx* ctx);
-template <typename T> hipError_t program_set_max_lds(int bytes);
+template <typename T> hipError_t launch_program(hipStream_t, const MicroOp<T>* ops, const ProgDesc* progs, int n_progs, T* sig, StepCtx* ctx);
 template <typename T> hipError_t launch_vecops(hipStream_t, const MicroOp<T>* ops, int n_ops, int wgs, T* sig, const StepCtx* ctx);
 template <typename T> hipError_t launch_matvec(hipStream_t, const MatvecBatch<T>&, int count);
 template <typename T> hipError_t launch_matvec_ordered(hipStream_t, const T* Wt, const T* x, T* y, int rows, int cols, int ldt);
 template <typename T> hipError_t launch_transpose(hipStream_t, const T* src, T* dst, int rows, int cols, int ld, int ldt);
 template <typename T> hipError_t launch_spmv_partial(hipStream_t, const SpmvBatch<T>&, int count);
-template <typename T> hipError_t launch_spmv_rows(hipStream_t, const T* Wt, int ldt, const T* spikes, int n, int rows, const int* list, const int* count,
-                                                  T* out, int out_set);
-template <typename T> hipError_t launch_neurons_compact(hipStream_t, const NeuronParams<T>&, const T* J, T* out, T* V, T* R, int n, T amp,
-                                                        int* list, int* count);
 template <typename T> hipError_t launch_neurons(hipStream_t, const NeuronsBatch<T>&, int count);
 template <typename T> hipError_t launch_pes(hipStream_t, T* W, const T* err, const T* act, int rows, int cols, int ld, T kappa);
 template <typename T> hipError_t launch_voja(hipStream_t, T* E, const T* spk, const T* key, const T* learn, const T* scale,
