@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSN_ABI_VERSION 3
+#define SSN_ABI_VERSION 4
 
 enum ssn_status {
   SSN_OK = 0,
@@ -82,7 +82,7 @@ typedef struct ssn_op_desc {
   int32_t stage;        /* 0 pre, 1 core (stepped one timestep at a time), 2 post; pre/post run time-batched  */
   int32_t border;       /* position in the time-batched order of its stage (pre/post), else -1              */
   int32_t src_prev;     /* batched: source operand is a synapse state read before its update (previous row) */
-  int32_t reserved;
+  int32_t phase;        /* neuron-sharded models: 0 = before the per-timestep exchange, 1 = after it (the updates)  */
   int64_t i[12];
   double f[4];
 } ssn_op_desc;
@@ -117,6 +117,12 @@ typedef struct ssn_model_desc {
   int32_t n_core_to_post;
   const ssn_range* pre_to_core;
   const ssn_range* core_to_post;
+  /* Neuron-sharded model (one rank of a SLAMNetwork split over several GPUs): the partial sums in these signal
+   * ranges are completed by an all-reduce between the two phases of every timestep.  The library does not communicate: the
+   * caller steps with ssn_run_phase(0), exchanges (ssn_exchange_pack -> all-reduce -> ssn_exchange_unpack), ssn_run_phase(1). */
+  int32_t n_exchange;
+  int32_t reserved;
+  const ssn_range* exchange;
   int32_t block_steps;                /* timesteps per time-batched block; 0 = library default (1024, or 256 for very wide models) */
   int32_t flags;                      /* debug / A-B switches (default 0; tests check that every alternative plan gives the same results):
                                          1 = no fused recurrent-array core (generic programs),
@@ -205,6 +211,14 @@ int ssn_read_signal(ssn_sim* sim, int64_t off, int64_t count, double* dst);
 int ssn_write_signal(ssn_sim* sim, int64_t off, int64_t count, const double* src);
 int ssn_read_buffer(ssn_sim* sim, int32_t buffer_id, double* dst, int64_t count);
 int ssn_write_buffer(ssn_sim* sim, int32_t buffer_id, const double* src, int64_t count);
+
+/* Neuron-sharded models: one half of a timestep (phase 0: everything up to the exchange; phase 1: the updates, probe
+ * sampling, step counter).  Blocking.  ssn_run_steps refuses such models. */
+int ssn_run_phase(ssn_sim* sim, int32_t phase);
+/* Elements of the exchange (sum of the range lengths); copy them to / from one contiguous device buffer of the simulator's dtype. */
+int64_t ssn_exchange_size(ssn_sim* sim);
+int ssn_exchange_pack(ssn_sim* sim, void* dst_dev);
+int ssn_exchange_unpack(ssn_sim* sim, const void* src_dev);
 
 int ssn_get_counters(ssn_sim* sim, ssn_counters* out);
 /* Fills at most `capacity` entries; returns the number of kernels with timed launches (or a negative status). */

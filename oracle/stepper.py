@@ -81,6 +81,10 @@ class OracleSimulator:
         self.dtype = np.dtype(dtype)
         self.reset()
 
+    def exchange_hook(self, sig, ranges):
+        """All-reduce(sum) of ``sig[lo:hi]`` over the ranks of a neuron-sharded run; installed by the sharded runner."""
+        raise RuntimeError("this model was built with neuron_shard=...: step it through sharding.ShardedSLAM, which supplies the exchange")
+
     def reset(self):
         m = self.model
         self.sig = m.sig_init.astype(self.dtype).copy()
@@ -119,8 +123,13 @@ class OracleSimulator:
         # deltas of steps < t.  The pes / voja operators below add this step's delta at once, so sample first.
         learned_samples = {i: np.array(buf[self._probe_buffer(p)], dtype=np.float64)
                            for i, p in enumerate(m.probes) if "src" not in p and self.n_steps % p["every"] == 0}
+        exchanged = not getattr(m, "exchange", None)
         for o in m.ops:
             k = o["kind"]
+            if not exchanged and o.get("phase", 0) == 1:
+                # neuron-sharded model (builder.shard_phases): the partial sums are completed before the first update
+                self.exchange_hook(sig, m.exchange)
+                exchanged = True
             if k == "fill":
                 sig[o["dst"]:o["dst"] + o["len"]] = o["value"]
             elif k == "table":

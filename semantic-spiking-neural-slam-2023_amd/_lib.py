@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSN_HIP_LIB") or os.path.join(_HERE, "libssn_hip.so")     # override: A/B builds of the library
 
-SSN_ABI_VERSION = 3
+SSN_ABI_VERSION = 4
 SSN_F32, SSN_F64 = 0, 1
 SSN_BUF_REAL, SSN_BUF_I32 = 0, 1
 NEURON_CODE = {"lif": 0, "lifrate": 1, "relu": 2}
@@ -24,7 +24,7 @@ class BufferDesc(C.Structure):
 
 class OpDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("level", C.c_int32), ("stage", C.c_int32), ("border", C.c_int32),
-                ("src_prev", C.c_int32), ("reserved", C.c_int32), ("i", C.c_int64 * 12), ("f", C.c_double * 4)]
+                ("src_prev", C.c_int32), ("phase", C.c_int32), ("i", C.c_int64 * 12), ("f", C.c_double * 4)]
 
 
 class ProbeDesc(C.Structure):
@@ -41,8 +41,9 @@ class ModelDesc(C.Structure):
                 ("n_buffers", C.c_int32), ("n_ops", C.c_int32), ("n_probes", C.c_int32),
                 ("steps_per_graph", C.c_int32), ("buffers", C.POINTER(BufferDesc)), ("ops", C.POINTER(OpDesc)),
                 ("probes", C.POINTER(ProbeDesc)), ("n_pre_to_core", C.c_int32), ("n_core_to_post", C.c_int32),
-                ("pre_to_core", C.POINTER(Range)), ("core_to_post", C.POINTER(Range)), ("block_steps", C.c_int32),
-                ("flags", C.c_int32)]
+                ("pre_to_core", C.POINTER(Range)), ("core_to_post", C.POINTER(Range)),
+                ("n_exchange", C.c_int32), ("reserved", C.c_int32), ("exchange", C.POINTER(Range)),
+                ("block_steps", C.c_int32), ("flags", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -72,6 +73,10 @@ EXPORTS = {
     "ssn_write_signal": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "ssn_read_buffer": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "ssn_write_buffer": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
+    "ssn_run_phase": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ssn_exchange_size": (C.c_int64, [C.c_void_p]),
+    "ssn_exchange_pack": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ssn_exchange_unpack": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ssn_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "ssn_get_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int32]),
     "ssn_n_steps": (C.c_int64, [C.c_void_p]),

@@ -167,14 +167,25 @@ def dft_structure(T):
 
 class Builder:
     def __init__(self, network, dt=0.001, seed=None, n_eval_points=None, solver_backend="auto",
-                 vco_shard=None, progress=None, probes=None, prune=False, staged=True):
+                 vco_shard=None, progress=None, probes=None, prune=False, staged=True, neuron_shard=None, replicate=()):
         self.net, self.dt = network, float(dt)
         self.n_eval_points = n_eval_points
         self.solver_backend = solver_backend
         self.vco_shard = vco_shard           # (rank, world): build only this rank's slice of every EnsembleArray
+        # (rank, world): the rank's share of EVERY neuron population (SLAMNetwork): EnsembleArrays are split over
+        # ensembles, dense ensembles over neurons (rows of the encoders, columns of the decoders / PES matrix); every
+        # decoded vector is then a partial sum, completed by ONE all-reduce per timestep (shard_phases below).  Ensembles
+        # in `replicate` are kept whole on every rank (their decoded output reaches other neurons within the timestep).
+        self.neuron_shard = neuron_shard
+        self.replicated = {id(e) for e in replicate}
+        if neuron_shard is not None:
+            if vco_shard is not None:
+                raise fe.BuildError("vco_shard and neuron_shard are alternatives")
+            self.vco_shard = neuron_shard      # EnsembleArrays: the same split over ensembles
+            staged = False                     # (every operator in the per-timestep core: the exchange cuts the timestep in two)
         self.progress = progress
         self.r_allocs = []
-        self.staged = staged
+        self.staged = staged and neuron_shard is None
         self.probes_override = probes        # build with these probes instead of the network's own
         self.prune = prune                   # drop operators that no probe (transitively) depends on
         self.model = BuiltModel(dt)
@@ -253,8 +264,8 @@ class Builder:
             if id(e) in self.block_of:
                 continue
             self.ens_in[id(e)] = self.alloc("R", e.dimensions)
-            self.ens_J[id(e)] = self.alloc("R", e.n_neurons)
-            self.ens_spk[id(e)] = self.alloc("W", e.n_neurons)
+            self.ens_J[id(e)] = self.alloc("R", self._local_count(e))
+            self.ens_spk[id(e)] = self.alloc("W", self._local_count(e))
             self.dense_rows[id(e)] = []
         for n in nodes:
             self._alloc_node(n)
@@ -461,6 +472,33 @@ class Builder:
         T = np.asarray(T, dtype=float)
         callback(D * float(T) if T.ndim == 0 else T @ D)
 
+    def _neuron_range(self, e):
+        """[lo, hi): the neurons of dense ensemble ``e`` this rank steps (all of them without neuron sharding)."""
+        if self.neuron_shard is None or id(e) in self.replicated or id(e) in getattr(self, "block_of", {}):
+            return 0, e.n_neurons
+        rank, world = self.neuron_shard
+        per = -(-e.n_neurons // world)
+        return min(e.n_neurons, rank * per), min(e.n_neurons, (rank + 1) * per)
+
+    def _local_count(self, e):
+        """Neurons of ``e`` in this rank's arrays: every rank's share is padded to the same size (silent neurons: zero
+        bias, encoders and decoders), so that the signal layout - and with it the exchange ranges - is the same on all ranks."""
+        if self.neuron_shard is None or id(e) in self.replicated or id(e) in getattr(self, "block_of", {}):
+            return e.n_neurons
+        return -(-e.n_neurons // self.neuron_shard[1])
+
+    @staticmethod
+    def _pad_rows(a, n):
+        a = np.asarray(a, dtype=float)
+        if a.shape[0] == n:
+            return a
+        out = np.zeros((n,) + a.shape[1:])
+        out[:a.shape[0]] = a
+        return out
+
+    def _is_sharded(self, e):
+        return self.neuron_shard is not None and id(e) not in self.replicated
+
     def _is_local(self, e):
         """False for EnsembleArray members owned by another rank of a VCO-sharded build."""
         if id(e) not in self.block_of:
@@ -482,6 +520,8 @@ class Builder:
             ens = obj.ensemble
             if id(ens) in self.block_of:
                 raise fe.BuildError("direct neuron input into an EnsembleArray member is not supported")
+            if self._is_sharded(ens) and length is not None:
+                raise fe.BuildError("slices of the neurons of a neuron-sharded ensemble are not supported")
             full = self.ens_J[id(ens)]
         elif k == "rule":
             full = self._rule_input(obj)
@@ -529,6 +569,9 @@ class Builder:
                     raise fe.BuildError("only Voja on a plain Node -> Ensemble connection is supported")
                 self._lower_voja(c, src, post_obj, float(T), rule)
                 return
+            if _kind(post_obj) == "neurons" and T.ndim == 2:
+                lo, hi = self._neuron_range(post_obj.ensemble)      # direct neuron input: this rank's rows of the transform
+                T = self._pad_rows(T[lo:hi], self._local_count(post_obj.ensemble))
             if T.ndim == 0:
                 self._apply_synapse(c, src, dst, size_out, gain=float(T))
             elif T.ndim == 1:
@@ -542,6 +585,8 @@ class Builder:
             ens = pre_obj.ensemble
             if id(ens) in self.block_of:
                 raise fe.BuildError("connections from the neurons of an EnsembleArray member are not supported")
+            if self._is_sharded(ens):
+                raise fe.BuildError("connections from the neurons of a neuron-sharded ensemble are not supported")
             full = self.ens_spk[id(ens)]
             src = full if pre_len is None else full.slice(pre_start, pre_len)
             if T.ndim == 0:
@@ -566,6 +611,10 @@ class Builder:
                 bc.weights = W
                 self._register_rows(e, W, w)
             self._request_decoders(c, e, pre_start, pre_len, T, done)
+        elif self.neuron_shard is not None:
+            # neuron sharding: the slot is this rank's (zero) share of a sum that the exchange completes in place - it has to
+            # be cleared again every timestep
+            self.op("fill", dst=w, len=size_out, value=0.0, partial_zero=True)
         self._apply_synapse(c, w, dst, size_out)
 
     def _lower_matrix(self, c, T, src, dst):
@@ -589,30 +638,35 @@ class Builder:
                 if np.any(W[r]):
                     blk["rows"][i].append((W[r], w_ref.slice(r, 1)))
         else:
-            self.dense_rows[id(e)].append((W, w_ref))
+            lo, hi = self._neuron_range(e)
+            self.dense_rows[id(e)].append((self._pad_rows(W[:, lo:hi].T, self._local_count(e)).T, w_ref))
 
     def _lower_pes(self, c, e, pre_start, pre_len, T, dst, rule):
         if id(e) in self.block_of:
             raise fe.BuildError("PES on an EnsembleArray member is not supported")
         size_out, n = dst.len, e.n_neurons
-        b = self.model.add_buffer(np.zeros((size_out, n)), f"pes_decoders_{len(self.model.buffers)}", role="learned")
+        lo, hi = self._neuron_range(e)           # neuron sharding: this rank learns its columns of the decoder matrix
+        nl = self._local_count(e)
+        b = self.model.add_buffer(np.zeros((size_out, nl)), f"pes_decoders_{len(self.model.buffers)}", role="learned")
         self.model.params[c].learned_buffer = b
+        self.model.params[c].learned_columns = (lo, hi)
 
-        def done(W, b=b, c=c):
-            self.model.buffers[b][...] = W
-            self.model.params[c].weights = self.model.buffers[b]
+        def done(W, b=b, c=c, lo=lo, hi=hi):
+            self.model.buffers[b][:, :hi - lo] = W[:, lo:hi]
+            self.model.params[c].weights = W
         self._request_decoders(c, e, pre_start, pre_len, T, done)
         w = self.alloc("W", size_out)
         spk = self.ens_spk[id(e)]
-        self.op("matvec", dst=w, src=spk, rows=size_out, cols=n, w=b, mode="set")
+        self.op("matvec", dst=w, src=spk, rows=size_out, cols=nl, w=b, mode="set", partial_out=self._is_sharded(e))
         self._apply_synapse(c, w, dst, size_out)
-        # filtered pre activities (pre_synapse) and the fused delta + increment (Appendix A.7)
-        act = self.alloc("S", n)
+        # filtered pre activities (pre_synapse) and the fused delta + increment (Appendix A.7); kappa uses the size of the
+        # WHOLE pre population (nengo: -lr * dt / n_neurons)
+        act = self.alloc("S", nl)
         tau = float(rule.pre_synapse.tau) if rule.pre_synapse is not None else 0.0
         err = self._rule_input(c.learning_rule)
-        self.op("pes", w=b, rows=size_out, cols=n, err=err, act=act,
+        self.op("pes", w=b, rows=size_out, cols=nl, err=err, act=act,
                 kappa=-float(rule.learning_rate) * self.dt / n)
-        self.op("lowpass", dst=act, src=spk, len=n, a=_lowpass_coeff(tau, self.dt) if tau > 0 else 0.0, gain=1.0)
+        self.op("lowpass", dst=act, src=spk, len=nl, a=_lowpass_coeff(tau, self.dt) if tau > 0 else 0.0, gain=1.0)
         self.learned[id(c)] = b
 
     def _lower_voja(self, c, src, post_ens, alpha, rule):
@@ -636,14 +690,18 @@ class Builder:
     # -- emit ensembles --------------------------------------------------------------------
     def _emit_dense_ensemble(self, e):
         be = self.built_ens[id(e)]
-        n, d = e.n_neurons, e.dimensions
+        d = e.dimensions
+        lo, hi = self._neuron_range(e)
+        n = self._local_count(e)
+        part = self._is_sharded(e)
         J, spk, x = self.ens_J[id(e)], self.ens_spk[id(e)], self.ens_in[id(e)]
-        bias = self.alloc("C", n, init=be.bias)
+        bias = self.alloc("C", n, init=self._pad_rows(be.bias[lo:hi], n))
         role = "learned" if hasattr(be, "voja") else "param"
-        eb = self.model.add_buffer(np.ascontiguousarray(be.scaled_encoders), f"encoders_{e.label}", role=role)
+        eb = self.model.add_buffer(np.ascontiguousarray(self._pad_rows(be.scaled_encoders[lo:hi], n)), f"encoders_{e.label}", role=role)
         be.encoder_buffer = eb
+        be.neuron_range = (lo, hi)
         self.op("axpy", dst=J, src=bias, len=n, alpha=1.0, mode="inc")
-        self.op("matvec", dst=J, src=x, rows=n, cols=d, w=eb, mode="inc")
+        self.op("matvec", dst=J, src=x, rows=n, cols=d, w=eb, mode="inc", local_out=part)
         vb = self.model.add_buffer(np.zeros(n), f"voltage_{e.label}", role="state")
         rb = self.model.add_buffer(np.zeros(n), f"refractory_{e.label}", role="state")
         be.state_buffers = (vb, rb)
@@ -651,11 +709,12 @@ class Builder:
                 amp=be.neuron["amplitude"] / self.dt if be.neuron["type"] == "lif" else be.neuron["amplitude"])
         for W, w_ref in self.dense_rows[id(e)]:
             b = self.model.add_buffer(np.ascontiguousarray(W), f"decoders_{e.label}_{len(self.model.buffers)}")
-            self.op("matvec", dst=w_ref, src=spk, rows=W.shape[0], cols=n, w=b, mode="set")
+            self.op("matvec", dst=w_ref, src=spk, rows=W.shape[0], cols=n, w=b, mode="set", partial_out=part)
         if hasattr(be, "voja"):
             v = be.voja
             self.op("voja", w=eb, rows=n, cols=d, spk=spk, key=v["key"], learn=v["learn"],
-                    lr_dt=v["lr"] * self.dt, scale_buf=self.model.add_buffer(be.gain / be.radius, f"voja_scale_{e.label}"))
+                    lr_dt=v["lr"] * self.dt,
+                    scale_buf=self.model.add_buffer(self._pad_rows((be.gain / be.radius)[lo:hi], n), f"voja_scale_{e.label}"))
 
     def _live_elements(self, probes):
         """Which signal elements can influence anything observable (a probe, a neuron, a learning rule)?
@@ -763,7 +822,7 @@ class Builder:
                 dec=m.add_buffer(dec, f"{label}_dec"), dst_refs=dst_idx,
                 v=m.add_buffer(np.zeros((K, n)), f"{label}_voltage", role="state"),
                 r=m.add_buffer(np.zeros((K, n)), f"{label}_refractory", role="state"),
-                neuron=nd, label=label, k_lo=lo, k_total=K_all)
+                neuron=nd, label=label, k_lo=lo, k_total=K_all, partial_out=bool(self.neuron_shard is not None and K < K_all))
 
     # -- probes ----------------------------------------------------------------------------
     def _lower_probe(self, p):
@@ -801,6 +860,8 @@ class Builder:
             e = obj.ensemble
             if id(e) in self.block_of:
                 raise fe.BuildError("probing neurons of an EnsembleArray member is not supported yet")
+            if self._is_sharded(e):
+                raise fe.BuildError("probing the neurons of a neuron-sharded ensemble is not supported")
             full = self.ens_spk[id(e)]
         else:
             raise fe.BuildError(f"unsupported probe target {obj!r}")
@@ -851,6 +912,8 @@ class Builder:
             ops = prune_ops(ops, m)
         r_allocs = [(base["R"] + off, ln) for off, ln in self.r_allocs]
         m.ops = stage_ops(ops, m, r_allocs, schedule_ops, op_access, _overlap, enable=self.staged)
+        if self.neuron_shard is not None:
+            shard_phases(m, self.neuron_shard)
         m.stats.update(n_raw_ops=len(self.raw_ops), n_ops=len(m.ops), sig_size=m.sig_size,
                        n_buffers=len(m.buffers))
 
@@ -864,7 +927,7 @@ def merge_ops(ops, model):
     for o in ops:
         k = o["kind"]
         if k == "fill":
-            key = ("fill", o["value"])
+            key = ("fill", o["value"], bool(o.get("partial_zero")))
         elif k == "axpy":
             key = ("axpy", o["alpha"], o["mode"], o["dst"] - o["src"])
         elif k == "lowpass":
@@ -977,6 +1040,139 @@ def prune_ops(ops, model):
     return [o for o, k in zip(ops, keep) if k]
 
 
+def shard_phases(model, shard):
+    """Neuron-sharded model (SLAMNetwork on several GPUs): cut the timestep in two around ONE exchange.
+
+    Every rank steps its share of each neuron population, so what its neurons decode is a partial sum.  Linear operators
+    commute with the sum; the non-linear consumers of decoded values are neurons, function nodes and - through a synapse,
+    i.e. one timestep later - everything else.  So the timestep becomes
+
+        phase 0: every operator except the updates (Lowpass, PES, Voja), on partial data where data is partial
+        exchange: all-reduce(sum) of the partial signals the updates (and probes) read - ``model.exchange`` ranges
+        phase 1: the updates, then probe sampling
+
+    which is a valid nengo order (updates come last for every signal; they keep their relative order).  A forward pass
+    over the operators tracks which elements are replicated / partial and refuses models in which partial data would reach a
+    non-linear operator within the timestep (the ensemble in question has to be replicated: ``replicate=``) or in which a
+    replicated and a partial term meet in one accumulator."""
+    rank, world = shard
+    ops = model.ops
+    n = model.sig_size
+    full = np.zeros(n, dtype=bool)
+    part = np.zeros(n, dtype=bool)
+    base, size = model.arena_base, model.arena_size
+    for a in "SCT":
+        full[base[a]:base[a] + size[a]] = True           # states, constants, tables: identical on every rank
+
+    def need_full(lo, ln, what):
+        if part[lo:lo + ln].any():
+            raise fe.BuildError(f"neuron sharding: {what} would read a partial sum within the timestep - replicate its source "
+                                "ensemble (build(..., replicate=[...]))")
+
+    exchange = []
+    phase = []
+    for o in ops:
+        k = o["kind"]
+        ph = 1 if k in ("lowpass", "pes", "voja") else 0
+        phase.append(ph)
+        if k == "fill":
+            sl = slice(o["dst"], o["dst"] + o["len"])
+            full[sl] = o["value"] != 0.0
+            part[sl] = bool(o.get("partial_zero"))       # another rank's share of a decoded sum: this rank adds 0
+        elif k == "table":
+            sl = slice(o["dst"], o["dst"] + o["width"])
+            full[sl], part[sl] = True, False
+        elif k == "axpy":
+            d, sr = slice(o["dst"], o["dst"] + o["len"]), slice(o["src"], o["src"] + o["len"])
+            if o["mode"] == "set":
+                full[d], part[d] = full[sr].copy(), part[sr].copy()
+            else:
+                full[d] |= full[sr]
+                part[d] |= part[sr]
+        elif k == "matvec":
+            d = slice(o["dst"], o["dst"] + o["rows"])
+            sr = slice(o["src"], o["src"] + o["cols"])
+            if o.get("partial_out"):
+                f_new, p_new = np.zeros(o["rows"], bool), np.ones(o["rows"], bool)
+            elif o.get("local_out"):
+                need_full(o["src"], o["cols"], "an encoder product")
+                f_new, p_new = np.ones(o["rows"], bool), np.zeros(o["rows"], bool)
+            else:
+                if model.buffer_meta[o["w"]]["role"] == "param":
+                    nz = model.buffers[o["w"]] != 0
+                    f_new, p_new = (nz & full[sr][None, :]).any(axis=1), (nz & part[sr][None, :]).any(axis=1)
+                else:
+                    f_new, p_new = np.full(o["rows"], full[sr].any()), np.full(o["rows"], part[sr].any())
+            if o["mode"] == "set":
+                full[d], part[d] = f_new, p_new
+            else:
+                full[d] |= f_new
+                part[d] |= p_new
+        elif k == "ensarray":
+            need_full(o["x"], o["K"] * o["din"], "an ensemble array")
+            idx = model.buffers[o["dst_idx"]].reshape(-1)
+            full[idx], part[idx] = (not o.get("partial_out")), bool(o.get("partial_out"))
+        elif k == "neurons":
+            sl = slice(o["out"], o["out"] + o["n"])
+            full[sl], part[sl] = True, False             # (a rank's own spike vector: local, never exchanged)
+        elif k in ("gate", "cleanup"):
+            ln = 2 * o["d"] + 1 if k == "gate" else o["cols"]
+            need_full(o["src"], ln, f"the {k} node")
+            w = o["d"] if k == "gate" else o["cols"]
+            full[o["dst"]:o["dst"] + w], part[o["dst"]:o["dst"] + w] = True, False
+        elif k == "lowpass":
+            sr = slice(o["src"], o["src"] + o["len"])
+            if part[sr].any():
+                exchange.append((o["src"], o["src"] + o["len"]))
+        elif k == "pes":
+            need_full(o["err"], o["rows"], "the PES error")
+        elif k == "voja":
+            need_full(o["key"], o["cols"], "the Voja key")
+    for p in model.probes:
+        if "src" in p and part[p["src"]:p["src"] + p["width"]].any():
+            exchange.append((p["src"], p["src"] + p["width"]))
+    # only the partial elements of what the updates read are summed (a merged Lowpass may span a replicated vector too)
+    want = np.zeros(n, dtype=bool)
+    for lo, hi in exchange:
+        want[lo:hi] = True
+    want &= part
+    if (want & full).any():
+        bad = int(np.flatnonzero(want & full)[0])
+        raise fe.BuildError(f"neuron sharding: a replicated and a partial term are added into one signal (element {bad}): "
+                            "the all-reduce would count the replicated one once per rank")
+    edges = np.flatnonzero(np.diff(np.concatenate(([0], want.view(np.int8), [0]))))
+    merged = []
+    for lo, hi in zip(edges[::2], edges[1::2]):
+        # short gaps of elements nobody writes (dropped dead rows: zero on every rank) are summed along: one range per
+        # ensemble array instead of one per ensemble
+        if merged and lo - merged[-1][1] <= 8 and not (full[merged[-1][1]:lo] | part[merged[-1][1]:lo]).any():
+            merged[-1][1] = int(hi)
+        else:
+            merged.append([int(lo), int(hi)])
+    merged = [(lo, hi) for lo, hi in merged]
+    a_ops = [dict(o) for o, ph in zip(ops, phase) if ph == 0]
+    b_ops = [dict(o) for o, ph in zip(ops, phase) if ph == 1]
+    out = []
+    level0 = 0
+    for ph, sub in ((0, a_ops), (1, b_ops)):
+        for o in sub:
+            for key in ("level", "micro"):
+                o.pop(key, None)
+        sched = schedule_ops(sub, model)
+        for o in sched:
+            o["level"] += level0
+            o["phase"] = ph
+            o["stage"], o["border"], o["src_prev"] = 1, -1, 0
+        level0 = (max(o["level"] for o in sched) + 1) if sched else level0
+        out.extend(sched)
+    model.ops = out
+    model.exchange = [(int(lo), int(hi)) for lo, hi in merged]
+    model.shard = (int(rank), int(world))
+    info = getattr(model, "stage_info", None)
+    if info is not None:
+        info["enabled"] = False
+
+
 def _overlap(a, b):
     if a[0] != b[0]:
         return False
@@ -1046,8 +1242,9 @@ def schedule_ops(ops, model):
 
 
 def build(network, dt=0.001, seed=None, n_eval_points=None, solver_backend="auto", vco_shard=None,
-          probes=None, prune=False, staged=True):
+          probes=None, prune=False, staged=True, neuron_shard=None, replicate=()):
     """Build ``network`` into a :class:`BuiltModel`.  ``staged=False`` keeps every operator in the
     per-timestep core (no time-batched pre/post stages)."""
     return Builder(network, dt=dt, seed=seed, n_eval_points=n_eval_points, solver_backend=solver_backend,
-                   vco_shard=vco_shard, probes=probes, prune=prune, staged=staged).build()
+                   vco_shard=vco_shard, probes=probes, prune=prune, staged=staged, neuron_shard=neuron_shard,
+                   replicate=replicate).build()

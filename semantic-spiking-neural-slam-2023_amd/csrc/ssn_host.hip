@@ -83,6 +83,9 @@ struct ssn_sim {
                         const int32_t* idx, int64_t n_idx, int64_t first_step) = 0;
   virtual int reserve_probes(int64_t n) = 0;
   virtual int run_steps(int64_t n, int profile) = 0;
+  virtual int run_phase(int phase) = 0;
+  virtual int64_t exchange_size() = 0;
+  virtual int exchange_copy(void* buf, bool pack) = 0;
   virtual int read_probe(int id, double* dst, void* dst_dev, int64_t first, int64_t count) = 0;
   virtual int64_t probe_count(int id) = 0;
   virtual int rw_signal(int64_t off, int64_t count, double* dst, const double* src) = 0;
@@ -114,6 +117,7 @@ struct Sim final : ssn_sim {
     int* list = nullptr; int* count = nullptr;     // spike list (k_neurons_compact -> k_spmv_partial)
     int seg = 0;                                   // > 0: segmented spike list (k_neurons), segments per spmv chunk
     int level = -1;                                // scheduling round of the operator (builder): equal level = independent
+    int phase = -1;                                // neuron-sharded models: 0 before the per-timestep exchange, 1 after (set by plan())
     int batch = 1;                                 // this item and the next batch-1 items (same kind, independent) share one launch
     bool merged = false;                           // launched by the item that leads its batch
     ssn::DftArgs dft;
@@ -184,6 +188,12 @@ struct Sim final : ssn_sim {
   double dom_bytes = 0.0;
   int64_t dom_units = 0;
   int launches_per_step = 0;
+  // neuron-sharded model: the timestep's items in two halves around the caller's all-reduce
+  std::vector<ssn_range> exchange;
+  bool phased = false;
+  int next_phase = 0;
+  hipGraphExec_t phase_exec[2] = {nullptr, nullptr};
+  hipGraph_t phase_graph[2] = {nullptr, nullptr};
   static constexpr int N_ITEM_TYPES = 16;
   double type_ms[N_ITEM_TYPES] = {};             // profile = 2: device time per plan-item type
   int64_t type_launches[N_ITEM_TYPES] = {};
@@ -195,6 +205,10 @@ struct Sim final : ssn_sim {
     if (stream) hipStreamSynchronize(stream);
     if (graph_exec) hipGraphExecDestroy(graph_exec);
     if (graph) hipGraphDestroy(graph);
+    for (int h = 0; h < 2; ++h) {
+      if (phase_exec[h]) hipGraphExecDestroy(phase_exec[h]);
+      if (phase_graph[h]) hipGraphDestroy(phase_graph[h]);
+    }
     for (auto& b : bufs) if (b.d) hipFree(b.d);
     for (auto p : table_rows) if (p) hipFree(p);
     for (auto p : table_idx) if (p) hipFree(p);
@@ -495,11 +509,15 @@ struct Sim final : ssn_sim {
     for (int i = 0; i < m->n_probes; ++i) pslots[i].every = probes[i].every;
     CHK(dmalloc(&d_pslots, std::max<int64_t>(1, m->n_probes) * (int64_t)sizeof(ssn::ProbeSlot)));
     if (m->n_probes) HIPCHK(hipMemcpy(d_pslots, pslots.data(), pslots.size() * sizeof(ssn::ProbeSlot), hipMemcpyHostToDevice));
+    exchange.assign(m->exchange, m->exchange + (m->n_exchange > 0 ? m->n_exchange : 0));
+    phased = !exchange.empty();
+    for (auto& r : exchange) CHK(check_range(r.lo, r.hi - r.lo, "exchange"));
     // time-batched stages
     bool staged = false;
     for (int i = 0; i < m->n_ops; ++i) staged = staged || m->ops[i].stage != 1;
     for (auto& p : probes) staged = staged || p.stage != 1;
     batched_mask.assign((size_t)n_sig, 0);
+    if (staged && phased) return fail(SSN_EINVAL, "a neuron-sharded model is stepped whole (build it unstaged)");
     if (staged) {
       // default: 1024 timesteps per block while the block buffer stays under 256 MiB, else 256
       block = m->block_steps > 0 ? m->block_steps : ((int64_t)1025 * n_sig * (int64_t)sizeof(T) <= (256ll << 20) ? 1024 : 256);
@@ -901,6 +919,7 @@ struct Sim final : ssn_sim {
     };
     int64_t best_units = -1;
     int best_item = -1;
+    int cur_phase = 0;
     for (auto& r : pre_to_core) {        // the pre stage's results for this timestep
       if (fused) break;
       MOp op{};
@@ -918,6 +937,12 @@ struct Sim final : ssn_sim {
       const ssn_op_desc& o = m->ops[i];
       MOp op{};
       const size_t items_before = items.size();
+      if (phased && o.stage == 1 && o.phase != cur_phase) {      // the exchange: no program spans it
+        if (o.phase < cur_phase) return fail(SSN_EINVAL, "operators of phase 0 after phase 1");
+        flush();
+        for (auto& it : items) if (it.phase < 0) it.phase = cur_phase;
+        cur_phase = o.phase;
+      }
       struct LevelTag { std::vector<Item>& v; size_t from; int level; ~LevelTag() { for (size_t q = from; q < v.size(); ++q) if (v[q].type != IT_PROGRAM && v[q].level < 0) v[q].level = level; } }
           level_tag{items, items_before, o.level};
       if (o.stage == 1 && !fused && !pending_reduce.empty() &&
@@ -1178,6 +1203,8 @@ struct Sim final : ssn_sim {
     }
     force_barrier = true;
     flush();
+    for (auto& it : items) if (it.phase < 0) it.phase = cur_phase;      // (the tail program - probes, step counter - closes phase 1)
+    if (phased && cur_phase != 1) return fail(SSN_EINVAL, "a model with exchange ranges needs operators of phase 1");
     if (best_item >= 0) {
       items[best_item].dominant = true;
       const ssn::EnsArgs<T>& a = items[best_item].ens;
@@ -1188,7 +1215,7 @@ struct Sim final : ssn_sim {
     // argmax + row gather, whose result is first used after the path integrator's ensembles; the chunk reductions
     // of sparse products whose sums are first used behind the next neuron populations) joins that next program -
     // same operators, same order among dependent ones, one launch (~8 us inside the step graph) fewer each.
-    if (!fused && !(flags & 1048576)) {
+    if (!fused && !(flags & 1048576) && !phased) {
       for (bool changed = true; changed;) {
         changed = false;
         analyse_dependencies(programs, item_prog);
@@ -1217,7 +1244,7 @@ struct Sim final : ssn_sim {
     // timestep, so the tail / head fusion is given up: worth it from ~16 k elements on (SLAM config 3: 42 -> ~23 us).
     std::vector<MOp>& vec_ops = vecops_host;
     vec_ops.clear();
-    if (!fused && !(flags & 131072) && !items.empty() && items.front().type == IT_PROGRAM && !programs.empty()) {
+    if (!fused && !(flags & 131072) && !phased && !items.empty() && items.front().type == IT_PROGRAM && !programs.empty()) {
       std::vector<MOp>& head = programs[(size_t)item_prog[0]];
       size_t lv = 0;
       long long elems = 0;
@@ -1260,7 +1287,7 @@ struct Sim final : ssn_sim {
     int pi = 0;
     for (auto& it : items)
       if (it.type == IT_PROGRAM) { it.op_begin = pi; it.op_count = 1; ++pi; }      // op_begin = program index
-    can_fuse = !fused && items.size() >= 2 && items.front().type == IT_PROGRAM && items.back().type == IT_PROGRAM;
+    can_fuse = !fused && !phased && items.size() >= 2 && items.front().type == IT_PROGRAM && items.back().type == IT_PROGRAM;
     if (can_fuse) {
       // the tail is the last program: a copy of the head's descriptor behind it makes [tail, head] one launch
       ssn::ProgDesc hd = prog_descs.front();
@@ -1315,7 +1342,7 @@ struct Sim final : ssn_sim {
       if (lead.type == IT_ENS && (lead.dominant || lead.ens.defer)) continue;
       const int cap = lead.type == IT_ENS ? ssn::MAX_ENS_BATCH : ssn::MAX_BATCH;
       int k = 1;
-      while (i + k < n && k < cap && items[(size_t)(i + k)].type == lead.type) {
+      while (i + k < n && k < cap && items[(size_t)(i + k)].type == lead.type && items[(size_t)(i + k)].phase == lead.phase) {
         const Item& nx = items[(size_t)(i + k)];
         if (lead.type == IT_MATVEC && xlds(nx) != xlds(lead)) break;
         if (lead.type == IT_ENS && (nx.dominant || nx.ens.din != lead.ens.din || nx.ens.dout != lead.ens.dout || nx.ens.fast != lead.ens.fast)) break;
@@ -1624,7 +1651,28 @@ struct Sim final : ssn_sim {
     return on(main_stream, items[(size_t)(n_items - 1)]);
   }
 
+  hipError_t launch_phase(int phase) {
+    for (const Item& it : items) {
+      if (it.phase != phase) continue;
+      hipError_t e = launch_item(it, nullptr, nullptr);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+
   int capture() {
+    if (phased) {             // one graph per half of the timestep
+      if (fused_core || core_empty) return fail(SSN_EUNSUPPORTED, "neuron-sharded models run on the generic per-timestep plan");
+      for (int h = 0; h < 2; ++h) {
+        HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e = launch_phase(h);
+        hipError_t e2 = hipStreamEndCapture(stream, &phase_graph[h]);
+        HIPCHK(e);
+        HIPCHK(e2);
+        HIPCHK(hipGraphInstantiate(&phase_exec[h], phase_graph[h], nullptr, nullptr, 0));
+      }
+      return SSN_OK;
+    }
     if (steps_per_graph <= 1 || fused_block) return SSN_OK;
     const bool dag = (flags & 256) && !fused_core && items.size() >= 4 && item_deps.size() == items.size();
     if (getenv("SSN_DEBUG_PLAN")) {
@@ -1667,8 +1715,46 @@ struct Sim final : ssn_sim {
     return SSN_OK;
   }
 
+  int run_phase(int phase) override {
+    HIPCHK(hipSetDevice(device));
+    if (!phased) return fail(SSN_EINVAL, "ssn_run_phase: the model has no exchange ranges (use ssn_run_steps)");
+    if (phase != next_phase) return fail(SSN_EINVAL, "ssn_run_phase(%d): phase %d is due", phase, next_phase);
+    HIPCHK(hipGraphLaunch(phase_exec[phase], stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    next_phase = 1 - phase;
+    if (phase == 1) {
+      steps_done += 1;
+      ssn::StepCtx ctx;
+      HIPCHK(hipMemcpy(&ctx, d_ctx, sizeof ctx, hipMemcpyDeviceToHost));
+      if (ctx.step != steps_done) return fail(SSN_EHIP, "device step counter %lld != host %lld", (long long)ctx.step, (long long)steps_done);
+      if (ctx.probe_overflow) return fail(SSN_EINVAL, "probe storage overflow: call ssn_reserve_probes before stepping");
+    }
+    return SSN_OK;
+  }
+
+  int64_t exchange_size() override {
+    int64_t n = 0;
+    for (auto& r : exchange) n += r.hi - r.lo;
+    return n;
+  }
+
+  // signal ranges of the exchange <-> one contiguous device buffer (a handful of ranges: one device copy each)
+  int exchange_copy(void* buf, bool pack) override {
+    HIPCHK(hipSetDevice(device));
+    T* b = (T*)buf;
+    for (auto& r : exchange) {
+      const size_t bytes = (size_t)(r.hi - r.lo) * sizeof(T);
+      if (pack) HIPCHK(hipMemcpyAsync(b, sig + r.lo, bytes, hipMemcpyDeviceToDevice, stream));
+      else HIPCHK(hipMemcpyAsync(sig + r.lo, b, bytes, hipMemcpyDeviceToDevice, stream));
+      b += r.hi - r.lo;
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    return SSN_OK;
+  }
+
   int run_steps(int64_t n, int profile) override {
     HIPCHK(hipSetDevice(device));
+    if (phased) return fail(SSN_EINVAL, "a neuron-sharded model is stepped with ssn_run_phase (the caller exchanges between the phases)");
     if (n < 0) return fail(SSN_EINVAL, "negative step count");
     if (n == 0) return SSN_OK;
     int n_dom = 0;
@@ -1806,6 +1892,7 @@ struct Sim final : ssn_sim {
     HIPCHK(hipMemset(d_ctx, 0, sizeof(ssn::StepCtx)));
     CHK(init_bsig());
     steps_done = 0;
+    next_phase = 0;
     reserve_first = reserve_n = 0;
     for (auto& s : pslots) { s.base_slot = 0; s.capacity = 0; }
     if (!pslots.empty()) HIPCHK(hipMemcpy(d_pslots, pslots.data(), pslots.size() * sizeof(ssn::ProbeSlot), hipMemcpyHostToDevice));
@@ -2024,6 +2111,16 @@ int ssn_get_counters(ssn_sim* sim, ssn_counters* out) {
   if (!sim || !out) return fail(SSN_EINVAL, "null argument");
   return sim->counters(out);
 }
+int ssn_run_phase(ssn_sim* sim, int32_t phase) { return sim ? sim->run_phase(phase) : fail(SSN_EINVAL, "null simulator"); }
+int64_t ssn_exchange_size(ssn_sim* sim) { return sim ? sim->exchange_size() : -1; }
+int ssn_exchange_pack(ssn_sim* sim, void* dst_dev) {
+  if (!sim || !dst_dev) return fail(SSN_EINVAL, "null argument");
+  return sim->exchange_copy(dst_dev, true);
+}
+int ssn_exchange_unpack(ssn_sim* sim, const void* src_dev) {
+  if (!sim || !src_dev) return fail(SSN_EINVAL, "null argument");
+  return sim->exchange_copy(const_cast<void*>(src_dev), false);
+}
 int ssn_get_kernel_times(ssn_sim* sim, ssn_kernel_time* out, int32_t capacity) {
   if (!sim || (!out && capacity > 0) || capacity < 0) return fail(SSN_EINVAL, "null argument");
   return sim->kernel_times(out, capacity);
@@ -2034,6 +2131,6 @@ int ssn_device_count(void) {
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 const char* ssn_last_error(void) { return g_err.c_str(); }
-const char* ssn_version(void) { return "libssn_hip 0.4 (gfx950, ABI 3)"; }
+const char* ssn_version(void) { return "libssn_hip 0.5 (gfx950, ABI 4)"; }
 
 }  // extern "C"

@@ -329,3 +329,121 @@ class ShardedPathIntegration:
         for s in (self.sim, self.readout):
             if s is not None and hasattr(s, "close"):
                 s.close()
+
+
+class ShardedSLAM:
+    """One rank of a SLAMNetwork whose neuron populations are split over the ranks (reference
+    ``networks/slam.py:241-307``: the loop through the gate, ``:259,306-307``, closes every timestep, so - unlike the
+    path integrator alone - the ranks exchange once per timestep).
+
+    * EnsembleArrays (the VCOs, the product arrays of the two circular convolutions) are split over ensembles, the dense
+      ensembles ``memory`` / ``recall`` / ``error`` over neurons: rows of their encoders, columns of their decoders - PES
+      learns its own columns, Voja moves its own rows.  ``ovc_ens`` stays whole on every rank: its decoded vector reaches
+      the product neurons within the timestep (``slam.py:262-266``, ``synapse=None``).
+    * Whatever the sharded neurons decode is a partial sum.  Linear operators commute with the sum, and every non-linear
+      consumer sits behind a synapse, so ONE all-reduce per timestep - of the vectors the synapse filters and probes read
+      (``builder.shard_phases``: ``model.exchange``) - completes them: phase 0, all-reduce, phase 1 (updates + probes).
+    * RCCL (torch.distributed "nccl") keeps the exchange in HBM: ``ssn_exchange_pack`` -> ``all_reduce`` ->
+      ``ssn_exchange_unpack``; gloo (tests, CPU) goes through the host.
+
+    ``sim_factory(model)`` is injectable: the tests run the orchestration on the NumPy oracle."""
+
+    def __init__(self, sm, rank, world, dt=0.001, dtype="f32", device=0, n_eval_points=None, sim_factory=None, dist=None,
+                 replicate=None):
+        if dist is None:
+            import torch.distributed as dist
+        self.dist, self.rank, self.world, self.dt, self.dtype = dist, rank, world, dt, dtype
+        self.sm = sm
+        if replicate is None:
+            replicate = [sm.slam.ovc_ens]
+        self.model = build(sm.model, dt=dt, n_eval_points=n_eval_points, neuron_shard=(rank, world), replicate=replicate)
+        if sim_factory is None:
+            from .simulator import Simulator
+
+            def sim_factory(model):
+                return Simulator(None, model=model, dtype=dtype, device=device)
+        self.sim = sim_factory(self.model)
+        self.n_steps = 0
+        self._buf = None
+        if not hasattr(self.sim, "run_phase"):          # oracle-backed stand-in: the stepper calls back between the phases
+            self.sim.set_exchange(self._allreduce_host)
+
+    # -- the exchange ---------------------------------------------------------------------------------------------
+    def _allreduce_host(self, vec):
+        """In-place sum of a float64 vector over the ranks."""
+        if self.world == 1 or not self.dist.is_initialized():
+            return
+        import torch
+        t = torch.from_numpy(vec)
+        if self.dist.get_backend() == "nccl":
+            d = t.cuda()
+            self.dist.all_reduce(d)
+            t.copy_(d.cpu())
+        else:
+            self.dist.all_reduce(t)
+
+    def _exchange(self):
+        dev = self.world > 1 and self.dist.is_initialized() and self.dist.get_backend() == "nccl" and hasattr(self.sim, "exchange_pack")
+        if not dev:
+            self.sim.exchange_host(self._allreduce_host)
+            return
+        import torch
+        if self._buf is None:
+            tdt = torch.float32 if self.dtype == "f32" else torch.float64
+            self._buf = torch.empty(self.sim.exchange_size(), dtype=tdt, device=torch.device("cuda", torch.cuda.current_device()))
+        self.sim.exchange_pack(self._buf.data_ptr())        # (blocking: the copies run on the simulator's stream)
+        self.dist.all_reduce(self._buf)
+        torch.cuda.current_stream().synchronize()
+        self.sim.exchange_unpack(self._buf.data_ptr())
+
+    # -- running ----------------------------------------------------------------------------------------------------
+    def prepare(self, n_steps):
+        self.sim.prepare(n_steps)
+
+    def run_steps(self, n):
+        if hasattr(self.sim, "run_phase"):
+            for _ in range(int(n)):
+                self.sim.run_phase(0)
+                self._exchange()
+                self.sim.run_phase(1)
+        else:
+            self.sim.run_steps(n)
+        self.n_steps += int(n)
+
+    # -- results ----------------------------------------------------------------------------------------------------
+    def probe_data(self, probe=None):
+        """A signal probe (by default the filtered PathIntegration output): identical on every rank after the exchange."""
+        return self.sim.data[self.sm.probe if probe is None else probe]
+
+    def _gather_rows(self, local, n_total):
+        """(per, ...) local share of every rank -> (n_total, ...) on every rank."""
+        import torch
+        local = np.ascontiguousarray(local, dtype=np.float64)
+        if self.world == 1 or not self.dist.is_initialized():
+            return local[:n_total]
+        t = torch.from_numpy(local)
+        if self.dist.get_backend() == "nccl":
+            t = t.cuda()
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return torch.cat(outs, dim=0).cpu().numpy()[:n_total]
+
+    def learned_decoders(self, conn):
+        """The whole PES-learned decoder matrix (size_out, n_neurons) of ``conn``, gathered from the ranks' column shares."""
+        bc = self.model.params[conn]
+        local = self.sim.read_buffer(bc.learned_buffer)
+        n = _contig_obj(conn.pre).n_neurons
+        return self._gather_rows(local.T, n).T
+
+    def learned_encoders(self, ens):
+        """The whole Voja-moved scaled-encoder matrix (n_neurons, d) of ``ens``."""
+        local = self.sim.read_buffer(self.model.params[ens].encoder_buffer)
+        return self._gather_rows(local, ens.n_neurons)
+
+    def close(self):
+        if hasattr(self.sim, "close"):
+            self.sim.close()
+
+
+def _contig_obj(x):
+    return x.obj if hasattr(x, "obj") and hasattr(x, "slice") else x

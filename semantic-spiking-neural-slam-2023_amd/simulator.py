@@ -70,6 +70,7 @@ def pack_model(model, dtype, device=0, steps_per_graph=0, block_steps=0, flags=0
         d.stage = int(o.get("stage", 1))
         d.border = int(o.get("border", -1))
         d.src_prev = int(o.get("src_prev", 0))
+        d.phase = int(o.get("phase", 0))
         ii, ff = [0] * 12, [0.0] * 4
         if k == "fill":
             ii[:2] = [o["dst"], o["len"]]
@@ -142,7 +143,12 @@ def pack_model(model, dtype, device=0, steps_per_graph=0, block_steps=0, flags=0
     desc.pre_to_core, desc.core_to_post = r_p2c, r_c2p
     desc.block_steps = int(block_steps)
     desc.flags = int(flags)
-    keep += [bufs, ops, probes, r_p2c, r_c2p]
+    xr = getattr(model, "exchange", None) or []
+    r_x = (_lib.Range * max(1, len(xr)))()
+    for j, (lo, hi) in enumerate(xr):
+        r_x[j].lo, r_x[j].hi = int(lo), int(hi)
+    desc.n_exchange, desc.exchange = len(xr), r_x
+    keep += [bufs, ops, probes, r_p2c, r_c2p, r_x]
     return desc, keep, sig_probes
 
 
@@ -447,6 +453,34 @@ class Simulator:
         c = _lib.Counters()
         self._check(self._lib.ssn_get_counters(self._h, C.byref(c)))
         return {f: getattr(c, f) for f, _ in c._fields_}
+
+    # -- neuron-sharded models (builder.shard_phases): the caller completes the partial sums between the phases ---------
+    def run_phase(self, phase):
+        if phase == 0 and self._prepared_until < self.n_steps + 1:
+            raise fe.SimulationError("neuron-sharded model: call prepare(n_steps) before stepping")
+        self._check(self._lib.ssn_run_phase(self._h, int(phase)))
+        if phase == 1:
+            self.n_steps += 1
+            self._uncollected = True
+
+    def exchange_size(self):
+        return int(self._lib.ssn_exchange_size(self._h))
+
+    def exchange_pack(self, dev_ptr):
+        self._check(self._lib.ssn_exchange_pack(self._h, C.c_void_p(dev_ptr)))
+
+    def exchange_unpack(self, dev_ptr):
+        self._check(self._lib.ssn_exchange_unpack(self._h, C.c_void_p(dev_ptr)))
+
+    def exchange_host(self, allreduce):
+        """Host path (gloo): the exchange ranges as one float64 vector -> ``allreduce(vector)`` (in place) -> back."""
+        ranges = self.model.exchange
+        vec = np.concatenate([self.read_signal(lo, hi - lo) for lo, hi in ranges]) if ranges else np.zeros(0)
+        allreduce(vec)
+        off = 0
+        for lo, hi in ranges:
+            self.write_signal(lo, vec[off:off + hi - lo])
+            off += hi - lo
 
     def kernel_times(self):
         """{kernel name: (launches, total ms)} of the launches timed by ``run_steps(..., profile=2)``."""

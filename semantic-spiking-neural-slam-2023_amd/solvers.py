@@ -40,7 +40,12 @@ class _blas_threads:
 
     def __enter__(self):
         try:
-            from threadpoolctl import threadpool_limits
+            from threadpoolctl import threadpool_info, threadpool_limits
+            # only ever LOWER the count: a pool started with OMP_NUM_THREADS / OPENBLAS_NUM_THREADS = 1 or 2 (torchrun sets 1
+            # for its workers) crashes inside dpotrs when the limit is raised past what it was started with
+            cur = max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] + [1])
+            if cur <= self.n:
+                return
             self.ctx = threadpool_limits(limits=self.n)
             self.ctx.__enter__()
         except Exception:  # pragma: no cover

@@ -29,6 +29,20 @@ class OracleBackedSimulator:
     def prepare(self, n):
         pass
 
+    def set_exchange(self, allreduce):
+        """Neuron-sharded models: ``allreduce(vector)`` sums a float64 vector over the ranks in place."""
+        def hook(sig, ranges):
+            vec = np.concatenate([sig[lo:hi] for lo, hi in ranges]) if ranges else np.zeros(0)
+            allreduce(vec)
+            off = 0
+            for lo, hi in ranges:
+                sig[lo:hi] = vec[off:off + hi - lo]
+                off += hi - lo
+        self.o.exchange_hook = hook
+
+    def read_buffer(self, buffer_id):
+        return np.array(self.o.buf[buffer_id], dtype=np.float64)
+
     def run_steps(self, n, collect=True, profile=False):
         self.o.run_steps(n)
         self.n_steps += n

@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.BufferDesc) == 24 and C.sizeof(_lib.ProbeDesc) == 32 and C.sizeof(_lib.Range) == 16
     assert C.sizeof(_lib.Counters) == 88 and _lib.Counters.block_tpb.offset == 64 and _lib.Counters.fft_transforms.offset == 80
     assert _lib.ModelDesc.dt.offset == 16 and _lib.ModelDesc.buffers.offset == 56
-    assert _lib.ModelDesc.pre_to_core.offset == 88 and C.sizeof(_lib.ModelDesc) == 112
+    assert _lib.ModelDesc.pre_to_core.offset == 88 and _lib.ModelDesc.exchange.offset == 112 and C.sizeof(_lib.ModelDesc) == 128
 
 
 def test_create_fails_loudly_without_gpu_or_with_bad_args(lib):

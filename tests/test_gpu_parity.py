@@ -515,6 +515,71 @@ def test_two_ranks_on_hip_equal_the_unsharded_model(Simulator, tmp_path):
     assert H.cosine_error(got["f32"][20:], want[20:]).max() < 1e-3
 
 
+SLAM_SHARD_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import torch
+import torch.distributed as dist
+from sspslam_amd import harness as H
+from sspslam_amd.sharding import ShardedSLAM
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+s = H.make_ssp_space(2, 55)
+path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
+res = {{}}
+for dtype in ("f64", "f32"):
+    for turn in range(world):            # ranks share one GPU here: build (rocSOLVER) one after the other
+        if turn == rank:
+            sm = H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=100, mem_n_neurons=300, circonv_n_neurons=50, view_rad=0.6)
+            r = ShardedSLAM(sm, rank, world, dtype=dtype)
+        dist.barrier()
+    r.prepare({steps})
+    r.run_steps({steps})
+    am = sm.slam.assomemory
+    res[dtype] = r.probe_data()
+    res[dtype + "_W"], res[dtype + "_E"] = r.learned_decoders(am.conn_out), r.learned_encoders(am.memory)
+    res["launches"] = r.sim.counters()["launches_per_step"]
+    r.close()
+if rank == 0:
+    np.savez({out!r}, **res)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_of_a_neuron_sharded_slam_on_hip(Simulator, tmp_path):
+    """SLAMNetwork split over two ranks (gloo, sharing this GPU; with one GPU per rank the same runner exchanges through
+    RCCL in HBM): VCOs and product ensembles by ensemble, memory / recall / error by neuron, one all-reduce per timestep
+    between the two captured halves of the step graph (ssn_run_phase).  f64: trajectory, gathered PES decoders and
+    Voja encoders equal the UNSHARDED oracle run at 1e-9; f32 within the cosine bar."""
+    import subprocess
+    import sys
+    steps = 300
+    script, out = tmp_path / "worker.py", tmp_path / "slam.npz"
+    script.write_text(SLAM_SHARD_WORKER.format(root=ROOT, out=str(out), steps=steps))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29674", str(script)],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    got = np.load(out)
+    sm = _small_slam(weights_every=None)
+    model = build(sm.model)
+    ref = OracleSimulator(model)
+    ref.run_steps(steps)
+    want = ref.probe_data(0)
+    am = sm.slam.assomemory
+    W_ref = ref.buf[model.params[am.conn_out].learned_buffer]
+    E_ref = ref.buf[model.params[am.memory].encoder_buffer]
+    assert np.abs(W_ref).max() > 1e-6
+    np.testing.assert_allclose(got["f64"], want, atol=1e-9, rtol=0)
+    np.testing.assert_allclose(got["f64_W"], W_ref, atol=1e-12, rtol=1e-9)
+    np.testing.assert_allclose(got["f64_E"], E_ref, atol=1e-10, rtol=1e-9)
+    assert H.cosine_error(got["f32"][20:], want[20:]).max() < 1e-3
+    assert 10 <= int(got["launches"]) <= 60
+
+
 def test_sharded_runner_device_exchange(Simulator):
     """The all-device block exchange (probe -> RCCL all-gather -> read-out table, no host copies) on a
     single-rank RCCL group: same read-out as the oracle."""

@@ -79,3 +79,89 @@ def test_assemble_gathered_with_a_padded_last_shard():
         out[r, :, :3 * (hi - lo)] = full[:, 3 * lo:3 * hi]
     got = ShardedPathIntegration.assemble_gathered(out, K)
     assert got.shape == (n, 3 * K) and torch.equal(got, full)
+
+
+SLAM_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import torch.distributed as dist
+from helpers import OracleBackedSimulator
+from sspslam_amd import harness as H
+from sspslam_amd.sharding import ShardedSLAM
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+s = H.make_ssp_space(2, 55)
+path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
+sm = H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=60, mem_n_neurons={M}, circonv_n_neurons=30, view_rad=0.6)
+r = ShardedSLAM(sm, rank, world, sim_factory=lambda m: OracleBackedSimulator(m))
+r.run_steps({steps})
+am = sm.slam.assomemory
+W, E = r.learned_decoders(am.conn_out), r.learned_encoders(am.memory)
+if rank == 0:
+    np.savez({out!r}, probe=r.probe_data(), W=W, E=E, exchange=np.array(r.model.exchange))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world,M", [(2, 120), (3, 125)])
+def test_neuron_sharded_slam_equals_unsharded(world, M):
+    """SLAMNetwork with every neuron population split over the ranks and ONE all-reduce per timestep (the
+    feedback loop of reference slam.py:259,306-307 closes each timestep): trajectory, PES-learned decoders and
+    Voja-moved encoders equal the unsharded oracle run (float64 sums in another order: 1e-9).  125 memory neurons over 3
+    ranks: shares of 42, 42, 41 padded to 42."""
+    import subprocess
+    from sspslam_amd import harness as H
+    from sspslam_amd.builder import build
+    from oracle import OracleSimulator
+    steps = 300
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "slam.npz")
+        script = os.path.join(tmp, "worker.py")
+        with open(script, "w") as f:
+            f.write(SLAM_WORKER.format(root=ROOT, out=out, M=M, steps=steps))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                            "--master-addr", "127.0.0.1", "--master-port", str(29620 + world), script],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        got = np.load(out)
+        probe, W, E, exchange = got["probe"], got["W"], got["E"], got["exchange"]
+    s = H.make_ssp_space(2, 55)
+    path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
+    sm = H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=60, mem_n_neurons=M, circonv_n_neurons=30, view_rad=0.6)
+    model = build(sm.model)
+    ref = OracleSimulator(model)
+    ref.run_steps(steps)
+    am = sm.slam.assomemory
+    W_ref = ref.buf[model.params[am.conn_out].learned_buffer]
+    E_ref = ref.buf[model.params[am.memory].encoder_buffer]
+    assert np.abs(W_ref).max() > 1e-6 and np.abs(E_ref - model.params[am.memory].scaled_encoders).max() > 1e-3
+    np.testing.assert_allclose(probe, ref.probe_data(0), atol=1e-9, rtol=0)
+    np.testing.assert_allclose(W, W_ref, atol=1e-12, rtol=1e-9)
+    np.testing.assert_allclose(E, E_ref, atol=1e-10, rtol=1e-9)
+    assert 3 <= len(exchange) <= 12            # a handful of ranges, one all-reduce per timestep
+
+
+def test_neuron_sharding_refuses_partial_sums_into_neurons():
+    """ovc_ens decodes into the product neurons of the first circular convolution within the timestep (reference
+    slam.py:262-266, synapse=None): sharded, it would feed them a partial sum - the builder says which ensemble to replicate."""
+    import sspslam_amd.frontend as fe
+    from sspslam_amd import harness as H
+    from sspslam_amd.builder import build
+    s = H.make_ssp_space(2, 55)
+    path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
+    sm = H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=60, mem_n_neurons=120, circonv_n_neurons=30, view_rad=0.6)
+    with pytest.raises(fe.BuildError, match="replicate"):
+        build(sm.model, neuron_shard=(0, 2))
+    ms = [build(H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=60, mem_n_neurons=120, circonv_n_neurons=30,
+                                  view_rad=0.6).model, neuron_shard=(r, 2), replicate=None) for r in ()]
+    assert ms == []
+    a = H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=60, mem_n_neurons=120, circonv_n_neurons=30, view_rad=0.6)
+    b = H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=60, mem_n_neurons=120, circonv_n_neurons=30, view_rad=0.6)
+    ma = build(a.model, neuron_shard=(0, 2), replicate=[a.slam.ovc_ens])
+    mb = build(b.model, neuron_shard=(1, 2), replicate=[b.slam.ovc_ens])
+    assert ma.exchange == mb.exchange and ma.sig_size == mb.sig_size            # the ranks agree on what they exchange
+    assert {o["phase"] for o in ma.ops} == {0, 1}
+    assert all(o["kind"] in ("lowpass", "pes", "voja") for o in ma.ops if o["phase"] == 1)
