@@ -45,7 +45,7 @@ enum ssn_neuron { SSN_LIF = 0, SSN_LIFRATE = 1, SSN_RELU = 2 };
 enum ssn_op_kind {
   SSN_OP_FILL = 1, SSN_OP_TABLE = 2, SSN_OP_AXPY = 3, SSN_OP_MATVEC = 4, SSN_OP_LOWPASS = 5,
   SSN_OP_ENSARRAY = 6, SSN_OP_NEURONS = 7, SSN_OP_PES = 8, SSN_OP_VOJA = 9, SSN_OP_CLEANUP = 10,
-  SSN_OP_GATE = 11
+  SSN_OP_GATE = 11, SSN_OP_LINCOMB = 12
 };
 
 typedef struct ssn_buffer_desc {
@@ -62,6 +62,10 @@ typedef struct ssn_buffer_desc {
  *  MATVEC   i0 dst  i1 src   i2 rows i3 cols i4 W buf i5 mode i6 dft          W is rows x cols; dft != 0: W is
  *           the real-DFT map of a circular-convolution network (1-4 transform_in A / B / conj A / conj B, 5 transform_out,
  *           reference binding.py:23-74) - the f32 core may then run k_dft (mixed-radix FFT) instead of W
+ *  LINCOMB  i0 dst  i1 len   i2 n_terms i3 src buf (int32 [n_terms]: signal offsets) i4 alpha buf (real [n_terms])
+ *                                                           f0 self f1 const  dst=self*dst+(const+sum_k alpha_k*sig[src_k+i])
+ *           (the folded linear glue between two big operators - chains of nengo Reset / ElementwiseInc / copy operators
+ *           collapsed at build time; per-timestep core only)
  *  LOWPASS  i0 dst  i1 src   i2 len                         f0 a  f1 gain     dst=a*dst+(1-a)*gain*src
  *  ENSARRAY i0 x    i1 K i2 n i3 din i4 dout i5 enc buf [K][din][n] i6 bias buf [K][n]
  *           i7 dec buf [K][dout][n] i8 dst_idx buf (int32 [K][dout]) i9 V buf i10 R buf

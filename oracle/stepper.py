@@ -141,6 +141,14 @@ class OracleSimulator:
                     sig[o["dst"]:o["dst"] + o["len"]] = o["alpha"] * src
                 else:
                     sig[o["dst"]:o["dst"] + o["len"]] += o["alpha"] * src
+            elif k == "lincomb":      # folded linear glue (glue.py): dst = self * dst + (const + sum_k alpha_k * src_k)
+                acc = np.full(o["len"], o["const"], dtype=self.dtype)
+                for src, alpha in zip(o["srcs"], o["alphas"]):
+                    acc = acc + alpha * sig[src:src + o["len"]]
+                if o["self"]:
+                    sig[o["dst"]:o["dst"] + o["len"]] = o["self"] * sig[o["dst"]:o["dst"] + o["len"]] + acc
+                else:
+                    sig[o["dst"]:o["dst"] + o["len"]] = acc
             elif k == "matvec":
                 y = buf[o["w"]] @ sig[o["src"]:o["src"] + o["cols"]]
                 if o["mode"] == "set":

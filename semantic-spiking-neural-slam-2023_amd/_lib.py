@@ -14,7 +14,7 @@ SSN_F32, SSN_F64 = 0, 1
 SSN_BUF_REAL, SSN_BUF_I32 = 0, 1
 NEURON_CODE = {"lif": 0, "lifrate": 1, "relu": 2}
 OP_CODE = {"fill": 1, "table": 2, "axpy": 3, "matvec": 4, "lowpass": 5, "ensarray": 6, "neurons": 7,
-           "pes": 8, "voja": 9, "cleanup": 10, "gate": 11}
+           "pes": 8, "voja": 9, "cleanup": 10, "gate": 11, "lincomb": 12}
 STATUS = {0: "SSN_OK", -1: "SSN_EINVAL", -2: "SSN_EHIP", -3: "SSN_ERCCL", -4: "SSN_ENOMEM", -5: "SSN_EUNSUPPORTED"}
 
 

@@ -29,6 +29,7 @@ import numpy as np
 
 from . import frontend as fe
 from .solvers import solve_decoders
+from .glue import collapse_glue
 from .stages import stage_ops
 
 MICRO_KINDS = ("fill", "table", "axpy", "lowpass", "matvec_small", "gate")
@@ -167,7 +168,8 @@ def dft_structure(T):
 
 class Builder:
     def __init__(self, network, dt=0.001, seed=None, n_eval_points=None, solver_backend="auto",
-                 vco_shard=None, progress=None, probes=None, prune=False, staged=True, neuron_shard=None, replicate=()):
+                 vco_shard=None, progress=None, probes=None, prune=False, staged=True, neuron_shard=None, replicate=(),
+                 collapse=True):
         self.net, self.dt = network, float(dt)
         self.n_eval_points = n_eval_points
         self.solver_backend = solver_backend
@@ -188,6 +190,7 @@ class Builder:
         self.staged = staged and neuron_shard is None
         self.probes_override = probes        # build with these probes instead of the network's own
         self.prune = prune                   # drop operators that no probe (transitively) depends on
+        self.collapse = collapse             # fold the linear glue of the per-timestep core into lincomb operators (glue.py)
         self.model = BuiltModel(dt)
         self.arena_size = {a: 0 for a in "RWSCT"}
         self.inits = []                      # (Ref, values)
@@ -911,7 +914,17 @@ class Builder:
         if self.prune:
             ops = prune_ops(ops, m)
         r_allocs = [(base["R"] + off, ln) for off, ln in self.r_allocs]
-        m.ops = stage_ops(ops, m, r_allocs, schedule_ops, op_access, _overlap, enable=self.staged)
+        collapse = None
+        if self.collapse and self.neuron_shard is None:
+            def collapse(sub, protected):
+                sub, st = collapse_glue(sub, m, op_access, protected)
+                m.stats.update({"glue_" + k: v for k, v in st.items()})
+                for o in sub:
+                    if o["kind"] == "lincomb":       # the term lists travel as buffers (signal offsets, coefficients)
+                        o["srcs_buf"] = m.add_buffer(np.asarray(o["srcs"], dtype=np.int32), f"lincomb_src_{len(m.buffers)}", role="index")
+                        o["alphas_buf"] = m.add_buffer(np.asarray(o["alphas"], dtype=np.float64), f"lincomb_alpha_{len(m.buffers)}")
+                return sub
+        m.ops = stage_ops(ops, m, r_allocs, schedule_ops, op_access, _overlap, enable=self.staged, collapse=collapse)
         if self.neuron_shard is not None:
             shard_phases(m, self.neuron_shard)
         m.stats.update(n_raw_ops=len(self.raw_ops), n_ops=len(m.ops), sig_size=m.sig_size,
@@ -979,6 +992,10 @@ def op_access(o, model):
     if k == "axpy":
         w = [S(o["dst"], o["len"])]
         return (w, [], [S(o["src"], o["len"])], []) if o["mode"] == "set" else ([], w, [S(o["src"], o["len"])], [])
+    if k == "lincomb":
+        w = [S(o["dst"], o["len"])]
+        r = [S(src, o["len"]) for src in o["srcs"]]
+        return ([], w, r, []) if o["self"] else (w, [], r, [])
     if k == "matvec":
         w = [S(o["dst"], o["rows"])]
         r = [S(o["src"], o["cols"]), B(o["w"])]
@@ -1183,7 +1200,7 @@ def _overlap(a, b):
 
 def is_micro(o):
     k = o["kind"]
-    if k in ("fill", "table", "axpy", "lowpass", "gate"):
+    if k in ("fill", "table", "axpy", "lowpass", "gate", "lincomb"):
         return True
     return k == "matvec" and o["cols"] <= 16 and o["rows"] <= 8192
 
@@ -1242,9 +1259,10 @@ def schedule_ops(ops, model):
 
 
 def build(network, dt=0.001, seed=None, n_eval_points=None, solver_backend="auto", vco_shard=None,
-          probes=None, prune=False, staged=True, neuron_shard=None, replicate=()):
+          probes=None, prune=False, staged=True, neuron_shard=None, replicate=(), collapse=True):
     """Build ``network`` into a :class:`BuiltModel`.  ``staged=False`` keeps every operator in the
-    per-timestep core (no time-batched pre/post stages)."""
+    per-timestep core (no time-batched pre/post stages); ``collapse=False`` keeps nengo's one-operator-per-connection
+    glue (no lincomb folding, glue.py)."""
     return Builder(network, dt=dt, seed=seed, n_eval_points=n_eval_points, solver_backend=solver_backend,
                    vco_shard=vco_shard, probes=probes, prune=prune, staged=staged, neuron_shard=neuron_shard,
-                   replicate=replicate).build()
+                   replicate=replicate, collapse=collapse).build()

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <map>
 #include <set>
 #include <string>
 #include <vector>
@@ -72,7 +73,7 @@ struct Buf {
   int64_t ldt = 0;
 };
 
-enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_DFT, IT_VECOPS, IT_GRID_LHS, IT_GRID_GEMM, IT_ARGMAX_PART };
+enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_DFT, IT_VECOPS, IT_GRID_LHS, IT_GRID_GEMM, IT_ARGMAX_PART, IT_ROUND };
 
 }  // namespace
 
@@ -162,6 +163,14 @@ struct Sim final : ssn_sim {
   struct Rng { const void* space; int64_t lo, hi; bool w; };
   std::vector<std::vector<int>> item_deps;
   std::vector<MOp> vecops_host;               // operators of the grid-wide first level (IT_VECOPS), host copy
+  std::map<const void*, std::vector<ssn::LinTerm<T>>> lin_terms;   // device term list of a M_LINCOMB operator -> host copy
+  // round plan (k_round, ssn_round.hpp): every launch of a timestep, in order
+  struct RoundLaunch { ssn::RoundArgs<T> args; int n_blocks = 0; size_t lds = 0; int round = 0; };
+  struct Launch { int rl = -1; int item = -1; int phase = 0; };
+  bool round_mode = false;
+  std::vector<RoundLaunch> round_launches;
+  std::vector<Launch> launch_list;
+  std::vector<void*> round_bufs;
   std::vector<hipStream_t> side_streams;
   std::vector<hipEvent_t> dag_events;
   ssn::StepCtx* d_ctx = nullptr;
@@ -216,6 +225,7 @@ struct Sim final : ssn_sim {
     for (auto& it : items) if (it.type == IT_ENS && it.ens.partials) hipFree(it.ens.partials);
     for (auto p : scratch_bufs) if (p) hipFree(p);
     for (auto p : fused_bufs) if (p) hipFree(p);
+    for (auto p : round_bufs) if (p) hipFree(p);
     for (auto e : ev_pool) hipEventDestroy(e);
     for (auto e : dag_events) hipEventDestroy(e);
     for (auto st : side_streams) hipStreamDestroy(st);
@@ -346,7 +356,7 @@ struct Sim final : ssn_sim {
 
   static bool is_micro(const ssn_op_desc& o) {
     switch (o.kind) {
-      case SSN_OP_FILL: case SSN_OP_TABLE: case SSN_OP_AXPY: case SSN_OP_LOWPASS: case SSN_OP_GATE: return true;
+      case SSN_OP_FILL: case SSN_OP_TABLE: case SSN_OP_AXPY: case SSN_OP_LOWPASS: case SSN_OP_GATE: case SSN_OP_LINCOMB: return true;
       case SSN_OP_MATVEC: return o.i[3] <= 16 && o.i[2] <= 8192;
       default: return false;
     }
@@ -472,6 +482,15 @@ struct Sim final : ssn_sim {
         case SSN_OP_AXPY: CHK(check_range(o.i[0], o.i[2], "axpy dst")); CHK(check_range(o.i[1], o.i[2], "axpy src")); break;
         case SSN_OP_LOWPASS: CHK(check_range(o.i[0], o.i[2], "lowpass dst")); CHK(check_range(o.i[1], o.i[2], "lowpass src")); break;
         case SSN_OP_GATE: CHK(check_range(o.i[0], o.i[2], "gate dst")); CHK(check_range(o.i[1], 2 * o.i[2] + 1, "gate src")); break;
+        case SSN_OP_LINCOMB: {
+          CHK(check_range(o.i[0], o.i[1], "lincomb dst"));
+          if (o.stage != 1) return fail(SSN_EUNSUPPORTED, "lincomb operators belong to the per-timestep core");
+          if (o.i[2] < 0 || o.i[3] < 0 || o.i[3] >= m->n_buffers || o.i[4] < 0 || o.i[4] >= m->n_buffers) return fail(SSN_EINVAL, "lincomb term buffers out of range");
+          const ssn_buffer_desc& sb = m->buffers[o.i[3]]; const ssn_buffer_desc& ab = m->buffers[o.i[4]];
+          if (sb.kind != SSN_BUF_I32 || ab.kind != SSN_BUF_REAL || sb.count != o.i[2] || ab.count != o.i[2]) return fail(SSN_EINVAL, "lincomb term buffers: int32 offsets and real coefficients of n_terms elements each");
+          for (int64_t q = 0; q < o.i[2]; ++q) CHK(check_range(((const int32_t*)sb.data)[q], o.i[1], "lincomb src"));
+          break;
+        }
         default: return fail(SSN_EINVAL, "unknown operator kind %d", o.kind);
       }
     }
@@ -984,6 +1003,19 @@ struct Sim final : ssn_sim {
           op.kind = ssn::M_LOWPASS; op.dst = o.i[0]; op.src = o.i[1]; op.len = o.i[2];
           op.a = (T)o.f[0]; op.b = (T)((1.0 - o.f[0]) * o.f[1]);
           push_micro(op, o.level, false); break;
+        case SSN_OP_LINCOMB: {
+          std::vector<ssn::LinTerm<T>> terms((size_t)o.i[2]);
+          for (int64_t q = 0; q < o.i[2]; ++q)
+            terms[(size_t)q] = ssn::LinTerm<T>{(long long)((const int32_t*)m->buffers[o.i[3]].data)[q], (T)((const double*)m->buffers[o.i[4]].data)[q]};
+          ssn::LinTerm<T>* d_terms = nullptr;
+          CHK(dmalloc(&d_terms, (int64_t)std::max<size_t>(1, terms.size()) * (int64_t)sizeof(ssn::LinTerm<T>)));
+          scratch_bufs.push_back(d_terms);
+          if (!terms.empty()) HIPCHK(hipMemcpy(d_terms, terms.data(), terms.size() * sizeof(ssn::LinTerm<T>), hipMemcpyHostToDevice));
+          lin_terms[(const void*)d_terms] = terms;
+          op.kind = ssn::M_LINCOMB; op.dst = o.i[0]; op.len = o.i[1]; op.i0 = o.i[2]; op.p0 = d_terms;
+          op.a = (T)o.f[0]; op.b = T(1); op.c = (T)o.f[1];
+          push_micro(op, o.level, false); break;
+        }
         case SSN_OP_GATE:
           op.kind = ssn::M_GATE; op.dst = o.i[0]; op.src = o.i[1]; op.len = o.i[2]; op.a = (T)o.f[0]; op.b = (T)o.f[1];
           push_micro(op, o.level, true); break;
@@ -1211,6 +1243,17 @@ struct Sim final : ssn_sim {
       dom_units = (int64_t)a.K * a.n;
       dom_bytes = (double)dom_units * (a.din + a.dout + 5) * sizeof(T);
     }
+    round_mode = !fused && !(flags & 2097152);
+    if (round_mode) {
+      CHK(build_rounds(programs, item_prog));
+      int n_core = 0;
+      for (int i = 0; i < m->n_ops; ++i) n_core += m->ops[i].stage == 1;
+      bool probe_in_core = false;
+      for (auto& p : probes) probe_in_core = probe_in_core || p.stage == 1;
+      core_empty = bsig && n_core == 0 && !probe_in_core;
+      if (core_empty) launches_per_step = 0;
+      return SSN_OK;
+    }
     // Sink programs: a program none of the operators up to the next program depends on (e.g. the clean-up's
     // argmax + row gather, whose result is first used after the path integrator's ensembles; the chunk reductions
     // of sparse products whose sums are first used behind the next neuron populations) joins that next program -
@@ -1332,6 +1375,194 @@ struct Sim final : ssn_sim {
     return SSN_OK;
   }
 
+
+  // ---- round plan ---------------------------------------------------------------------------------------------------
+  // Every micro-operator and every big operator of the timestep is a unit; a unit's round is the earliest one its data
+  // hazards (RAW, WAR, WAW against every earlier unit of the sequential order) allow.  A round is launched as one k_round
+  // grid (ssn_round.hpp) plus one plain launch for each operator whose kernel has no body there (ensemble arrays, the
+  // ordered / factored clean-up products).
+  static bool glue_row_kind(int k) {
+    return k == ssn::M_MATVEC_INC || k == ssn::M_MATVEC_SET || k == ssn::M_ENS_FINISH || k == ssn::M_REDUCE_SET || k == ssn::M_REDUCE_INC;
+  }
+  int build_rounds(const std::vector<std::vector<MOp>>& programs, const std::vector<int>& item_prog) {
+    struct Unit { int mop = -1; int item = -1; int round = 0; int phase = 0; std::vector<Rng> acc; };
+    std::vector<Unit> units;
+    mops.clear();
+    int prog_i = 0;
+    for (size_t i = 0; i < items.size(); ++i) {
+      const Item& it = items[i];
+      if (it.type == IT_PROGRAM) {
+        for (const MOp& op0 : programs[(size_t)item_prog[(size_t)prog_i]]) {
+          MOp op = op0;
+          op.barrier = 0;
+          Unit u; u.mop = (int)mops.size(); u.phase = std::max(0, it.phase);
+          micro_access(u.acc, op, true);
+          mops.push_back(op);
+          units.push_back(std::move(u));
+        }
+        ++prog_i;
+      } else {
+        Unit u; u.item = (int)i; u.phase = std::max(0, it.phase);
+        item_access(u.acc, it);
+        units.push_back(std::move(u));
+      }
+    }
+    int n_rounds = 0, phase1_base = 0;
+    bool in_phase1 = false;
+    for (size_t u = 0; u < units.size(); ++u) {
+      if (units[u].phase == 1 && !in_phase1) { in_phase1 = true; phase1_base = n_rounds; }
+      int r = in_phase1 ? phase1_base : 0;
+      for (size_t v = 0; v < u; ++v)
+        if (units[v].round >= r && hazard(units[u].acc, units[v].acc)) r = units[v].round + 1;
+      units[u].round = r;
+      n_rounds = std::max(n_rounds, r + 1);
+    }
+    // device copies: micro-operators, the block -> (operator, chunk) maps of the glue entries, body arguments
+    CHK(dmalloc(&d_mops, (int64_t)std::max<size_t>(1, mops.size()) * (int64_t)sizeof(MOp)));
+    if (!mops.empty()) HIPCHK(hipMemcpy(d_mops, mops.data(), mops.size() * sizeof(MOp), hipMemcpyHostToDevice));
+    std::vector<ssn::GlueBlock> glue_map;
+    std::vector<unsigned char> arena;
+    auto put = [&](const void* src, size_t bytes) { const size_t off = (arena.size() + 15) / 16 * 16; arena.resize(off + bytes); memcpy(arena.data() + off, src, bytes); return off; };
+    struct Fix { size_t rl; int entry; int what; size_t off; };     // what: 0 arena, 1 glue map, 2 micro-operator
+    std::vector<Fix> fixes;
+    round_launches.clear();
+    launch_list.clear();
+    for (int r = 0; r < n_rounds; ++r) {
+      RoundLaunch rl;
+      rl.round = r;
+      rl.args = ssn::RoundArgs<T>{};
+      rl.args.mops = d_mops; rl.args.sig = sig; rl.args.ctx = d_ctx;
+      int phase = 0;
+      std::vector<Launch> plain;
+      auto close = [&]() {
+        if (rl.args.n == 0) return;
+        Launch l; l.rl = (int)round_launches.size(); l.phase = phase;
+        round_launches.push_back(rl);
+        launch_list.push_back(l);
+        rl.args.n = 0; rl.n_blocks = 0; rl.lds = 0;
+      };
+      auto entry = [&](int kind, int gx, int gy, size_t lds, int what, size_t off) {
+        if (rl.args.n == ssn::MAX_ROUND_ENTRIES) close();
+        ssn::RoundEntry& e = rl.args.e[rl.args.n];
+        e.kind = kind; e.first = rl.n_blocks; e.gx = std::max(1, gx); e.gy = std::max(1, gy); e.args = nullptr;
+        fixes.push_back(Fix{round_launches.size(), rl.args.n, what, off});
+        rl.n_blocks += e.gx * e.gy;
+        rl.lds = std::max(rl.lds, lds);
+        rl.args.n += 1;
+      };
+      // glue: one entry for all chunked micro-operators of the round
+      const size_t map_begin = glue_map.size();
+      for (const Unit& u : units) {
+        if (u.round != r) continue;
+        phase = u.phase;
+        if (u.mop < 0) continue;
+        const MOp& op = mops[(size_t)u.mop];
+        if (op.kind == ssn::M_GATE || op.kind == ssn::M_ARGMAX_GATHER) continue;
+        const long long per = glue_row_kind(op.kind) ? ssn::GLUE_ROWS : ssn::GLUE_CHUNK;
+        const int chunks = (int)std::max<long long>(1, (op.len + per - 1) / per);
+        for (int c = 0; c < chunks; ++c) glue_map.push_back(ssn::GlueBlock{u.mop, c});
+      }
+      if (glue_map.size() > map_begin) entry(ssn::RK_GLUE, (int)(glue_map.size() - map_begin), 1, 64, 1, map_begin);
+      for (const Unit& u : units) {
+        if (u.round != r) continue;
+        if (u.mop >= 0) {
+          const MOp& op = mops[(size_t)u.mop];
+          if (op.kind == ssn::M_GATE) entry(ssn::RK_GATE, 1, 1, 64, 2, (size_t)u.mop);
+          else if (op.kind == ssn::M_ARGMAX_GATHER) entry(ssn::RK_ARGMAX, 1, 1, 64, 2, (size_t)u.mop);
+          continue;
+        }
+        const Item& it = items[(size_t)u.item];
+        const size_t xb = (size_t)it.cols * sizeof(T);
+        switch (it.type) {
+          case IT_MATVEC:
+            if (xb <= 48 * 1024) {
+              ssn::MatvecArgs<T> a{it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set};
+              const bool r1 = it.rows <= 4096;
+              entry(r1 ? ssn::RK_MATVEC_R1 : ssn::RK_MATVEC_R4, r1 ? (it.rows + 3) / 4 : (it.rows + 15) / 16, 1, xb, 0, put(&a, sizeof a));
+              continue;
+            }
+            break;
+          case IT_SPMV: {
+            ssn::SpmvArgs<T> a{it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count, it.seg};
+            const size_t lds = 272 * sizeof(int) + (it.list ? 0 : (size_t)it.cols * sizeof(int));
+            if (lds <= 60 * 1024) { entry(ssn::RK_SPMV, (it.rows + 255) / 256, it.n, lds, 0, put(&a, sizeof a)); continue; }
+            break;
+          }
+          case IT_NEURONS: {
+            ssn::NeuronsArgs<T> a{it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count};
+            entry(ssn::RK_NEURONS, (it.n + 255) / 256, 1, 64, 0, put(&a, sizeof a));
+            continue;
+          }
+          case IT_DFT: {
+            const size_t lds = (size_t)(it.dft.M > 0 ? it.dft.M : it.dft.N) * 3 * sizeof(float2);
+            if (lds <= 60 * 1024) { entry(ssn::RK_DFT, 1, 1, lds, 0, put(&it.dft, sizeof it.dft)); continue; }
+            break;
+          }
+          case IT_PES: {
+            ssn::PesArgs<T> a{it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar};
+            entry(ssn::RK_PES, (it.cols + 1023) / 1024, it.rows, 64, 0, put(&a, sizeof a));
+            continue;
+          }
+          case IT_VOJA: {
+            ssn::VojaArgs<T> a{it.Wm, it.src, it.aux0, it.aux1, it.aux2, it.rows, it.cols, it.ld, it.scalar};
+            entry(ssn::RK_VOJA, (it.rows + 3) / 4, 1, 64, 0, put(&a, sizeof a));
+            continue;
+          }
+          default: break;
+        }
+        Launch l; l.item = u.item; l.phase = u.phase;
+        plain.push_back(l);
+      }
+      // the plain launches first (ensemble arrays: the long ones), then the round's grid
+      for (size_t q = 0; q < plain.size(); ++q) {
+        Item& a = items[(size_t)plain[q].item];
+        if (q + 1 < plain.size() && plain[q + 1].item == plain[q].item + 1 && a.type == IT_ENS && !a.dominant && !a.ens.defer) {
+          const Item& b = items[(size_t)plain[q + 1].item];
+          if (b.type == IT_ENS && !b.dominant && !b.ens.defer && b.ens.din == a.ens.din && b.ens.dout == a.ens.dout && b.ens.fast == a.ens.fast) {
+            a.batch = 2;
+            items[(size_t)plain[q + 1].item].merged = true;
+          }
+        }
+        launch_list.push_back(plain[q]);
+      }
+      close();
+    }
+    T* d_arena = nullptr; ssn::GlueBlock* d_map = nullptr;
+    CHK(dmalloc(&d_arena, (int64_t)arena.size() + 16));
+    round_bufs.push_back(d_arena);
+    CHK(dmalloc(&d_map, (int64_t)(glue_map.size() + 1) * (int64_t)sizeof(ssn::GlueBlock)));
+    round_bufs.push_back(d_map);
+    if (!arena.empty()) HIPCHK(hipMemcpy(d_arena, arena.data(), arena.size(), hipMemcpyHostToDevice));
+    if (!glue_map.empty()) HIPCHK(hipMemcpy(d_map, glue_map.data(), glue_map.size() * sizeof(ssn::GlueBlock), hipMemcpyHostToDevice));
+    for (const Fix& f : fixes) {
+      ssn::RoundEntry& e = round_launches[f.rl].args.e[f.entry];
+      if (f.what == 0) e.args = (const unsigned char*)d_arena + f.off;
+      else if (f.what == 1) e.args = d_map + f.off;
+      else e.args = d_mops + f.off;
+    }
+    int launches = 0;
+    for (const Launch& l : launch_list) launches += (l.rl >= 0 || !items[(size_t)l.item].merged) ? 1 : 0;
+    launches_per_step = launches;
+    if (getenv("SSN_DEBUG_PLAN")) {
+      fprintf(stderr, "[ssn] round plan: %zu units in %d rounds, %d launches per timestep\n", units.size(), n_rounds, launches);
+      for (const Launch& l : launch_list) {
+        if (l.rl < 0) { const Item& it = items[(size_t)l.item]; fprintf(stderr, "[ssn]   plain item %d type %d rows %d cols %d n %d%s\n", l.item, it.type, it.rows, it.cols, it.n, it.merged ? " (batched)" : ""); continue; }
+        const RoundLaunch& rl = round_launches[(size_t)l.rl];
+        fprintf(stderr, "[ssn]   round %2d phase %d: %d blocks, %zu B LDS:", rl.round, l.phase, rl.n_blocks, rl.lds);
+        for (int q = 0; q < rl.args.n; ++q) fprintf(stderr, " %d[%dx%d]", rl.args.e[q].kind, rl.args.e[q].gx, rl.args.e[q].gy);
+        fprintf(stderr, "\n");
+        for (const Unit& u : units)
+          if (u.round == rl.round && u.mop >= 0) fprintf(stderr, "[ssn]       micro %d/%lld dst %lld src %lld\n", mops[(size_t)u.mop].kind, (long long)mops[(size_t)u.mop].len, (long long)mops[(size_t)u.mop].dst, (long long)mops[(size_t)u.mop].src);
+      }
+    }
+    return SSN_OK;
+  }
+
+  hipError_t launch_one(const Launch& l) {
+    if (l.rl >= 0) { const RoundLaunch& rl = round_launches[(size_t)l.rl]; return ssn::launch_round<T>(stream, rl.args, rl.n_blocks, rl.lds); }
+    return launch_item(items[(size_t)l.item], nullptr, nullptr);
+  }
+
   // Adjacent items of one kind with no data hazard between them share a launch (blockIdx.y selects the item).
   void merge_adjacent_items() {
     const int n = (int)items.size();
@@ -1359,98 +1590,113 @@ struct Sim final : ssn_sim {
     if (!core_empty) launches_per_step = launches - (can_fuse ? 1 : 0);
   }
 
-  // Read / write sets of every item of the generic plan -> item_deps (RAW, WAR and WAW hazards on earlier items).
-  void analyse_dependencies(const std::vector<std::vector<MOp>>& programs, const std::vector<int>& item_prog) {
-    const void* S = (const void*)sig;
-    std::vector<std::vector<Rng>> acc(items.size());
-    auto sg = [&](std::vector<Rng>& a, int64_t lo, int64_t len, bool w) { if (len > 0) a.push_back(Rng{S, lo, lo + len, w}); };
-    auto pt = [&](std::vector<Rng>& a, const void* p, bool w) { if (p) a.push_back(Rng{p, 0, 1, w}); };
-    auto micro_access = [&](std::vector<Rng>& a, const MOp& op) {
-      switch (op.kind) {
-        case ssn::M_FILL: case ssn::M_TABLE: case ssn::M_ROW_IN: sg(a, op.dst, op.len, true); break;
-        case ssn::M_AXPY_INC: case ssn::M_LOWPASS: sg(a, op.src, op.len, false); sg(a, op.dst, op.len, true); break;
-        case ssn::M_AXPY_SET: sg(a, op.src, op.len, false); sg(a, op.dst, op.len, true); break;
-        case ssn::M_MATVEC_INC: case ssn::M_MATVEC_SET: sg(a, op.src, op.i0, false); sg(a, op.dst, op.len, true); pt(a, op.p0, false); break;
-        case ssn::M_GATE: sg(a, op.src, 2 * op.len + 1, false); sg(a, op.dst, op.len, true); break;
-        case ssn::M_ARGMAX_GATHER: pt(a, op.p1, false); pt(a, op.p0, false); sg(a, op.dst, op.len, true); break;
-        case ssn::M_PROBE: case ssn::M_ROW_OUT: sg(a, op.src, op.len, false); break;
-        case ssn::M_REDUCE_SET: case ssn::M_REDUCE_INC: pt(a, op.p0, false); sg(a, op.dst, op.len, true); break;
-        case ssn::M_ENS_FINISH: {
-          pt(a, op.p0, false);
-          for (auto& h : host_idx)
-            if (h.first == op.p1)
-              for (int64_t j = 0; j < h.second.second; ++j) sg(a, h.second.first[j], 1, true);
-          break;
+  // Read / write sets of micro-operators and plan items (signal ranges, buffers and scratch memory by base pointer)
+  void acc_sig(std::vector<Rng>& a, int64_t lo, int64_t len, bool w) const { if (len > 0) a.push_back(Rng{(const void*)sig, lo, lo + len, w}); }
+  static void acc_ptr(std::vector<Rng>& a, const void* p, bool w) { if (p) a.push_back(Rng{p, 0, 1, w}); }
+  // scattered destinations (decoded rows of an ensemble array) as runs of consecutive signals
+  void acc_index_list(std::vector<Rng>& a, const void* dev_idx, bool w) const {
+    for (auto& h : host_idx)
+      if (h.first == dev_idx) {
+        std::vector<int32_t> v(h.second.first, h.second.first + h.second.second);
+        std::sort(v.begin(), v.end());
+        for (size_t j = 0; j < v.size();) {
+          size_t e = j + 1;
+          while (e < v.size() && v[e] <= v[e - 1] + 1) ++e;
+          acc_sig(a, v[j], (int64_t)v[e - 1] - v[j] + 1, w);
+          j = e;
         }
-        default: break;      // M_STEP_END: the tail program is a join point anyway
       }
-    };
+  }
+  void micro_access(std::vector<Rng>& a, const MOp& op, bool with_clock = false) const {
+    const void* clock = (const void*)d_ctx;
+    switch (op.kind) {
+      case ssn::M_FILL: acc_sig(a, op.dst, op.len, true); break;
+      case ssn::M_TABLE: case ssn::M_ROW_IN: acc_sig(a, op.dst, op.len, true); if (with_clock) acc_ptr(a, clock, false); break;
+      case ssn::M_AXPY_INC: case ssn::M_LOWPASS: acc_sig(a, op.src, op.len, false); acc_sig(a, op.dst, op.len, true); break;
+      case ssn::M_AXPY_SET: acc_sig(a, op.src, op.len, false); acc_sig(a, op.dst, op.len, true); break;
+      case ssn::M_LINCOMB: {
+        auto it = lin_terms.find(op.p0);
+        if (it != lin_terms.end()) for (auto& t : it->second) acc_sig(a, t.src, op.len, false);
+        acc_sig(a, op.dst, op.len, true);
+        break;
+      }
+      case ssn::M_MATVEC_INC: case ssn::M_MATVEC_SET: acc_sig(a, op.src, op.i0, false); acc_sig(a, op.dst, op.len, true); acc_ptr(a, op.p0, false); break;
+      case ssn::M_GATE: acc_sig(a, op.src, 2 * op.len + 1, false); acc_sig(a, op.dst, op.len, true); break;
+      case ssn::M_ARGMAX_GATHER: acc_ptr(a, op.p1, false); acc_ptr(a, op.p0, false); acc_sig(a, op.dst, op.len, true); break;
+      case ssn::M_PROBE: case ssn::M_ROW_OUT: acc_sig(a, op.src, op.len, false); if (with_clock) acc_ptr(a, clock, false); break;
+      case ssn::M_REDUCE_SET: case ssn::M_REDUCE_INC: acc_ptr(a, op.p0, false); acc_sig(a, op.dst, op.len, true); break;
+      case ssn::M_ENS_FINISH: acc_ptr(a, op.p0, false); acc_index_list(a, op.p1, true); break;
+      case ssn::M_STEP_END: if (with_clock) acc_ptr(a, clock, true); break;      // (item plan: the tail program is a join point anyway)
+      default: break;
+    }
+  }
+  void item_access(std::vector<Rng>& a, const Item& it) const {
+    switch (it.type) {
+      case IT_ENS:
+        if (it.ens.direct) acc_index_list(a, (const void*)it.ens.didx, true);
+        acc_sig(a, it.ens.x_off, (int64_t)it.ens.K * it.ens.din, false);
+        acc_ptr(a, it.ens.partials, true); acc_ptr(a, it.ens.V, true); acc_ptr(a, it.ens.R, true);
+        acc_ptr(a, it.ens.enc, false); acc_ptr(a, it.ens.bias, false); acc_ptr(a, it.ens.dec, false);
+        break;
+      case IT_DFT:
+        acc_sig(a, it.src - sig, it.cols, false); acc_sig(a, it.dst - sig, it.rows, true); acc_ptr(a, it.dft.tw, false);
+        break;
+      case IT_MATVEC: case IT_MATVEC_ORDERED:
+        acc_sig(a, it.src - sig, it.cols, false); acc_ptr(a, it.Wm, false);
+        if (it.dst >= sig && it.dst < sig + n_sig) acc_sig(a, it.dst - sig, it.rows, true); else acc_ptr(a, it.dst, true);
+        break;
+      case IT_GRID_LHS:
+        acc_ptr(a, it.src, false); acc_ptr(a, it.aux0, false); acc_ptr(a, it.dst, true);
+        break;
+      case IT_GRID_GEMM:
+        acc_ptr(a, it.src, false); acc_ptr(a, it.Wm, false); acc_ptr(a, it.dst, true);
+        break;
+      case IT_ARGMAX_PART:
+        acc_ptr(a, it.src, false); acc_ptr(a, it.dst, true);
+        break;
+      case IT_SPMV:
+        acc_sig(a, it.src - sig, it.cols, false); acc_ptr(a, it.Wm, false); acc_ptr(a, it.list, false); acc_ptr(a, it.count, false); acc_ptr(a, it.dst, true);
+        break;
+      case IT_NEURONS:
+        acc_sig(a, it.src - sig, it.n, false); acc_sig(a, it.dst - sig, it.n, true); acc_ptr(a, it.V, true); acc_ptr(a, it.R, true);
+        acc_ptr(a, it.list, true); acc_ptr(a, it.count, true);
+        break;
+      case IT_PES:
+        acc_ptr(a, it.Wm, true); acc_sig(a, it.aux0 - sig, it.rows, false); acc_sig(a, it.aux1 - sig, it.cols, false);
+        break;
+      case IT_VOJA:
+        acc_ptr(a, it.Wm, true); acc_sig(a, it.src - sig, it.rows, false); acc_sig(a, it.aux0 - sig, it.cols, false); acc_sig(a, it.aux1 - sig, 1, false);
+        acc_ptr(a, it.aux2, false);
+        break;
+      default: break;
+    }
+  }
+  static bool hazard(const std::vector<Rng>& x, const std::vector<Rng>& y) {
+    for (const Rng& p : x)
+      for (const Rng& q : y)
+        if (p.space == q.space && p.lo < q.hi && q.lo < p.hi && (p.w || q.w)) return true;
+    return false;
+  }
+
+  // item_deps of the item plan (RAW, WAR and WAW hazards on earlier items).
+  void analyse_dependencies(const std::vector<std::vector<MOp>>& programs, const std::vector<int>& item_prog) {
+    std::vector<std::vector<Rng>> acc(items.size());
     int prog_i = 0;
     for (size_t i = 0; i < items.size(); ++i) {
       const Item& it = items[i];
-      std::vector<Rng>& a = acc[i];
-      switch (it.type) {
-        case IT_PROGRAM: {
-          for (const MOp& op : programs[(size_t)item_prog[(size_t)prog_i]]) micro_access(a, op);
-          ++prog_i;
-          break;
-        }
-        case IT_ENS:
-          if (it.ens.direct)
-            for (auto& h : host_idx)
-              if (h.first == (const void*)it.ens.didx)
-                for (int64_t j = 0; j < h.second.second; ++j) sg(a, h.second.first[j], 1, true);
-          sg(a, it.ens.x_off, (int64_t)it.ens.K * it.ens.din, false);
-          pt(a, it.ens.partials, true); pt(a, it.ens.V, true); pt(a, it.ens.R, true);
-          pt(a, it.ens.enc, false); pt(a, it.ens.bias, false); pt(a, it.ens.dec, false);
-          break;
-        case IT_VECOPS:
-          for (const MOp& op : vecops_host) micro_access(a, op);
-          break;
-        case IT_DFT:
-          sg(a, it.src - sig, it.cols, false); sg(a, it.dst - sig, it.rows, true); pt(a, it.dft.tw, false);
-          break;
-        case IT_MATVEC: case IT_MATVEC_ORDERED:
-          sg(a, it.src - sig, it.cols, false); pt(a, it.Wm, false);
-          if (it.dst >= sig && it.dst < sig + n_sig) sg(a, it.dst - sig, it.rows, true); else pt(a, it.dst, true);
-          break;
-        case IT_GRID_LHS:
-          pt(a, it.src, false); pt(a, it.aux0, false); pt(a, it.dst, true);
-          break;
-        case IT_GRID_GEMM:
-          pt(a, it.src, false); pt(a, it.Wm, false); pt(a, it.dst, true);
-          break;
-        case IT_ARGMAX_PART:
-          pt(a, it.src, false); pt(a, it.dst, true);
-          break;
-        case IT_SPMV:
-          sg(a, it.src - sig, it.cols, false); pt(a, it.Wm, false); pt(a, it.list, false); pt(a, it.count, false); pt(a, it.dst, true);
-          break;
-        case IT_NEURONS:
-          sg(a, it.src - sig, it.n, false); sg(a, it.dst - sig, it.n, true); pt(a, it.V, true); pt(a, it.R, true);
-          pt(a, it.list, true); pt(a, it.count, true);
-          break;
-        case IT_PES:
-          pt(a, it.Wm, true); sg(a, it.aux0 - sig, it.rows, false); sg(a, it.aux1 - sig, it.cols, false);
-          break;
-        case IT_VOJA:
-          pt(a, it.Wm, true); sg(a, it.src - sig, it.rows, false); sg(a, it.aux0 - sig, it.cols, false); sg(a, it.aux1 - sig, 1, false);
-          pt(a, it.aux2, false);
-          break;
-        default: break;
+      if (it.type == IT_PROGRAM) {
+        for (const MOp& op : programs[(size_t)item_prog[(size_t)prog_i]]) micro_access(acc[i], op);
+        ++prog_i;
+      } else if (it.type == IT_VECOPS) {
+        for (const MOp& op : vecops_host) micro_access(acc[i], op);
+      } else {
+        item_access(acc[i], it);
       }
     }
     item_deps.assign(items.size(), {});
     for (size_t i = 0; i < items.size(); ++i)
-      for (size_t j = 0; j < i; ++j) {
-        bool hit = false;
-        for (const Rng& x : acc[i]) {
-          for (const Rng& y : acc[j])
-            if (x.space == y.space && x.lo < y.hi && y.lo < x.hi && (x.w || y.w)) { hit = true; break; }
-          if (hit) break;
-        }
-        if (hit) item_deps[i].push_back((int)j);
-      }
+      for (size_t j = 0; j < i; ++j)
+        if (hazard(acc[i], acc[j])) item_deps[i].push_back((int)j);
   }
 
   int init_bsig() {
@@ -1571,6 +1817,11 @@ struct Sim final : ssn_sim {
       hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, (long long)count);
       return hipGetLastError();
     }
+    if (round_mode) {
+      for (int s = 0; s < count; ++s)
+        for (const Launch& l : launch_list) { hipError_t e = launch_one(l); if (e != hipSuccess) return e; }
+      return hipSuccess;
+    }
     const int n_items = (int)items.size();
     for (int s = 0; s < count; ++s) {
       for (int i = 0; i < n_items; ++i) {
@@ -1652,6 +1903,14 @@ struct Sim final : ssn_sim {
   }
 
   hipError_t launch_phase(int phase) {
+    if (round_mode) {
+      for (const Launch& l : launch_list) {
+        if (l.phase != phase) continue;
+        hipError_t e = launch_one(l);
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    }
     for (const Item& it : items) {
       if (it.phase != phase) continue;
       hipError_t e = launch_item(it, nullptr, nullptr);
@@ -1674,7 +1933,7 @@ struct Sim final : ssn_sim {
       return SSN_OK;
     }
     if (steps_per_graph <= 1 || fused_block) return SSN_OK;
-    const bool dag = (flags & 256) && !fused_core && items.size() >= 4 && item_deps.size() == items.size();
+    const bool dag = (flags & 256) && !round_mode && !fused_core && items.size() >= 4 && item_deps.size() == items.size();
     if (getenv("SSN_DEBUG_PLAN")) {
       size_t edges = 0;
       for (auto& d : item_deps) edges += d.size();
@@ -1764,7 +2023,7 @@ struct Sim final : ssn_sim {
     if (profile == 2 && (fused_block || core_empty)) profile = 1;
     if (profile) {
       const size_t need = fused_block ? (size_t)(2 * (n / std::max(1, block) + 2))
-                                      : (size_t)(2 * n * (profile == 2 ? (int)items.size() : std::max(1, n_dom)));
+                                      : (size_t)(2 * n * (profile == 2 ? (int)(items.size() + launch_list.size()) : std::max(1, n_dom)));
       if (need > 400000) return fail(SSN_EINVAL, "profile run too long (%lld steps): at most 200000 timed launches", (long long)n);
       while (ev_pool.size() < need) {
         hipEvent_t ev;
@@ -1798,7 +2057,17 @@ struct Sim final : ssn_sim {
         HIPCHK(hipGetLastError());
       } else if (profile == 2) {
         // every launch of every timestep between its own event pair (plain eager launches, no graph)
-        for (int64_t s = 0; s < B; ++s) {
+        for (int64_t s = 0; s < B && round_mode; ++s)
+          for (const Launch& l : launch_list) {
+            if (l.rl < 0 && items[(size_t)l.item].merged) continue;
+            HIPCHK(hipEventRecord(ev_pool[ev_used], stream));
+            HIPCHK(launch_one(l));
+            HIPCHK(hipEventRecord(ev_pool[ev_used + 1], stream));
+            ev_types.push_back(l.rl >= 0 ? (int)IT_ROUND : items[(size_t)l.item].type);
+            ev_items.push_back(l.rl >= 0 ? (int)items.size() + l.rl : l.item);
+            ev_used += 2;
+          }
+        for (int64_t s = 0; s < B && !round_mode; ++s) {
           for (auto& it : items) {
             if (it.merged) continue;
             HIPCHK(hipEventRecord(ev_pool[ev_used], stream));
@@ -1810,6 +2079,12 @@ struct Sim final : ssn_sim {
           }
           if (fused_defer) { hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, 1LL); HIPCHK(hipGetLastError()); }
         }
+      } else if (profile && round_mode) {
+        for (int64_t s = 0; s < B; ++s)
+          for (const Launch& l : launch_list) {
+            if (l.rl < 0 && items[(size_t)l.item].dominant) { HIPCHK(launch_item(items[(size_t)l.item], ev_pool[ev_used], ev_pool[ev_used + 1])); ev_used += 2; }
+            else HIPCHK(launch_one(l));
+          }
       } else if (profile) {
         for (int64_t s = 0; s < B; ++s) {
           for (auto& it : items) {
@@ -1840,7 +2115,7 @@ struct Sim final : ssn_sim {
         const int ty = ev_types[j / 2];
         type_ms[ty] += ms;
         type_launches[ty] += 1;
-        if (item_ms.size() != items.size()) { item_ms.assign(items.size(), 0.0); item_n.assign(items.size(), 0); }
+        if (item_ms.size() != items.size() + round_launches.size()) { item_ms.assign(items.size() + round_launches.size(), 0.0); item_n.assign(items.size() + round_launches.size(), 0); }
         item_ms[(size_t)ev_items[j / 2]] += ms; item_n[(size_t)ev_items[j / 2]] += 1;
         continue;
       }
@@ -1870,8 +2145,12 @@ struct Sim final : ssn_sim {
     }
     if (profile == 2 && getenv("SSN_DEBUG_PLAN"))
       for (size_t i = 0; i < item_ms.size(); ++i)
-        if (item_n[i]) fprintf(stderr, "[ssn] item %2zu type %2d batch %d: %8.2f us avg over %lld launches\n", i, items[i].type, items[i].batch,
-                               1e3 * item_ms[i] / item_n[i], (long long)item_n[i]);
+        if (item_n[i]) {
+          if (i < items.size()) fprintf(stderr, "[ssn] item %2zu type %2d batch %d: %8.2f us avg over %lld launches\n", i, items[i].type, items[i].batch,
+                                        1e3 * item_ms[i] / item_n[i], (long long)item_n[i]);
+          else fprintf(stderr, "[ssn] round launch %2zu (round %d, %d blocks): %8.2f us avg over %lld launches\n", i - items.size(),
+                       round_launches[i - items.size()].round, round_launches[i - items.size()].n_blocks, 1e3 * item_ms[i] / item_n[i], (long long)item_n[i]);
+        }
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, ev_run0, ev_run1));
     last_run_ms = ms;
@@ -2022,7 +2301,7 @@ struct Sim final : ssn_sim {
   int kernel_times(ssn_kernel_time* out, int capacity) override {
     static const char* names[N_ITEM_TYPES] = {"k_program", "k_ensarray", "k_matvec", "k_neurons", "k_pes", "k_voja", "k_matvec_ordered",
                                               "k_ens_finish", "k_spmv_partial", "k_dft", "k_vecops", "k_grid_lhs", "k_gemm_nt_mfma_f32",
-                                              "k_argmax_partial", "", ""};
+                                              "k_argmax_partial", "k_round", ""};
     int n = 0;
     for (int t = 0; t < N_ITEM_TYPES; ++t) {
       if (!type_launches[t]) continue;

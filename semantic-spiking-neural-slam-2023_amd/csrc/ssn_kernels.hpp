@@ -470,10 +470,7 @@ __device__ inline float2* dft_stockham(float2* x, float2* y, const float2* tw, i
   return x;
 }
 
-template <int DUMMY>
-__global__ __launch_bounds__(1024) void k_dft(DftBatch batch) {
-  const DftArgs& a = batch.a[blockIdx.x];       // (a reference: the radix list is indexed dynamically - a copy would live in scratch)
-  extern __shared__ __align__(16) unsigned char ssn_dft_dyn[];
+__device__ __forceinline__ void dft_body(const DftArgs& a, unsigned char* ssn_dft_dyn) {
   const int N = a.N, H = N / 2 + 1, tid = threadIdx.x, nthr = blockDim.x;
   const int L = a.M > 0 ? a.M : N;              // length of the transforms actually run
   float2* x = reinterpret_cast<float2*>(ssn_dft_dyn);
@@ -532,6 +529,11 @@ __global__ __launch_bounds__(1024) void k_dft(DftBatch batch) {
       if (a.set) a.dst[i] = v; else a.dst[i] += v;
     }
   }
+}
+template <int DUMMY>
+__global__ __launch_bounds__(1024) void k_dft(DftBatch batch) {
+  extern __shared__ __align__(16) unsigned char ssn_dft_smem[];
+  dft_body(batch.a[blockIdx.x], ssn_dft_smem);      // (a reference: the radix list is indexed dynamically - a copy would live in scratch)
 }
 
 template <typename T>
@@ -626,6 +628,16 @@ __global__ __launch_bounds__(1024) void k_program(const MicroOp<T>* __restrict__
         { T* const d = sig + op.dst; const T* const x = sig + op.src;
           vec4_loop<T>(tid, op.len, [&](int i) { return op.a * d[i] + op.b * x[i]; }, [&](int i, T v) { d[i] = v; }); }
         break;
+      case M_LINCOMB: {   // dst = a * dst + b * (c + sum_k alpha_k * sig[src_k + i]); p0 = LinTerm[i0]
+        const LinTerm<T>* const t = (const LinTerm<T>*)op.p0;
+        T* const d = sig + op.dst;
+        for (int i = tid; i < (int)op.len; i += 1024) {
+          T acc = op.c;
+          for (int k = 0; k < (int)op.i0; ++k) acc += t[k].alpha * sig[t[k].src + i];
+          d[i] = (op.a != T(0) ? op.a * d[i] : T(0)) + op.b * acc;
+        }
+        break;
+      }
       case M_TABLE: {   // p0 = TableSlot*
         const TableSlot* t = (const TableSlot*)op.p0;
         const long long rel = step - t->first_step;
@@ -831,13 +843,12 @@ hipError_t launch_program(hipStream_t s, const MicroOp<T>* d_ops, const ProgDesc
 // whole matrix read.
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool XLDS, int RW, int CUV = 8>
-__global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
-  const MatvecArgs<T> ma = batch.a[blockIdx.y];
+__device__ __forceinline__ void matvec_body(const MatvecArgs<T>& ma, const int bx, unsigned char* ssn_mv_dyn) {
   const T* __restrict__ Wm = ma.Wm;
   const T* __restrict__ sig_src = ma.src;
   T* __restrict__ sig_dst = ma.dst;
   const int rows = ma.rows, cols = ma.cols, ld = ma.ld, set = ma.set;
-  if ((int)blockIdx.x * 4 * RW >= rows) return;      // (grid.x is sized for the tallest matrix of the batch)
+  if (bx * 4 * RW >= rows) return;      // (grid.x is sized for the tallest matrix of the batch)
   // y = W x, one wave per RW rows (4 RW rows per workgroup): the source vector is staged in LDS once per
   // workgroup and each lane keeps independent 16-byte row loads in flight per trip - one of each of four rows (RW = 4),
   // or CUV consecutive vectors of one row (RW = 1: short, wide matrices such as a learned decoder product, which
@@ -849,10 +860,9 @@ __global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
   constexpr int W = VecT<T>::W;
   constexpr int CU = RW == 1 ? CUV : 1;            // vectors of one row in flight per lane (RW = 1: few workgroups, more per lane)
   constexpr int SLAB = 48 * 1024 / (int)sizeof(T);
-  extern __shared__ __align__(16) unsigned char ssn_mv_dyn[];
   T* xs = reinterpret_cast<T*>(ssn_mv_dyn);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r0 = (blockIdx.x * 4 + wave) * RW;
+  const int r0 = (bx * 4 + wave) * RW;
   if (XLDS) {
     int nz = 0;
     for (int c = threadIdx.x; c < cols; c += 256) {
@@ -918,6 +928,11 @@ __global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
     if (lane == 0 && r0 + q < rows) { if (set) sig_dst[r0 + q] = t; else sig_dst[r0 + q] += t; }
   }
 }
+template <typename T, bool XLDS, int RW, int CUV = 8>
+__global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
+  extern __shared__ __align__(16) unsigned char ssn_mv_smem[];
+  matvec_body<T, XLDS, RW, CUV>(batch.a[blockIdx.y], (int)blockIdx.x, ssn_mv_smem);
+}
 
 template <typename T>
 hipError_t launch_matvec(hipStream_t s, const MatvecBatch<T>& b, int count) {
@@ -947,8 +962,7 @@ hipError_t launch_matvec(hipStream_t s, const MatvecBatch<T>& b, int count) {
 //   Traffic: (#spikes x rows) weights instead of (n x rows).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_spmv_partial(SpmvBatch<T> batch) {
-  const SpmvArgs<T> sa = batch.a[blockIdx.z];
+__device__ __forceinline__ void spmv_body(const SpmvArgs<T>& sa, const int bx, const int by, unsigned char* smem_all) {
   const T* __restrict__ Wt = sa.Wt;
   const int ldt = sa.ldt;
   const T* __restrict__ spikes = sa.spikes;
@@ -958,9 +972,9 @@ __global__ __launch_bounds__(256) void k_spmv_partial(SpmvBatch<T> batch) {
   const int* __restrict__ glist = sa.list;
   const int* __restrict__ gcount = sa.count;
   const int seg = sa.seg;
-  if ((int)blockIdx.x * 256 >= rows || (int)blockIdx.y >= chunks) return;      // (grid sized for the largest product of a batch)
-  extern __shared__ unsigned char smem[];
-  __shared__ int counts[257];
+  if (bx * 256 >= rows || by >= chunks) return;      // (grid sized for the largest product of a batch)
+  int* counts = reinterpret_cast<int*>(smem_all);       // [257] (+ pad), then the locally compacted spike list
+  unsigned char* smem = smem_all + 272 * sizeof(int);
   const int tid = threadIdx.x;
   const int* list = glist;                      // spike list produced by k_neurons_compact ...
   int m = 0;
@@ -984,8 +998,8 @@ __global__ __launch_bounds__(256) void k_spmv_partial(SpmvBatch<T> batch) {
     m = counts[256];
     list = llist;
   }
-  const int c = blockIdx.y;
-  const int r = blockIdx.x * 256 + tid;
+  const int c = by;
+  const int r = bx * 256 + tid;
   if (seg > 0) {
     // segmented spike list from k_neurons (256 neurons per segment): chunk c takes segments [c*seg, (c+1)*seg)
     T acc = T(0);
@@ -1022,14 +1036,19 @@ __global__ __launch_bounds__(256) void k_spmv_partial(SpmvBatch<T> batch) {
     partial[(size_t)c * rows_pad + r] = acc;
   }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void k_spmv_partial(SpmvBatch<T> batch) {
+  extern __shared__ __align__(16) unsigned char ssn_spmv_smem[];
+  spmv_body<T>(batch.a[blockIdx.z], (int)blockIdx.x, (int)blockIdx.y, ssn_spmv_smem);
+}
 
 template <typename T>
 hipError_t launch_spmv_partial(hipStream_t s, const SpmvBatch<T>& b, int count) {
   int rows = 0, chunks = 0;
-  size_t lds = 16;
+  size_t lds = 272 * sizeof(int);
   for (int i = 0; i < count; ++i) {
     rows = std::max(rows, b.a[i].rows); chunks = std::max(chunks, b.a[i].chunks);
-    if (!b.a[i].list) lds = std::max(lds, (size_t)b.a[i].n * sizeof(int));
+    if (!b.a[i].list) lds = std::max(lds, 272 * sizeof(int) + (size_t)b.a[i].n * sizeof(int));
   }
   hipLaunchKernelGGL((k_spmv_partial<T>), dim3((rows + 255) / 256, chunks, count), dim3(256), lds, s, b);
   return hipGetLastError();
@@ -1073,8 +1092,7 @@ hipError_t launch_transpose(hipStream_t s, const T* src, T* dst, int rows, int c
 
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_neurons(NeuronsBatch<T> batch) {
-  const NeuronsArgs<T> na = batch.a[blockIdx.y];
+__device__ __forceinline__ void neurons_body(const NeuronsArgs<T>& na, const int bx, unsigned char* smem) {
   const NeuronParams<T> np = na.np;
   const T* __restrict__ J = na.J;
   T* __restrict__ out = na.out;
@@ -1084,8 +1102,8 @@ __global__ __launch_bounds__(256) void k_neurons(NeuronsBatch<T> batch) {
   const T amp = na.amp;
   int* __restrict__ seg_list = na.seg_list;
   int* __restrict__ seg_cnt = na.seg_cnt;
-  if ((int)blockIdx.x * 256 >= n) return;        // (grid.x is sized for the largest population of the batch)
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (bx * 256 >= n) return;        // (grid.x is sized for the largest population of the batch)
+  const int i = bx * 256 + threadIdx.x;
   T a = T(0);
   if (i < n) {
     T v = V[i], r = R[i];
@@ -1096,16 +1114,21 @@ __global__ __launch_bounds__(256) void k_neurons(NeuronsBatch<T> batch) {
   if (seg_list) {
     // this workgroup's spikes as an ascending index list (segment blockIdx.x of the ensemble's segmented spike
     // list): the spike-sparse decoder product walks segments in order and never has to scan the spike vector
-    __shared__ int wcnt[4];
+    int* wcnt = reinterpret_cast<int*>(smem);      // [4]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long mask = __ballot(a != T(0));
     if (lane == 0) wcnt[wave] = __popcll(mask);
     __syncthreads();
     int base = 0;
     for (int w = 0; w < wave; ++w) base += wcnt[w];
-    if (a != T(0)) seg_list[blockIdx.x * 256 + base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
-    if (threadIdx.x == 0) seg_cnt[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (a != T(0)) seg_list[bx * 256 + base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+    if (threadIdx.x == 0) seg_cnt[bx] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
   }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_neurons(NeuronsBatch<T> batch) {
+  __shared__ __align__(16) unsigned char smem[16];
+  neurons_body<T>(batch.a[blockIdx.y], (int)blockIdx.x, smem);
 }
 
 template <typename T>
@@ -1121,18 +1144,22 @@ hipError_t launch_neurons(hipStream_t s, const NeuronsBatch<T>& b, int count) {
 // One workgroup per (row, 1024-column tile): act is read once per tile, W streamed once.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_pes(T* __restrict__ Wm, const T* __restrict__ err, const T* __restrict__ act,
-                                             int rows, int cols, int ld, T kappa) {
-  const int r = blockIdx.y;
-  const T e = kappa * err[r];
+__device__ __forceinline__ void pes_body(const PesArgs<T>& a, const int bx, const int by) {
+  const int r = by;
+  const T e = a.kappa * a.err[r];
   if (e == T(0)) return;
-  T* wr = Wm + (size_t)r * ld;
-  const int c0 = blockIdx.x * 1024;
+  T* wr = a.Wm + (size_t)r * a.ld;
+  const int c0 = bx * 1024;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int c = c0 + j * 256 + threadIdx.x;
-    if (c < cols) wr[c] += e * act[c];
+    if (c < a.cols) wr[c] += e * a.act[c];
   }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_pes(T* __restrict__ Wm, const T* __restrict__ err, const T* __restrict__ act,
+                                             int rows, int cols, int ld, T kappa) {
+  pes_body<T>(PesArgs<T>{Wm, err, act, rows, cols, ld, kappa}, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 template <typename T>
@@ -1147,18 +1174,22 @@ hipError_t launch_pes(hipStream_t s, T* Wm, const T* err, const T* act, int rows
 // One wave per neuron row; silent neurons exit after one load.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
+__device__ __forceinline__ void voja_body(const VojaArgs<T>& v, const int bx) {
+  const int lane = threadIdx.x & 63;
+  const int i = bx * 4 + (threadIdx.x >> 6);
+  if (i >= v.rows) return;
+  const T a = v.spk[i];
+  if (a == T(0)) return;
+  const T g = v.lr_dt * (T(1) + v.learn[0]);
+  const T sa = v.scale[i] * a;
+  T* er = v.E + (size_t)i * v.ld;
+  for (int c = lane; c < v.cols; c += 64) er[c] += g * (sa * v.key[c] - a * er[c]);
+}
+template <typename T>
 __global__ __launch_bounds__(256) void k_voja(T* __restrict__ E, const T* __restrict__ spk, const T* __restrict__ key,
                                               const T* __restrict__ learn, const T* __restrict__ scale,
                                               int rows, int cols, int ld, T lr_dt) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= rows) return;
-  const T a = spk[i];
-  if (a == T(0)) return;
-  const T g = lr_dt * (T(1) + learn[0]);
-  const T sa = scale[i] * a;
-  T* er = E + (size_t)i * ld;
-  for (int c = lane; c < cols; c += 64) er[c] += g * (sa * key[c] - a * er[c]);
+  voja_body<T>(VojaArgs<T>{E, spk, key, learn, scale, rows, cols, ld, lr_dt}, (int)blockIdx.x);
 }
 
 template <typename T>
@@ -1577,6 +1608,7 @@ hipError_t launch_convert_out(hipStream_t s, const T* src, double* dst, int64_t 
 
 }  // namespace ssn
 #include "ssn_block.hpp"
+#include "ssn_round.hpp"
 namespace ssn {
 
 #define SSN_INSTANTIATE(T)                                                                                   \
@@ -1603,6 +1635,7 @@ namespace ssn {
   template hipError_t launch_gemm_nt<T>(hipStream_t, const T*, int, const T*, int, T*, int, int, int, int, int); \
   template hipError_t launch_batch_elementwise<T>(hipStream_t, const BatchOpList<T>&);                      \
   template hipError_t launch_convert_in<T>(hipStream_t, const double*, T*, int64_t, int64_t, int64_t);      \
-  template hipError_t launch_convert_out<T>(hipStream_t, const T*, double*, int64_t, int64_t, int64_t);
+  template hipError_t launch_convert_out<T>(hipStream_t, const T*, double*, int64_t, int64_t, int64_t);      \
+  template hipError_t launch_round<T>(hipStream_t, const RoundArgs<T>&, int, size_t);
 
 }  // namespace ssn

@@ -143,8 +143,10 @@ template <typename T> struct EnsBatch { EnsArgs<T> a[MAX_ENS_BATCH]; };
 
 enum MicroKind {
   M_FILL = 1, M_AXPY_INC, M_AXPY_SET, M_LOWPASS, M_TABLE, M_MATVEC_INC, M_MATVEC_SET, M_ENS_FINISH,
-  M_GATE, M_ARGMAX_GATHER, M_PROBE, M_STEP_END, M_ROW_IN, M_ROW_OUT, M_REDUCE_SET, M_REDUCE_INC
+  M_GATE, M_ARGMAX_GATHER, M_PROBE, M_STEP_END, M_ROW_IN, M_ROW_OUT, M_REDUCE_SET, M_REDUCE_INC,
+  M_LINCOMB            // dst = a * dst + b * (c + sum_k alpha_k * sig[src_k + i]); p0 = LinTerm[i0]
 };
+template <typename T> struct LinTerm { long long src; T alpha; };
 
 template <typename T>
 struct MicroOp {
@@ -155,6 +157,7 @@ struct MicroOp {
   const void* p0;
   const void* p1;
   long long i0, i1;
+  T c;
 };
 
 struct ProgDesc { int op_begin, op_count; };
@@ -193,6 +196,37 @@ struct BatchOp {
   const void* p0;        // W | TableSlot* | ProbeSlot*
   long long step0;       // = block_start
 };
+
+// ---------------------------------------------------------------------------------------------
+// Rounds (k_round, ssn_round.hpp): all mutually independent operators of a timestep - big and small - share ONE
+// launch.  A round is a list of entries; entry i owns the virtual blocks [first, first + gx * gy) of the grid and
+// names the operator body that runs them.  The arguments of every body live in device memory (they do not change
+// from timestep to timestep; the step counter is read from StepCtx).
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct PesArgs { T* Wm; const T* err; const T* act; int rows, cols, ld; T kappa; };
+template <typename T> struct VojaArgs { T* E; const T* spk; const T* key; const T* learn; const T* scale; int rows, cols, ld; T lr_dt; };
+
+enum RoundKind {
+  RK_GLUE = 0,        // element-wise / reduction micro-operators, one chunk per block (args: GlueBlock map)
+  RK_GATE, RK_ARGMAX, // whole-vector micro-operators: one block each (args: MicroOp)
+  RK_MATVEC_R1, RK_MATVEC_R4, RK_SPMV, RK_NEURONS, RK_DFT, RK_PES, RK_VOJA
+};
+struct GlueBlock { int op; int chunk; };        // micro-operator index (into RoundArgs::mops), chunk of it
+struct RoundEntry { int kind; int first; int gx; int gy; const void* args; };
+constexpr int MAX_ROUND_ENTRIES = 28;
+template <typename T>
+struct RoundArgs {
+  int n;
+  int pad;
+  const MicroOp<T>* mops;
+  T* sig;
+  StepCtx* ctx;
+  RoundEntry e[MAX_ROUND_ENTRIES];
+};
+template <typename T> hipError_t launch_round(hipStream_t, const RoundArgs<T>&, int n_blocks, size_t lds_bytes);
+// elements (rows for the reductions) of a micro-operator that one block of a round handles
+constexpr int GLUE_CHUNK = 1024;
+constexpr int GLUE_ROWS = 256;
 
 constexpr int MAX_BATCH_OPS = 6;
 template <typename T> struct BatchOpList { BatchOp<T> op[MAX_BATCH_OPS]; int count; };

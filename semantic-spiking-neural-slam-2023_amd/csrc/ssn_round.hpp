@@ -1,0 +1,265 @@
+// ssn_round.hpp - k_round: every mutually independent operator of a timestep in ONE launch.
+//
+// A SLAM timestep is a chain of ~25 dependency levels (reference networks/slam.py:259-307 wires ensembles, products
+// and memories through un-filtered connections, so most of a step is sequential), and each level holds a few big
+// operators next to a dozen 1 000 - 2 000 element vector operators.  A launch costs ~5 us on this GPU whatever it
+// does, so one launch per operator (or per operator kind) makes the step launch-bound.  k_round runs a whole level:
+// the host planner (ssn_host.hip, plan_rounds) assigns every operator of the step the earliest round its data
+// hazards allow; a round's operators become the entries of ONE grid - entry i owns virtual blocks
+// [first, first + gx * gy) - and each 256-thread workgroup runs the body its block belongs to:
+//
+//   RK_GLUE     one chunk (GLUE_CHUNK elements / GLUE_ROWS reduction rows) of one micro-operator: fill, axpy, lowpass,
+//               table row, block-row hand-off, probe sample, partial-sum reductions, step counter.  The single-workgroup
+//               interpreter k_program ran these back to back (~0.4 us each, latency-bound); here they run side by side.
+//   RK_GATE, RK_ARGMAX   whole-vector micro-operators (a dot product / an argmax decide what is written): one block
+//   RK_MATVEC_*, RK_SPMV, RK_NEURONS, RK_DFT, RK_PES, RK_VOJA   the bodies of the stand-alone kernels (ssn_kernels.hpp)
+//
+// Workgroup memory is one dynamic allocation sized for the round's hungriest body (no static LDS in any body: static
+// allocations of all bodies would add up).
+#pragma once
+#include "ssn_kernels.hpp"
+
+namespace ssn {
+
+// One chunk of one micro-operator.  Element-wise kinds: elements [chunk * GLUE_CHUNK, ...) - four per thread,
+// loads before stores; row kinds (reductions, ensemble finish, small matvec): rows [chunk * GLUE_ROWS, ...), one per thread.
+template <typename T>
+__device__ __forceinline__ void glue_body(const MicroOp<T>& op, const int chunk, T* __restrict__ sig, StepCtx* __restrict__ ctx) {
+  const int tid = threadIdx.x;
+  auto ew = [&](auto load, auto store) {
+    const long long base = (long long)chunk * GLUE_CHUNK;
+    T v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const long long i = base + u * 256 + tid; if (i < op.len) v[u] = load(i); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const long long i = base + u * 256 + tid; if (i < op.len) store(i, v[u]); }
+  };
+  switch (op.kind) {
+    case M_FILL:
+      { T* const d = sig + op.dst; ew([&](long long) { return op.a; }, [&](long long i, T v) { d[i] = v; }); }
+      break;
+    case M_AXPY_INC:
+      { T* const d = sig + op.dst; const T* const x = sig + op.src;
+        ew([&](long long i) { return d[i] + op.a * x[i]; }, [&](long long i, T v) { d[i] = v; }); }
+      break;
+    case M_AXPY_SET:
+      { T* const d = sig + op.dst; const T* const x = sig + op.src;
+        ew([&](long long i) { return op.a * x[i]; }, [&](long long i, T v) { d[i] = v; }); }
+      break;
+    case M_LOWPASS:
+      { T* const d = sig + op.dst; const T* const x = sig + op.src;
+        ew([&](long long i) { return op.a * d[i] + op.b * x[i]; }, [&](long long i, T v) { d[i] = v; }); }
+      break;
+    case M_LINCOMB: {   // dst = a * dst + b * (c + sum_k alpha_k * sig[src_k + i]); p0 = LinTerm[i0], i1 bits of c
+      const LinTerm<T>* const t = (const LinTerm<T>*)op.p0;
+      const int nt = (int)op.i0;
+      T* const d = sig + op.dst;
+      const long long base = (long long)chunk * GLUE_CHUNK;
+      T acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = op.c;
+      for (int k = 0; k < nt; ++k) {
+        const T alpha = t[k].alpha;
+        const T* const x = sig + t[k].src;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const long long i = base + u * 256 + tid; if (i < op.len) acc[u] += alpha * x[i]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long i = base + u * 256 + tid;
+        if (i < op.len) d[i] = (op.a != T(0) ? op.a * d[i] : T(0)) + op.b * acc[u];
+      }
+      break;
+    }
+    case M_TABLE: {
+      const TableSlot* t = (const TableSlot*)op.p0;
+      const long long rel = ctx->step - t->first_step;
+      int row = -1;
+      if (rel >= 0 && rel < t->n_idx) row = t->idx[rel];
+      const bool have = row >= 0 && row < t->n_rows;
+      const T* const trow = (const T*)t->rows + (have ? (size_t)row * t->width : 0);
+      T* const d = sig + op.dst;
+      ew([&](long long i) { return have ? trow[i] : T(0); }, [&](long long i, T v) { d[i] = v; });
+      break;
+    }
+    case M_ROW_IN: {
+      const T* const x = (const T*)op.p0 + (size_t)(ctx->step - ctx->block_start + 1) * op.i0 + op.i1;
+      T* const d = sig + op.dst;
+      ew([&](long long i) { return x[i]; }, [&](long long i, T v) { d[i] = v; });
+      break;
+    }
+    case M_ROW_OUT: {
+      T* const d = (T*)op.p0 + (size_t)(ctx->step - ctx->block_start + 1) * op.i0 + op.i1;
+      const T* const x = sig + op.src;
+      ew([&](long long i) { return x[i]; }, [&](long long i, T v) { d[i] = v; });
+      break;
+    }
+    case M_PROBE: {
+      const ProbeSlot* ps = (const ProbeSlot*)op.p0;
+      const long long s1 = ctx->step + 1;
+      if (s1 % ps->every == 0) {
+        const long long slot = s1 / ps->every - 1 - ps->base_slot;
+        if (slot >= 0 && slot < ps->capacity) {
+          T* const out = (T*)ps->data + (size_t)slot * op.len;
+          const T* const x = sig + op.src;
+          ew([&](long long i) { return x[i]; }, [&](long long i, T v) { out[i] = v; });
+        } else if (tid == 0 && chunk == 0) {
+          ctx->probe_overflow = 1;
+        }
+      }
+      break;
+    }
+    case M_MATVEC_INC:
+    case M_MATVEC_SET: {
+      const T* Wm = (const T*)op.p0;
+      const long long r = (long long)chunk * GLUE_ROWS + tid;
+      if (r < op.len) {
+        T s = T(0);
+        for (int c = 0; c < (int)op.i0; ++c) s += Wm[(size_t)r * op.i1 + c] * sig[op.src + c];
+        if (op.kind == M_MATVEC_INC) sig[op.dst + r] += s; else sig[op.dst + r] = s;
+      }
+      break;
+    }
+    case M_ENS_FINISH: {
+      const T* part = (const T*)op.p0;
+      const int* didx = (const int*)op.p1;
+      const int P = (int)op.i0, dout = (int)op.i1;
+      const long long i = (long long)chunk * GLUE_ROWS + tid;
+      if (i < op.len) {
+        const long long k = i / dout, r = i - k * dout;
+        T s = T(0);
+        for (int p = 0; p < P; ++p) s += part[((size_t)k * P + p) * dout + r];
+        sig[didx[i]] = s;
+      }
+      break;
+    }
+    case M_REDUCE_SET:
+    case M_REDUCE_INC: {
+      const T* part = (const T*)op.p0;
+      const int nc = (int)op.i0;
+      const long long r = (long long)chunk * GLUE_ROWS + tid;
+      if (r < op.len) {
+        T s = T(0);
+        int c = 0;
+        for (; c + 8 <= nc; c += 8) {            // eight chunk reads in flight, added in chunk order
+          T v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(c + q) * op.i1 + r];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; c < nc; ++c) s += part[(size_t)c * op.i1 + r];
+        if (op.kind == M_REDUCE_INC) sig[op.dst + r] += s; else sig[op.dst + r] = s;
+      }
+      break;
+    }
+    case M_STEP_END:
+      if (tid == 0 && chunk == 0) ctx->step = ctx->step + 1;
+      break;
+    default:
+      break;
+  }
+}
+
+// GATE (reference slam.py:236-257's loop-closure correction): dst = open ? rate * (est - cur) : 0, open when the two
+// d-vectors agree (dot product above the threshold) and the flag input is 0.
+template <typename T>
+__device__ __forceinline__ void gate_body(const MicroOp<T>& op, T* __restrict__ sig, unsigned char* smem) {
+  T* sred = reinterpret_cast<T*>(smem);
+  const int tid = threadIdx.x;
+  T part = T(0);
+  for (long long i = tid; i < op.len; i += 256) part += sig[op.src + i] * sig[op.src + op.len + i];
+  part = wave_sum(part);
+  if ((tid & 63) == 0) sred[tid >> 6] = part;
+  __syncthreads();
+  const T dot = ((sred[0] + sred[1]) + sred[2]) + sred[3];
+  const T flag = sig[op.src + 2 * op.len];
+  const bool open = (flag <= T(1e-3) && flag >= T(-1e-3)) && dot > op.a;
+  for (long long i = tid; i < op.len; i += 256)
+    sig[op.dst + i] = open ? op.b * (sig[op.src + i] - sig[op.src + op.len + i]) : T(0);
+}
+
+// ARGMAX + row gather of the clean-up memory: dst = table[first argmax of sims]
+template <typename T>
+__device__ __forceinline__ void argmax_gather_body(const MicroOp<T>& op, T* __restrict__ sig, unsigned char* smem) {
+  T* sred = reinterpret_cast<T*>(smem);
+  int* sidx = reinterpret_cast<int*>(smem + 4 * sizeof(T));
+  const int tid = threadIdx.x;
+  T best = T(-INFINITY);
+  int bi = 0x7fffffff;
+  const T* sims = (const T*)op.p1;
+  const int n_cand = op.src > 0 ? (int)op.src : (int)op.i0;
+  const int* cand_idx = op.src > 0 ? (const int*)(sims + op.src) : nullptr;
+  for (int i0 = tid; i0 < n_cand; i0 += 2048) {       // eight reads in flight, examined in ascending order
+    T v[8];
+    int vi[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256;
+      v[u] = i < n_cand ? sims[i] : T(-INFINITY);
+      vi[u] = (cand_idx && i < n_cand) ? cand_idx[i] : i;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (v[u] > best) { best = v[u]; bi = vi[u]; }     // first maximum within a thread (ascending i)
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const T ov = __shfl_down(best, off, 64);
+    const int oi = __shfl_down(bi, off, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if ((tid & 63) == 0) { sred[tid >> 6] = best; sidx[tid >> 6] = bi; }
+  __syncthreads();
+  best = sred[0]; bi = sidx[0];
+  for (int w = 1; w < 4; ++w)
+    if (sred[w] > best || (sred[w] == best && sidx[w] < bi)) { best = sred[w]; bi = sidx[w]; }
+  if (bi == 0x7fffffff) bi = 0;
+  const T* const trow = (const T*)op.p0 + (size_t)bi * op.i1;
+  T* const d = sig + op.dst;
+  for (long long i = tid; i < op.len; i += 256) d[i] = trow[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_round(RoundArgs<T> ra) {
+  extern __shared__ __align__(16) unsigned char ssn_round_smem[];
+  int vb = (int)blockIdx.x, ei = 0;
+  for (int q = 1; q < ra.n; ++q) if (vb >= ra.e[q].first) ei = q;       // (entries in ascending `first` order; uniform)
+  const RoundEntry e = ra.e[ei];
+  vb -= e.first;
+  const int bx = vb % e.gx, by = vb / e.gx;
+  switch (e.kind) {
+    case RK_GLUE: {
+      const GlueBlock g = ((const GlueBlock*)e.args)[vb];
+      glue_body<T>(ra.mops[g.op], g.chunk, ra.sig, ra.ctx);
+      break;
+    }
+    case RK_GATE: gate_body<T>(*(const MicroOp<T>*)e.args, ra.sig, ssn_round_smem); break;
+    case RK_ARGMAX: argmax_gather_body<T>(*(const MicroOp<T>*)e.args, ra.sig, ssn_round_smem); break;
+    case RK_MATVEC_R1: matvec_body<T, true, 1, 4>(*(const MatvecArgs<T>*)e.args, bx, ssn_round_smem); break;
+    case RK_MATVEC_R4: matvec_body<T, true, 4>(*(const MatvecArgs<T>*)e.args, bx, ssn_round_smem); break;
+    case RK_SPMV: spmv_body<T>(*(const SpmvArgs<T>*)e.args, bx, by, ssn_round_smem); break;
+    case RK_NEURONS: neurons_body<T>(*(const NeuronsArgs<T>*)e.args, bx, ssn_round_smem); break;
+    case RK_DFT:
+      if constexpr (sizeof(T) == 4) dft_body(*(const DftArgs*)e.args, ssn_round_smem);
+      break;
+    case RK_PES: pes_body<T>(*(const PesArgs<T>*)e.args, bx, by); break;
+    case RK_VOJA: voja_body<T>(*(const VojaArgs<T>*)e.args, bx); break;
+    default: break;
+  }
+}
+
+template <typename T>
+hipError_t launch_round(hipStream_t s, const RoundArgs<T>& ra, int n_blocks, size_t lds_bytes) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_round<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  if (lds_bytes > 64 * 1024 || n_blocks <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((k_round<T>), dim3((unsigned)n_blocks), dim3(256), std::max<size_t>(lds_bytes, 64), s, ra);
+  return hipGetLastError();
+}
+
+}  // namespace ssn

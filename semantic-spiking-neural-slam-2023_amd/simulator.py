@@ -80,6 +80,9 @@ def pack_model(model, dtype, device=0, steps_per_graph=0, block_steps=0, flags=0
         elif k == "axpy":
             ii[:4] = [o["dst"], o["src"], o["len"], 1 if o["mode"] == "set" else 0]
             ff[0] = o["alpha"]
+        elif k == "lincomb":
+            ii[:5] = [o["dst"], o["len"], len(o["srcs"]), o["srcs_buf"], o["alphas_buf"]]
+            ff[:2] = [o["self"], o["const"]]
         elif k == "matvec":
             ii[:7] = [o["dst"], o["src"], o["rows"], o["cols"], o["w"], 1 if o["mode"] == "set" else 0, int(o.get("dft", 0) or 0)]
         elif k == "lowpass":

@@ -105,7 +105,7 @@ def _split_elementwise(ops, stage):
     return ops, stage
 
 
-def stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=True):
+def stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=True, collapse=None):
     n = len(ops)
     acc = [op_access(o, model) for o in ops]
     sig_writes = [[r for cls in (0, 1, 3) for r in a[cls]] for a in acc]
@@ -157,7 +157,7 @@ def stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=Tru
                 for j in succ[i]:
                     if stage[j] > stage[i] and any(overlap(w, r) for w in acc[i][3] for r in reads[j]):
                         if ops[j]["kind"] in CORE_KINDS:
-                            return stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=False)
+                            return stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=False, collapse=collapse)
                         stage[j] = stage[i]
                         changed = True
 
@@ -195,6 +195,14 @@ def stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=Tru
     level0 = 0
     for st in (PRE, CORE, POST):
         sub = [dict(o) for o, s in zip(all_ops, all_stage) if s == st]
+        if st == CORE and collapse is not None:
+            # signals that the batched stages or a probe touch keep their values; the rest of the core's linear glue is folded
+            keep = [(p["src"], p["src"] + p["width"]) for p in model.probes if "src" in p]
+            for o, s in zip(all_ops, all_stage):
+                if s != CORE:
+                    a = op_access(o, model)
+                    keep += [(r[1], r[2]) for cls in range(4) for r in a[cls] if r[0] == "s"]
+            sub = collapse(sub, _merge_ranges(keep))
         sched = schedule_ops(sub, model)
         for o in sched:
             o["stage"] = st
@@ -250,7 +258,7 @@ def stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=Tru
             ready.sort()
         if len(order) != m:
             # a feedback cycle inside a feed-forward stage would be a partitioning bug: fall back
-            return stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=False)
+            return stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=False, collapse=collapse)
         for k, a in enumerate(order):
             out[idx[a]]["border"] = k
 

@@ -742,7 +742,7 @@ def test_fused_recurrent_core_equals_generic_path(Simulator):
             sim.run_steps(150)        # block boundaries, eager remainders and a second call: flush/begin paths
             outs.append(sim.data[pm.probe])
             outs.append(sim.counters()["launches_per_step"])
-    assert outs[1] == 1 and outs[3] == 2 and outs[5] == 2
+    assert outs[1] == 1 and 2 <= outs[3] <= 8 and outs[5] == 2      # (the generic plan: one launch per dependency round)
     np.testing.assert_array_equal(outs[0], outs[2])
     np.testing.assert_array_equal(outs[0], outs[4])
     # LIF fast path (packed state word, spike-sparse neuron-major decoders) vs the generic kernel: same bits
@@ -888,7 +888,7 @@ def test_slam_3d_matches_oracle(Simulator):
             launches.append(sim.counters()["launches_per_step"])
         cc = H.cosine_error(got_clean[5:], want_clean[5:])
         assert (cc < 1e-6).mean() >= 0.7 and cc.max() < 0.05, (flags, (cc < 1e-6).mean(), cc.max())
-    assert launches[0] == launches[1] + 2
+    assert launches[1] < launches[0] <= launches[1] + 6       # the factored route adds the half-spectrum, left-operand and product launches (and their rounds)
 
 
 def test_long_run_pipelines_input_tabulation(Simulator):
@@ -1031,6 +1031,7 @@ def _gridcell_models():
     from sspslam_amd.sspspace import SPSpace
     from sspslam_amd.utils import Rd_sampling
     space = H.make_ssp_space(2, 55)
+    space.rng = np.random.default_rng(11)       # grid-cell encoders are drawn from the space's generator (unseeded by default, like the reference)
     path, vels = H.make_random_path(10.0, limit=0.2, seed=1)
     real_ssp = space.encode(path)
     scale = 1.0 / np.max(np.abs(space.phase_matrix @ vels.T))
@@ -1070,6 +1071,7 @@ def test_gridcell_populations_match_oracle(Simulator):
                 want = ref.probe_data(idx[id(p)])
                 assert np.abs(want).max() > 0
                 np.testing.assert_allclose(sim.data[p], want, atol=1e-9, rtol=0)
-        with Simulator(None, model=model, dtype="f32") as sim:
-            sim.run_steps(300)
-            assert H.cosine_error(sim.data[probes[0]][20:], ref.probe_data(idx[id(probes[0])])[20:]).max() < 1e-3
+        for flags in (0, 2097152):        # the round plan | one launch per operator and program
+            with Simulator(None, model=model, dtype="f32", flags=flags) as sim:
+                sim.run_steps(300)
+                assert H.cosine_error(sim.data[probes[0]][20:], ref.probe_data(idx[id(probes[0])])[20:]).max() < 1e-3
