@@ -169,7 +169,9 @@ struct Sim final : ssn_sim {
   struct Launch { int rl = -1; int item = -1; int phase = 0; };
   bool round_mode = false;
   std::vector<RoundLaunch> round_launches;
-  std::vector<Launch> launch_list;
+  std::vector<Launch> launch_list;            // one timestep
+  std::vector<Launch> graph_list;             // steps_per_graph timesteps, software-pipelined (empty: replay launch_list)
+  int graph_rounds = 0;
   std::vector<void*> round_bufs;
   std::vector<hipStream_t> side_streams;
   std::vector<hipEvent_t> dag_events;
@@ -547,8 +549,9 @@ struct Sim final : ssn_sim {
       for (auto& r : pre_to_core) CHK(check_range(r.lo, r.hi - r.lo, "pre->core boundary"));
       for (auto& r : core_to_post) CHK(check_range(r.lo, r.hi - r.lo, "core->post boundary"));
     }
-    CHK(plan(m));
     steps_per_graph = m->steps_per_graph != 0 ? m->steps_per_graph : 16;
+    if (steps_per_graph > 64) return fail(SSN_EINVAL, "steps_per_graph %d: at most 64", steps_per_graph);
+    CHK(plan(m));
     CHK(capture());
     HIPCHK(hipStreamSynchronize(stream));
     return SSN_OK;
@@ -1385,7 +1388,7 @@ struct Sim final : ssn_sim {
     return k == ssn::M_MATVEC_INC || k == ssn::M_MATVEC_SET || k == ssn::M_ENS_FINISH || k == ssn::M_REDUCE_SET || k == ssn::M_REDUCE_INC;
   }
   int build_rounds(const std::vector<std::vector<MOp>>& programs, const std::vector<int>& item_prog) {
-    struct Unit { int mop = -1; int item = -1; int round = 0; int phase = 0; std::vector<Rng> acc; };
+    struct Unit { int mop = -1; int item = -1; int phase = 0; bool writes = false; std::vector<Rng> acc; };
     std::vector<Unit> units;
     mops.clear();
     int prog_i = 0;
@@ -1407,126 +1410,194 @@ struct Sim final : ssn_sim {
         units.push_back(std::move(u));
       }
     }
-    int n_rounds = 0, phase1_base = 0;
-    bool in_phase1 = false;
-    for (size_t u = 0; u < units.size(); ++u) {
-      if (units[u].phase == 1 && !in_phase1) { in_phase1 = true; phase1_base = n_rounds; }
-      int r = in_phase1 ? phase1_base : 0;
-      for (size_t v = 0; v < u; ++v)
-        if (units[v].round >= r && hazard(units[u].acc, units[v].acc)) r = units[v].round + 1;
-      units[u].round = r;
-      n_rounds = std::max(n_rounds, r + 1);
-    }
+    for (Unit& u : units) for (const Rng& r : u.acc) u.writes = u.writes || r.w;
     // device copies: micro-operators, the block -> (operator, chunk) maps of the glue entries, body arguments
     CHK(dmalloc(&d_mops, (int64_t)std::max<size_t>(1, mops.size()) * (int64_t)sizeof(MOp)));
     if (!mops.empty()) HIPCHK(hipMemcpy(d_mops, mops.data(), mops.size() * sizeof(MOp), hipMemcpyHostToDevice));
     std::vector<ssn::GlueBlock> glue_map;
     std::vector<unsigned char> arena;
     auto put = [&](const void* src, size_t bytes) { const size_t off = (arena.size() + 15) / 16 * 16; arena.resize(off + bytes); memcpy(arena.data() + off, src, bytes); return off; };
+    std::vector<long long> unit_arg(units.size(), -1);      // arena offset of a big operator's body arguments (shared by its instances)
     struct Fix { size_t rl; int entry; int what; size_t off; };     // what: 0 arena, 1 glue map, 2 micro-operator
     std::vector<Fix> fixes;
     round_launches.clear();
-    launch_list.clear();
-    for (int r = 0; r < n_rounds; ++r) {
-      RoundLaunch rl;
-      rl.round = r;
-      rl.args = ssn::RoundArgs<T>{};
-      rl.args.mops = d_mops; rl.args.sig = sig; rl.args.ctx = d_ctx;
-      int phase = 0;
-      std::vector<Launch> plain;
-      auto close = [&]() {
-        if (rl.args.n == 0) return;
-        Launch l; l.rl = (int)round_launches.size(); l.phase = phase;
-        round_launches.push_back(rl);
-        launch_list.push_back(l);
-        rl.args.n = 0; rl.n_blocks = 0; rl.lds = 0;
-      };
-      auto entry = [&](int kind, int gx, int gy, size_t lds, int what, size_t off) {
-        if (rl.args.n == ssn::MAX_ROUND_ENTRIES) close();
-        ssn::RoundEntry& e = rl.args.e[rl.args.n];
-        e.kind = kind; e.first = rl.n_blocks; e.gx = std::max(1, gx); e.gy = std::max(1, gy); e.args = nullptr;
-        fixes.push_back(Fix{round_launches.size(), rl.args.n, what, off});
-        rl.n_blocks += e.gx * e.gy;
-        rl.lds = std::max(rl.lds, lds);
-        rl.args.n += 1;
-      };
-      // glue: one entry for all chunked micro-operators of the round
-      const size_t map_begin = glue_map.size();
-      for (const Unit& u : units) {
-        if (u.round != r) continue;
-        phase = u.phase;
-        if (u.mop < 0) continue;
-        const MOp& op = mops[(size_t)u.mop];
-        if (op.kind == ssn::M_GATE || op.kind == ssn::M_ARGMAX_GATHER) continue;
-        const long long per = glue_row_kind(op.kind) ? ssn::GLUE_ROWS : ssn::GLUE_CHUNK;
-        const int chunks = (int)std::max<long long>(1, (op.len + per - 1) / per);
-        for (int c = 0; c < chunks; ++c) glue_map.push_back(ssn::GlueBlock{u.mop, c});
-      }
-      if (glue_map.size() > map_begin) entry(ssn::RK_GLUE, (int)(glue_map.size() - map_begin), 1, 64, 1, map_begin);
-      for (const Unit& u : units) {
-        if (u.round != r) continue;
-        if (u.mop >= 0) {
+
+    // One instance of a unit: (unit, timestep offset inside the launch sequence, round).
+    struct Inst { int unit; int sub; int round; };
+    // Launch sequence of a set of instances grouped by round (instances of one round are mutually independent).
+    auto emit = [&](const std::vector<Inst>& insts, int n_rounds, std::vector<Launch>& out) {
+      std::vector<std::vector<const Inst*>> by_round((size_t)n_rounds);
+      for (const Inst& in : insts) by_round[(size_t)in.round].push_back(&in);
+      for (int r = 0; r < n_rounds; ++r) {
+        RoundLaunch rl;
+        rl.round = r;
+        rl.args = ssn::RoundArgs<T>{};
+        rl.args.mops = d_mops; rl.args.sig = sig; rl.args.ctx = d_ctx;
+        int phase = 0;
+        std::vector<Launch> plain;
+        auto close = [&]() {
+          if (rl.args.n == 0) return;
+          Launch l; l.rl = (int)round_launches.size(); l.phase = phase;
+          round_launches.push_back(rl);
+          out.push_back(l);
+          rl.args.n = 0; rl.n_blocks = 0; rl.lds = 0;
+        };
+        auto entry = [&](int kind, int gx, int gy, size_t lds, int what, size_t off) {
+          if (rl.args.n == ssn::MAX_ROUND_ENTRIES) close();
+          ssn::RoundEntry& e = rl.args.e[rl.args.n];
+          e.kind = kind; e.first = rl.n_blocks; e.gx = std::max(1, gx); e.gy = std::max(1, gy); e.args = nullptr;
+          fixes.push_back(Fix{round_launches.size(), rl.args.n, what, off});
+          rl.n_blocks += e.gx * e.gy;
+          rl.lds = std::max(rl.lds, lds);
+          rl.args.n += 1;
+        };
+        // glue: one entry for all chunked micro-operators of the round
+        const size_t map_begin = glue_map.size();
+        for (const Inst* in : by_round[(size_t)r]) {
+          const Unit& u = units[(size_t)in->unit];
+          phase = u.phase;
+          if (u.mop < 0) continue;
           const MOp& op = mops[(size_t)u.mop];
-          if (op.kind == ssn::M_GATE) entry(ssn::RK_GATE, 1, 1, 64, 2, (size_t)u.mop);
-          else if (op.kind == ssn::M_ARGMAX_GATHER) entry(ssn::RK_ARGMAX, 1, 1, 64, 2, (size_t)u.mop);
-          continue;
+          if (op.kind == ssn::M_GATE || op.kind == ssn::M_ARGMAX_GATHER) continue;
+          const long long per = glue_row_kind(op.kind) ? ssn::GLUE_ROWS : ssn::GLUE_CHUNK;
+          const int chunks = (int)std::max<long long>(1, (op.len + per - 1) / per);
+          for (int c = 0; c < chunks; ++c) glue_map.push_back(ssn::GlueBlock{u.mop, c | (in->sub << 24)});
         }
-        const Item& it = items[(size_t)u.item];
-        const size_t xb = (size_t)it.cols * sizeof(T);
-        switch (it.type) {
-          case IT_MATVEC:
-            if (xb <= 48 * 1024) {
-              ssn::MatvecArgs<T> a{it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set};
-              const bool r1 = it.rows <= 4096;
-              entry(r1 ? ssn::RK_MATVEC_R1 : ssn::RK_MATVEC_R4, r1 ? (it.rows + 3) / 4 : (it.rows + 15) / 16, 1, xb, 0, put(&a, sizeof a));
+        if (glue_map.size() > map_begin) entry(ssn::RK_GLUE, (int)(glue_map.size() - map_begin), 1, 64, 1, map_begin);
+        for (const Inst* in : by_round[(size_t)r]) {
+          const Unit& u = units[(size_t)in->unit];
+          if (u.mop >= 0) {
+            const MOp& op = mops[(size_t)u.mop];
+            if (op.kind == ssn::M_GATE) entry(ssn::RK_GATE, 1, 1, 64, 2, (size_t)u.mop);
+            else if (op.kind == ssn::M_ARGMAX_GATHER) entry(ssn::RK_ARGMAX, 1, 1, 64, 2, (size_t)u.mop);
+            continue;
+          }
+          const Item& it = items[(size_t)u.item];
+          const size_t xb = (size_t)it.cols * sizeof(T);
+          long long& ao = unit_arg[(size_t)in->unit];
+          switch (it.type) {
+            case IT_MATVEC:
+              if (xb <= 48 * 1024) {
+                ssn::MatvecArgs<T> a{it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set};
+                if (ao < 0) ao = (long long)put(&a, sizeof a);
+                const bool r1 = it.rows <= 4096;
+                entry(r1 ? ssn::RK_MATVEC_R1 : ssn::RK_MATVEC_R4, r1 ? (it.rows + 3) / 4 : (it.rows + 15) / 16, 1, xb, 0, (size_t)ao);
+                continue;
+              }
+              break;
+            case IT_ENS: {
+              const ssn::EnsArgs<T>& a = it.ens;
+              int kind = -1;
+              if (a.fast == 1 && a.din == 3 && a.dout == 4) kind = ssn::RK_ENS_3_4_S;
+              else if (a.fast == 1 && a.din == 3 && a.dout == 5) kind = ssn::RK_ENS_3_5_S;
+              else if (a.fast == 2 && a.din == 1 && a.dout == 1) kind = ssn::RK_ENS_1_1_D;
+              if (kind >= 0 && !a.defer && !a.xrows && !(flags & 4194304)) {
+                if (ao < 0) ao = (long long)put(&a, sizeof a);
+                entry(kind, a.K * a.P, 1, 512, 0, (size_t)ao);
+                continue;
+              }
+              break;
+            }
+            case IT_SPMV: {
+              ssn::SpmvArgs<T> a{it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count, it.seg};
+              const size_t lds = 272 * sizeof(int) + (it.list ? 0 : (size_t)it.cols * sizeof(int));
+              if (lds <= 60 * 1024) {
+                if (ao < 0) ao = (long long)put(&a, sizeof a);
+                entry(ssn::RK_SPMV, (it.rows + 255) / 256, it.n, lds, 0, (size_t)ao);
+                continue;
+              }
+              break;
+            }
+            case IT_NEURONS: {
+              ssn::NeuronsArgs<T> a{it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count};
+              if (ao < 0) ao = (long long)put(&a, sizeof a);
+              entry(ssn::RK_NEURONS, (it.n + 255) / 256, 1, 64, 0, (size_t)ao);
               continue;
             }
-            break;
-          case IT_SPMV: {
-            ssn::SpmvArgs<T> a{it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count, it.seg};
-            const size_t lds = 272 * sizeof(int) + (it.list ? 0 : (size_t)it.cols * sizeof(int));
-            if (lds <= 60 * 1024) { entry(ssn::RK_SPMV, (it.rows + 255) / 256, it.n, lds, 0, put(&a, sizeof a)); continue; }
-            break;
+            case IT_DFT: {
+              const size_t lds = (size_t)(it.dft.M > 0 ? it.dft.M : it.dft.N) * 3 * sizeof(float2);
+              if (lds <= 60 * 1024) {
+                if (ao < 0) ao = (long long)put(&it.dft, sizeof it.dft);
+                entry(ssn::RK_DFT, 1, 1, lds, 0, (size_t)ao);
+                continue;
+              }
+              break;
+            }
+            case IT_PES: {
+              ssn::PesArgs<T> a{it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar};
+              if (ao < 0) ao = (long long)put(&a, sizeof a);
+              entry(ssn::RK_PES, (it.cols + 1023) / 1024, it.rows, 64, 0, (size_t)ao);
+              continue;
+            }
+            case IT_VOJA: {
+              ssn::VojaArgs<T> a{it.Wm, it.src, it.aux0, it.aux1, it.aux2, it.rows, it.cols, it.ld, it.scalar};
+              if (ao < 0) ao = (long long)put(&a, sizeof a);
+              entry(ssn::RK_VOJA, (it.rows + 3) / 4, 1, 64, 0, (size_t)ao);
+              continue;
+            }
+            default: break;
           }
-          case IT_NEURONS: {
-            ssn::NeuronsArgs<T> a{it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count};
-            entry(ssn::RK_NEURONS, (it.n + 255) / 256, 1, 64, 0, put(&a, sizeof a));
-            continue;
-          }
-          case IT_DFT: {
-            const size_t lds = (size_t)(it.dft.M > 0 ? it.dft.M : it.dft.N) * 3 * sizeof(float2);
-            if (lds <= 60 * 1024) { entry(ssn::RK_DFT, 1, 1, lds, 0, put(&it.dft, sizeof it.dft)); continue; }
-            break;
-          }
-          case IT_PES: {
-            ssn::PesArgs<T> a{it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar};
-            entry(ssn::RK_PES, (it.cols + 1023) / 1024, it.rows, 64, 0, put(&a, sizeof a));
-            continue;
-          }
-          case IT_VOJA: {
-            ssn::VojaArgs<T> a{it.Wm, it.src, it.aux0, it.aux1, it.aux2, it.rows, it.cols, it.ld, it.scalar};
-            entry(ssn::RK_VOJA, (it.rows + 3) / 4, 1, 64, 0, put(&a, sizeof a));
-            continue;
-          }
-          default: break;
+          Launch l; l.item = u.item; l.phase = u.phase;
+          plain.push_back(l);
         }
-        Launch l; l.item = u.item; l.phase = u.phase;
-        plain.push_back(l);
+        for (const Launch& l : plain) out.push_back(l);      // the plain launches first (ensemble arrays: the long ones), then the round's grid
+        close();
       }
-      // the plain launches first (ensemble arrays: the long ones), then the round's grid
-      for (size_t q = 0; q < plain.size(); ++q) {
-        Item& a = items[(size_t)plain[q].item];
-        if (q + 1 < plain.size() && plain[q + 1].item == plain[q].item + 1 && a.type == IT_ENS && !a.dominant && !a.ens.defer) {
-          const Item& b = items[(size_t)plain[q + 1].item];
-          if (b.type == IT_ENS && !b.dominant && !b.ens.defer && b.ens.din == a.ens.din && b.ens.dout == a.ens.dout && b.ens.fast == a.ens.fast) {
-            a.batch = 2;
-            items[(size_t)plain[q + 1].item].merged = true;
-          }
-        }
-        launch_list.push_back(plain[q]);
-      }
-      close();
+    };
+
+    // ---- one timestep: the eager / profiled / phased sequence --------------------------------------------------------
+    std::vector<Inst> one;
+    int n_rounds = 0, phase1_base = 0;
+    bool in_phase1 = false;
+    for (size_t u = 0; u < units.size(); ++u) {
+      if (units[u].phase == 1 && !in_phase1) { in_phase1 = true; phase1_base = n_rounds; }
+      int r = in_phase1 ? phase1_base : 0;
+      for (size_t v = 0; v < u; ++v)
+        if (one[v].round >= r && hazard(units[u].acc, units[v].acc)) r = one[v].round + 1;
+      one.push_back(Inst{(int)u, 0, r});
+      n_rounds = std::max(n_rounds, r + 1);
     }
+    launch_list.clear();
+    emit(one, n_rounds, launch_list);
+    launches_per_step = (int)launch_list.size();
+    const int launches_unpipelined = launches_per_step;
+
+    // ---- G timesteps software-pipelined: the sequence a step graph replays -------------------------------------------
+    // Instance (u, s) takes the earliest round that its hazards against the instances of timesteps s and s - 1 allow
+    // (a writer conflicts with itself one step earlier, so older steps are ordered transitively).  The recurrence of a
+    // SLAM step runs through synapse states only: the long un-filtered chain of step s (two circular convolutions in
+    // series) ends in filter updates that step s + 1 reads only to update other filters, so the head of step s + 1 -
+    // the bandwidth-bound oscillators and encoder products - runs in the rounds where step s has one latency-bound
+    // workgroup left.  Clock readers take the step number from StepCtx plus their own offset; the clock itself
+    // advances once, behind the last round (k_advance).
+    graph_list.clear();
+    graph_rounds = 0;
+    const int G = steps_per_graph;
+    if (!phased && G > 1 && !(flags & 8388608) && units.size() * (size_t)G <= 40000) {
+      std::vector<int> keep;
+      for (size_t u = 0; u < units.size(); ++u)
+        if (!(units[u].mop >= 0 && mops[(size_t)units[u].mop].kind == ssn::M_STEP_END)) keep.push_back((int)u);
+      std::vector<std::vector<Rng>> acc_nc(units.size());     // access lists without the clock
+      for (int u : keep) { if (units[(size_t)u].mop >= 0) micro_access(acc_nc[(size_t)u], mops[(size_t)units[(size_t)u].mop], false); else acc_nc[(size_t)u] = units[(size_t)u].acc; }
+      std::vector<Inst> all;
+      all.reserve(keep.size() * (size_t)G);
+      int nr = 0;
+      const size_t per = keep.size();
+      for (int st = 0; st < G; ++st)
+        for (size_t q = 0; q < per; ++q) {
+          const int u = keep[q];
+          int r = 0;
+          const size_t lo = st > 0 ? (size_t)(st - 1) * per : 0, hi = all.size();
+          for (size_t v = lo; v < hi; ++v)
+            if (all[v].round >= r && hazard(acc_nc[(size_t)u], acc_nc[(size_t)all[v].unit])) r = all[v].round + 1;
+          all.push_back(Inst{u, st, r});
+          nr = std::max(nr, r + 1);
+        }
+      emit(all, nr, graph_list);
+      graph_rounds = nr;
+      launches_per_step = ((int)graph_list.size() + G - 1) / G;       // (average of the replayed sequence)
+    }
+
     T* d_arena = nullptr; ssn::GlueBlock* d_map = nullptr;
     CHK(dmalloc(&d_arena, (int64_t)arena.size() + 16));
     round_bufs.push_back(d_arena);
@@ -1540,19 +1611,27 @@ struct Sim final : ssn_sim {
       else if (f.what == 1) e.args = d_map + f.off;
       else e.args = d_mops + f.off;
     }
-    int launches = 0;
-    for (const Launch& l : launch_list) launches += (l.rl >= 0 || !items[(size_t)l.item].merged) ? 1 : 0;
-    launches_per_step = launches;
     if (getenv("SSN_DEBUG_PLAN")) {
-      fprintf(stderr, "[ssn] round plan: %zu units in %d rounds, %d launches per timestep\n", units.size(), n_rounds, launches);
+      fprintf(stderr, "[ssn] round plan: %zu units in %d rounds, %d launches per timestep; %d timesteps pipelined: %d rounds, %zu launches\n",
+              units.size(), n_rounds, launches_unpipelined, G, graph_rounds, graph_list.size());
       for (const Launch& l : launch_list) {
-        if (l.rl < 0) { const Item& it = items[(size_t)l.item]; fprintf(stderr, "[ssn]   plain item %d type %d rows %d cols %d n %d%s\n", l.item, it.type, it.rows, it.cols, it.n, it.merged ? " (batched)" : ""); continue; }
+        if (l.rl < 0) { const Item& it = items[(size_t)l.item]; fprintf(stderr, "[ssn]   plain item %d type %d rows %d cols %d n %d\n", l.item, it.type, it.rows, it.cols, it.n); continue; }
         const RoundLaunch& rl = round_launches[(size_t)l.rl];
         fprintf(stderr, "[ssn]   round %2d phase %d: %d blocks, %zu B LDS:", rl.round, l.phase, rl.n_blocks, rl.lds);
         for (int q = 0; q < rl.args.n; ++q) fprintf(stderr, " %d[%dx%d]", rl.args.e[q].kind, rl.args.e[q].gx, rl.args.e[q].gy);
         fprintf(stderr, "\n");
-        for (const Unit& u : units)
-          if (u.round == rl.round && u.mop >= 0) fprintf(stderr, "[ssn]       micro %d/%lld dst %lld src %lld\n", mops[(size_t)u.mop].kind, (long long)mops[(size_t)u.mop].len, (long long)mops[(size_t)u.mop].dst, (long long)mops[(size_t)u.mop].src);
+        for (const Inst& in : one)
+          if (in.round == rl.round && units[(size_t)in.unit].mop >= 0) {
+            const MOp& o = mops[(size_t)units[(size_t)in.unit].mop];
+            fprintf(stderr, "[ssn]       micro %d/%lld dst %lld src %lld\n", o.kind, (long long)o.len, (long long)o.dst, (long long)o.src);
+          }
+      }
+      for (const Launch& l : graph_list) {
+        if (l.rl < 0) { fprintf(stderr, "[ssn]   pipelined: plain item %d type %d\n", l.item, items[(size_t)l.item].type); continue; }
+        const RoundLaunch& rl = round_launches[(size_t)l.rl];
+        fprintf(stderr, "[ssn]   pipelined round %3d: %6d blocks, %5zu B LDS:", rl.round, rl.n_blocks, rl.lds);
+        for (int q = 0; q < rl.args.n; ++q) fprintf(stderr, " %d[%d]", rl.args.e[q].kind, rl.args.e[q].gx * rl.args.e[q].gy);
+        fprintf(stderr, "\n");
       }
     }
     return SSN_OK;
@@ -1818,6 +1897,11 @@ struct Sim final : ssn_sim {
       return hipGetLastError();
     }
     if (round_mode) {
+      if (count == steps_per_graph && !graph_list.empty()) {
+        for (const Launch& l : graph_list) { hipError_t e = launch_one(l); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, (long long)count);
+        return hipGetLastError();
+      }
       for (int s = 0; s < count; ++s)
         for (const Launch& l : launch_list) { hipError_t e = launch_one(l); if (e != hipSuccess) return e; }
       return hipSuccess;

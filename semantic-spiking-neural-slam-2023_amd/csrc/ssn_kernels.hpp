@@ -118,16 +118,15 @@ __device__ inline T wave_sum(T v) {
 template <int DOUT> struct DecPitch { static constexpr int value = DOUT <= 4 ? 4 : 8; };
 
 template <typename T, int DIN, int DOUT, int MODE>   // MODE 0 generic | 1 fast, spike-sparse decoders | 2 fast, dense decoders
-__global__ __launch_bounds__(256) void k_ensarray(EnsBatch<T> batch) {
-  const EnsArgs<T>& a = batch.a[blockIdx.y];
-  if ((int)blockIdx.x >= a.K * a.P) return;          // (grid.x is sized for the larger array of a batch)
+__device__ __forceinline__ void ens_body(const EnsArgs<T>& a, const int bx, unsigned char* smem) {   // smem: 4 * DOUT + DIN values of T
+  if (bx >= a.K * a.P) return;          // (grid.x is sized for the larger array of a batch)
   using vec = typename VecT<T>::type;
   constexpr int W = VecT<T>::W;
   constexpr bool FAST = MODE != 0;
   constexpr bool SPARSE = MODE == 1;
   constexpr int DP = DecPitch<DOUT>::value;
-  const int k = blockIdx.x / a.P;
-  const int p = blockIdx.x - k * a.P;
+  const int k = bx / a.P;
+  const int p = bx - k * a.P;
   const size_t row = (size_t)a.n_pad;
   const T* __restrict__ enc = a.enc + (size_t)k * DIN * row;
   const T* __restrict__ bias = a.bias + (size_t)k * row;
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsBatch<T> batch) {
     //  * workgroup p == 0, lanes 64 + r (r < DOUT): publish step-1's decoded row r (signal, filter state,
     //    hand-off to the post stage).  Every workgroup of an ensemble derives identical values from
     //    identical inputs, so nothing else needs to wait for the publisher.
-    __shared__ T s_x[DIN];
+    T* s_x = reinterpret_cast<T*>(smem) + 4 * DOUT;      // [DIN]
     const int par = (int)(step & 1);
     const long long NR = (long long)a.K * DOUT;
     const bool pending = (step - 1) > a.ctx->finished;
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsBatch<T> batch) {
     if constexpr (!FAST) { if (v + 256 < v_end) load_sweep(v + 256); }
   }
 
-  __shared__ T red[4][DOUT];
+  T (*red)[DOUT] = reinterpret_cast<T (*)[DOUT]>(smem);      // [4][DOUT]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int r = 0; r < DOUT; ++r) {
@@ -312,6 +311,11 @@ __global__ __launch_bounds__(256) void k_ensarray(EnsBatch<T> batch) {
       out[((size_t)k * a.P + p) * DOUT + r] = total;
     }
   }
+}
+template <typename T, int DIN, int DOUT, int MODE>
+__global__ __launch_bounds__(256) void k_ensarray(EnsBatch<T> batch) {
+  __shared__ __align__(16) unsigned char smem[(4 * DOUT + DIN) * sizeof(T)];
+  ens_body<T, DIN, DOUT, MODE>(batch.a[blockIdx.y], (int)blockIdx.x, smem);
 }
 
 // decoder re-layout [K][dout][n] (row-major, host order, ld = n_pad) <-> [K][n_pad][DP] (neuron-major)
@@ -443,25 +447,45 @@ hipError_t launch_ensarray(hipStream_t s, const EnsArgs<T>& a) {
 // ---------------------------------------------------------------------------------------------
 // One mixed-radix Stockham pass structure over L points held in LDS (x -> result returned; y is scratch)
 __device__ inline float2* dft_stockham(float2* x, float2* y, const float2* tw, int L, const int* radix, int nr, int tid, int nthr) {
+  // Four output points per thread at a time: a radix-r butterfly is r dependent LDS round trips (value + twiddle), and
+  // one wave per SIMD has nothing else to hide them behind - four independent chains do (a 256-thread workgroup then
+  // runs a 1015-point transform as fast as 1024 threads with one point each).
+  constexpr int U = 4;
   int n = L, s = 1;
   for (int st = 0; st < nr; ++st) {
     const unsigned r = (unsigned)radix[st], m = (unsigned)n / r, fn = (unsigned)(L / n), fr = (unsigned)L / r;
-    for (int o = tid; o < L; o += nthr) {
+    const unsigned us = (unsigned)s, stride = us * m;
+    for (int o0 = tid; o0 < L; o0 += nthr * U) {
       // (all products below stay under 2^32: p j fn < L * 32, L <= 6400, see plan_dft)
-      const unsigned uo = (unsigned)o, us = (unsigned)s;
-      const unsigned q = uo % us, u = uo / us, j = u % r, p = u / r;
-      int idx = (int)((p * j * fn) % (unsigned)L);
-      const int step = (int)((j * fr) % (unsigned)L);
-      const float2* xi = x + q + s * p;
-      float2 acc = make_float2(0.0f, 0.0f);
-      for (int k = 0; k < (int)r; ++k) {
-        const float2 v = xi[(unsigned)s * m * (unsigned)k], t = tw[idx];
-        acc.x = fmaf(v.x, t.x, fmaf(-v.y, t.y, acc.x));
-        acc.y = fmaf(v.x, t.y, fmaf(v.y, t.x, acc.y));
-        idx += step;
-        if (idx >= L) idx -= L;
+      int idx[U], stp[U];
+      const float2* xi[U];
+      float2 acc[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int o = o0 + u * nthr;
+        ok[u] = o < L;
+        const unsigned uo = ok[u] ? (unsigned)o : 0u;
+        const unsigned q = uo % us, w = uo / us, j = w % r, p = w / r;
+        idx[u] = (int)((p * j * fn) % (unsigned)L);
+        stp[u] = (int)((j * fr) % (unsigned)L);
+        xi[u] = x + q + us * p;
+        acc[u] = make_float2(0.0f, 0.0f);
       }
-      y[o] = acc;
+      for (unsigned k = 0; k < r; ++k) {
+        float2 v[U], t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { v[u] = xi[u][stride * k]; t[u] = tw[idx[u]]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          acc[u].x = fmaf(v[u].x, t[u].x, fmaf(-v[u].y, t[u].y, acc[u].x));
+          acc[u].y = fmaf(v[u].x, t[u].y, fmaf(v[u].y, t[u].x, acc[u].y));
+          idx[u] += stp[u];
+          if (idx[u] >= L) idx[u] -= L;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (ok[u]) y[o0 + u * nthr] = acc[u];
     }
     __syncthreads();
     float2* t2 = x; x = y; y = t2;

@@ -209,11 +209,12 @@ template <typename T> struct VojaArgs { T* E; const T* spk; const T* key; const 
 enum RoundKind {
   RK_GLUE = 0,        // element-wise / reduction micro-operators, one chunk per block (args: GlueBlock map)
   RK_GATE, RK_ARGMAX, // whole-vector micro-operators: one block each (args: MicroOp)
-  RK_MATVEC_R1, RK_MATVEC_R4, RK_SPMV, RK_NEURONS, RK_DFT, RK_PES, RK_VOJA
+  RK_MATVEC_R1, RK_MATVEC_R4, RK_SPMV, RK_NEURONS, RK_DFT, RK_PES, RK_VOJA,
+  RK_ENS_3_4_S, RK_ENS_3_5_S, RK_ENS_1_1_D      // k_ensarray<din, dout, spike-sparse | dense decoders>
 };
-struct GlueBlock { int op; int chunk; };        // micro-operator index (into RoundArgs::mops), chunk of it
+struct GlueBlock { int op; int chunk; };        // micro-operator index (into RoundArgs::mops); chunk of it (low 24 bits), timestep offset (high 8)
 struct RoundEntry { int kind; int first; int gx; int gy; const void* args; };
-constexpr int MAX_ROUND_ENTRIES = 28;
+constexpr int MAX_ROUND_ENTRIES = 96;
 template <typename T>
 struct RoundArgs {
   int n;

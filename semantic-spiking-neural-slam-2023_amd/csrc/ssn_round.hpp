@@ -13,6 +13,8 @@
 //               interpreter k_program ran these back to back (~0.4 us each, latency-bound); here they run side by side.
 //   RK_GATE, RK_ARGMAX   whole-vector micro-operators (a dot product / an argmax decide what is written): one block
 //   RK_MATVEC_*, RK_SPMV, RK_NEURONS, RK_DFT, RK_PES, RK_VOJA   the bodies of the stand-alone kernels (ssn_kernels.hpp)
+//   RK_ENS_*    k_ensarray's body for the variants a SLAM network uses: the path integrator's oscillators (3 inputs, 4 or 5
+//               decoded rows, spike-sparse decoders) and the product ensembles of the circular convolutions (1-D)
 //
 // Workgroup memory is one dynamic allocation sized for the round's hungriest body (no static LDS in any body: static
 // allocations of all bodies would add up).
@@ -24,7 +26,8 @@ namespace ssn {
 // One chunk of one micro-operator.  Element-wise kinds: elements [chunk * GLUE_CHUNK, ...) - four per thread,
 // loads before stores; row kinds (reductions, ensemble finish, small matvec): rows [chunk * GLUE_ROWS, ...), one per thread.
 template <typename T>
-__device__ __forceinline__ void glue_body(const MicroOp<T>& op, const int chunk, T* __restrict__ sig, StepCtx* __restrict__ ctx) {
+__device__ __forceinline__ void glue_body(const MicroOp<T>& op, const int chunk, const int sub, T* __restrict__ sig, StepCtx* __restrict__ ctx) {
+  // sub: timestep offset of this instance inside a pipelined launch sequence (the clock advances once per sequence)
   const int tid = threadIdx.x;
   auto ew = [&](auto load, auto store) {
     const long long base = (long long)chunk * GLUE_CHUNK;
@@ -73,7 +76,7 @@ __device__ __forceinline__ void glue_body(const MicroOp<T>& op, const int chunk,
     }
     case M_TABLE: {
       const TableSlot* t = (const TableSlot*)op.p0;
-      const long long rel = ctx->step - t->first_step;
+      const long long rel = ctx->step + sub - t->first_step;
       int row = -1;
       if (rel >= 0 && rel < t->n_idx) row = t->idx[rel];
       const bool have = row >= 0 && row < t->n_rows;
@@ -83,20 +86,20 @@ __device__ __forceinline__ void glue_body(const MicroOp<T>& op, const int chunk,
       break;
     }
     case M_ROW_IN: {
-      const T* const x = (const T*)op.p0 + (size_t)(ctx->step - ctx->block_start + 1) * op.i0 + op.i1;
+      const T* const x = (const T*)op.p0 + (size_t)(ctx->step + sub - ctx->block_start + 1) * op.i0 + op.i1;
       T* const d = sig + op.dst;
       ew([&](long long i) { return x[i]; }, [&](long long i, T v) { d[i] = v; });
       break;
     }
     case M_ROW_OUT: {
-      T* const d = (T*)op.p0 + (size_t)(ctx->step - ctx->block_start + 1) * op.i0 + op.i1;
+      T* const d = (T*)op.p0 + (size_t)(ctx->step + sub - ctx->block_start + 1) * op.i0 + op.i1;
       const T* const x = sig + op.src;
       ew([&](long long i) { return x[i]; }, [&](long long i, T v) { d[i] = v; });
       break;
     }
     case M_PROBE: {
       const ProbeSlot* ps = (const ProbeSlot*)op.p0;
-      const long long s1 = ctx->step + 1;
+      const long long s1 = ctx->step + sub + 1;
       if (s1 % ps->every == 0) {
         const long long slot = s1 / ps->every - 1 - ps->base_slot;
         if (slot >= 0 && slot < ps->capacity) {
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void k_round(RoundArgs<T> ra) {
   switch (e.kind) {
     case RK_GLUE: {
       const GlueBlock g = ((const GlueBlock*)e.args)[vb];
-      glue_body<T>(ra.mops[g.op], g.chunk, ra.sig, ra.ctx);
+      glue_body<T>(ra.mops[g.op], g.chunk & 0xffffff, g.chunk >> 24, ra.sig, ra.ctx);
       break;
     }
     case RK_GATE: gate_body<T>(*(const MicroOp<T>*)e.args, ra.sig, ssn_round_smem); break;
@@ -243,6 +246,9 @@ __global__ __launch_bounds__(256) void k_round(RoundArgs<T> ra) {
     case RK_DFT:
       if constexpr (sizeof(T) == 4) dft_body(*(const DftArgs*)e.args, ssn_round_smem);
       break;
+    case RK_ENS_3_4_S: ens_body<T, 3, 4, 1>(*(const EnsArgs<T>*)e.args, bx, ssn_round_smem); break;
+    case RK_ENS_3_5_S: ens_body<T, 3, 5, 1>(*(const EnsArgs<T>*)e.args, bx, ssn_round_smem); break;
+    case RK_ENS_1_1_D: ens_body<T, 1, 1, 2>(*(const EnsArgs<T>*)e.args, bx, ssn_round_smem); break;
     case RK_PES: pes_body<T>(*(const PesArgs<T>*)e.args, bx, by); break;
     case RK_VOJA: voja_body<T>(*(const VojaArgs<T>*)e.args, bx); break;
     default: break;

@@ -12,7 +12,7 @@ for net, probes in tp._gridcell_models():
     ref = OracleSimulator(model); ref.run_steps(300)
     idx = {id(p["probe"]): i for i, p in enumerate(model.probes)}
     want = ref.probe_data(idx[id(probes[0])])
-    for fl in (0, 2097152):
+    for fl in (0, 8388608, 2097152, 0, 8388608, 2097152):
         with Simulator(None, model=model, dtype="f32", flags=fl) as sim:
             sim.run_steps(300)
             ce = H.cosine_error(sim.data[probes[0]][20:], want[20:])
