@@ -173,6 +173,12 @@ struct Sim final : ssn_sim {
   std::vector<Launch> graph_list;             // steps_per_graph timesteps, software-pipelined (empty: replay launch_list)
   int graph_rounds = 0;
   std::vector<void*> round_bufs;
+  // persistent variant of the pipelined sequence (k_rounds): all its rounds in one resident grid
+  ssn::RoundArgs<T>* d_persist_rounds = nullptr;
+  int* d_persist_blocks = nullptr;
+  ssn::PersistCtl* d_persist_ctl = nullptr;
+  int persist_rounds = 0, persist_grid = 0;
+  size_t persist_lds = 0;
   std::vector<hipStream_t> side_streams;
   std::vector<hipEvent_t> dag_events;
   ssn::StepCtx* d_ctx = nullptr;
@@ -1387,15 +1393,170 @@ struct Sim final : ssn_sim {
   static bool glue_row_kind(int k) {
     return k == ssn::M_MATVEC_INC || k == ssn::M_MATVEC_SET || k == ssn::M_ENS_FINISH || k == ssn::M_REDUCE_SET || k == ssn::M_REDUCE_INC;
   }
+
+  // k_round body of an ensemble array (-1: its variant has none, it is launched on its own)
+  int ens_round_kind(const ssn::EnsArgs<T>& a) const {
+    if (a.defer || a.xrows || (flags & 4194304)) return -1;
+    if (a.fast == 1 && a.din == 3 && a.dout == 4) return ssn::RK_ENS_3_4_S;
+    if (a.fast == 1 && a.din == 3 && a.dout == 5) return ssn::RK_ENS_3_5_S;
+    if (a.fast == 2 && a.din == 1 && a.dout == 1) return ssn::RK_ENS_1_1_D;
+    return -1;
+  }
+
+  // Cost model of the round balancer: device time a unit needs when bandwidth-bound (us at ~5 TB/s), the latency of a
+  // single-workgroup unit (us), and the number of blocks of its grid (0: not splittable).
+  void unit_cost(int mop, int item, double* us, double* lat, int* blocks) const {
+    *us = 0.0; *lat = 0.0; *blocks = 0;
+    const double per_us = 5.0e6;      // bytes per microsecond
+    if (mop >= 0) {
+      const MOp& op = mops[(size_t)mop];
+      if (op.kind == ssn::M_GATE || op.kind == ssn::M_ARGMAX_GATHER) *lat = 3.0;
+      else *us = (double)op.len * 3.0 * sizeof(T) / per_us;
+      return;
+    }
+    const Item& it = items[(size_t)item];
+    switch (it.type) {
+      case IT_ENS:
+        *us = (double)it.ens.K * it.ens.n_pad * (it.ens.din + 4.5) * sizeof(T) / per_us;
+        if (ens_round_kind(it.ens) >= 0) *blocks = it.ens.K * it.ens.P;
+        break;
+      case IT_MATVEC:
+        *us = (double)it.rows * it.ld * sizeof(T) / per_us;
+        if ((size_t)it.cols * sizeof(T) <= 48 * 1024) *blocks = it.rows <= 4096 ? (it.rows + 3) / 4 : (it.rows + 15) / 16;
+        break;
+      case IT_PES: *us = 2.0 * it.rows * it.ld * sizeof(T) / per_us; *blocks = ((it.cols + 1023) / 1024) * it.rows; break;
+      case IT_VOJA: *us = 0.2 * it.rows * it.ld * sizeof(T) / per_us; break;
+      case IT_SPMV: *us = 0.1 * (double)it.cols * it.ld * sizeof(T) / per_us; break;
+      case IT_NEURONS: *us = (double)it.n * 5.0 * sizeof(T) / per_us; break;
+      case IT_DFT: *lat = 9.0; break;
+      default: *us = 1.0; break;
+    }
+  }
+
+  // Round balancer of the pipelined plan.  The earliest-round assignment stacks the bandwidth-bound operators of a
+  // timestep in a few rounds and leaves others with one latency-bound workgroup (a DFT) and an idle chip.  Every block of
+  // a grid is independent, so a heavy operator may run in pieces: any round from its own up to the last one before its
+  // first conflicting successor is valid for any of its blocks (successors were placed later than that, predecessors
+  // earlier; pieces only ever move later, which keeps every other window valid).  Heavy instances are poured, a
+  // thirty-second at a time, into the round of their window where the quantum costs least (free under a latency-bound
+  // round's critical workgroup; otherwise the least loaded).
+  template <typename Inst, typename H, typename C>
+  void balance_rounds(std::vector<Inst>& all, int nr, size_t per, H conflict, C cost) {
+    const size_t N = all.size();
+    std::vector<double> load((size_t)nr, 0.0), lat((size_t)nr, 0.0);
+    std::vector<double> us(N, 0.0);
+    std::vector<int> blocks(N, 0);
+    for (size_t i = 0; i < N; ++i) {
+      double l = 0.0;
+      cost(all[i].unit, &us[i], &l, &blocks[i]);
+      load[(size_t)all[i].round] += us[i];
+      lat[(size_t)all[i].round] = std::max(lat[(size_t)all[i].round], l);
+    }
+    std::vector<Inst> extra;
+    for (size_t i = 0; i < N; ++i) {
+      if (us[i] < 4.0 || blocks[i] < 64) continue;            // heavy: >= ~20 MB
+      const int r0 = all[i].round;
+      int r1 = nr - 1;
+      const size_t stop = std::min(N, ((size_t)all[i].sub + 2) * per);
+      for (size_t j = i + 1; j < stop; ++j)
+        if (all[j].round - 1 < r1 && conflict(all[i].unit, all[j].unit)) r1 = all[j].round - 1;
+      if (r1 <= r0) continue;
+      load[(size_t)r0] -= us[i];
+      const int Q = 32;
+      const double q = us[i] / Q;
+      std::vector<int> share((size_t)(r1 - r0 + 1), 0);
+      for (int k = 0; k < Q; ++k) {
+        int best = r0;
+        double best_cost = 1e30, best_load = 1e30;
+        for (int r = r0; r <= r1; ++r) {
+          const double before = std::max(load[(size_t)r], lat[(size_t)r]), after = std::max(load[(size_t)r] + q, lat[(size_t)r]);
+          const double c = after - before;
+          if (c < best_cost - 1e-9 || (c < best_cost + 1e-9 && load[(size_t)r] < best_load)) { best = r; best_cost = c; best_load = load[(size_t)r]; }
+        }
+        share[(size_t)(best - r0)] += 1;
+        load[(size_t)best] += q;
+      }
+      int lo = 0, used = 0;
+      bool first = true;
+      for (int r = r0; r <= r1; ++r) {
+        const int sh = share[(size_t)(r - r0)];
+        if (!sh) continue;
+        used += sh;
+        const int hi = used == Q ? blocks[i] : (int)((long long)blocks[i] * used / Q);
+        if (hi <= lo) continue;
+        if (first) { all[i].round = r; all[i].lo = lo; all[i].cnt = hi - lo; first = false; }
+        else { Inst p = all[i]; p.round = r; p.lo = lo; p.cnt = hi - lo; extra.push_back(p); }
+        lo = hi;
+      }
+    }
+    all.insert(all.end(), extra.begin(), extra.end());
+  }
+
   int build_rounds(const std::vector<std::vector<MOp>>& programs, const std::vector<int>& item_prog) {
     struct Unit { int mop = -1; int item = -1; int phase = 0; bool writes = false; std::vector<Rng> acc; };
     std::vector<Unit> units;
     mops.clear();
+    // Element-wise micro-operators are cut at every range endpoint of the other operators.  The builder merges
+    // neighbouring resets / hand-offs into one long operator (one fill over all accumulators of a network); as a unit
+    // it would inherit the hazards of every signal it spans - the reset of an accumulator that is read in the last
+    // round of step s would hold back the whole head of step s + 1.
+    std::vector<int64_t> cuts;
+    {
+      std::vector<Rng> all_acc;
+      int pj = 0;
+      for (size_t i = 0; i < items.size(); ++i) {
+        if (items[i].type == IT_PROGRAM) { for (const MOp& op : programs[(size_t)item_prog[(size_t)pj]]) micro_access(all_acc, op, false); ++pj; }
+        else item_access(all_acc, items[i]);
+      }
+      for (const Rng& r : all_acc) if (r.space == (const void*)sig) { cuts.push_back(r.lo); cuts.push_back(r.hi); }
+      std::sort(cuts.begin(), cuts.end());
+      cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    }
+    auto split_micro = [&](const MOp& op, std::vector<MOp>& out) -> int {
+      const bool ew = op.kind == ssn::M_FILL || op.kind == ssn::M_AXPY_INC || op.kind == ssn::M_AXPY_SET || op.kind == ssn::M_LOWPASS ||
+                      op.kind == ssn::M_LINCOMB || op.kind == ssn::M_ROW_IN || op.kind == ssn::M_ROW_OUT;
+      if (!ew || op.len <= 1 || (flags & 33554432)) { out.push_back(op); return SSN_OK; }
+      std::vector<int64_t> bases;                       // signal-space origins of the operator's operands
+      if (op.kind != ssn::M_ROW_OUT) bases.push_back(op.dst);
+      if (op.kind == ssn::M_AXPY_INC || op.kind == ssn::M_AXPY_SET || op.kind == ssn::M_LOWPASS || op.kind == ssn::M_ROW_OUT) bases.push_back(op.src);
+      const std::vector<ssn::LinTerm<T>>* terms = nullptr;
+      if (op.kind == ssn::M_LINCOMB) { auto f = lin_terms.find(op.p0); if (f != lin_terms.end()) { terms = &f->second; for (auto& t : *terms) bases.push_back(t.src); } }
+      std::vector<int64_t> offs{0, op.len};
+      for (int64_t b : bases) {
+        auto lo = std::upper_bound(cuts.begin(), cuts.end(), b), hi = std::lower_bound(cuts.begin(), cuts.end(), b + op.len);
+        for (auto it = lo; it < hi; ++it) offs.push_back(*it - b);
+      }
+      std::sort(offs.begin(), offs.end());
+      offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+      if (offs.size() > 64) { out.push_back(op); return SSN_OK; }       // (pathological fragmentation: keep the operator whole)
+      for (size_t q = 0; q + 1 < offs.size(); ++q) {
+        const int64_t o = offs[q];
+        MOp pc = op;
+        pc.len = offs[q + 1] - o;
+        pc.dst = op.dst + o;
+        if (op.kind == ssn::M_AXPY_INC || op.kind == ssn::M_AXPY_SET || op.kind == ssn::M_LOWPASS || op.kind == ssn::M_ROW_OUT) pc.src = op.src + o;
+        if (op.kind == ssn::M_ROW_IN || op.kind == ssn::M_ROW_OUT) pc.i1 = op.i1 + o;
+        if (terms && o != 0) {
+          std::vector<ssn::LinTerm<T>> tt = *terms;
+          for (auto& t : tt) t.src += o;
+          ssn::LinTerm<T>* d_terms = nullptr;
+          CHK(dmalloc(&d_terms, (int64_t)std::max<size_t>(1, tt.size()) * (int64_t)sizeof(ssn::LinTerm<T>)));
+          scratch_bufs.push_back(d_terms);
+          if (!tt.empty()) HIPCHK(hipMemcpy(d_terms, tt.data(), tt.size() * sizeof(ssn::LinTerm<T>), hipMemcpyHostToDevice));
+          lin_terms[(const void*)d_terms] = tt;
+          pc.p0 = d_terms;
+        }
+        out.push_back(pc);
+      }
+      return SSN_OK;
+    };
     int prog_i = 0;
     for (size_t i = 0; i < items.size(); ++i) {
       const Item& it = items[i];
       if (it.type == IT_PROGRAM) {
-        for (const MOp& op0 : programs[(size_t)item_prog[(size_t)prog_i]]) {
+        std::vector<MOp> pieces;
+        for (const MOp& op0 : programs[(size_t)item_prog[(size_t)prog_i]]) CHK(split_micro(op0, pieces));
+        for (const MOp& op0 : pieces) {
           MOp op = op0;
           op.barrier = 0;
           Unit u; u.mop = (int)mops.size(); u.phase = std::max(0, it.phase);
@@ -1423,7 +1584,7 @@ struct Sim final : ssn_sim {
     round_launches.clear();
 
     // One instance of a unit: (unit, timestep offset inside the launch sequence, round).
-    struct Inst { int unit; int sub; int round; };
+    struct Inst { int unit; int sub; int round; int lo = 0; int cnt = -1; };      // blocks [lo, lo + cnt) of the unit's grid (cnt < 0: all)
     // Launch sequence of a set of instances grouped by round (instances of one round are mutually independent).
     auto emit = [&](const std::vector<Inst>& insts, int n_rounds, std::vector<Launch>& out) {
       std::vector<std::vector<const Inst*>> by_round((size_t)n_rounds);
@@ -1442,16 +1603,37 @@ struct Sim final : ssn_sim {
           out.push_back(l);
           rl.args.n = 0; rl.n_blocks = 0; rl.lds = 0;
         };
+        int part_lo = 0, part_cnt = -1;      // block range of the instance being emitted (set per instance below)
+        // The grid's blocks are dispatched in order: single-workgroup bodies whose latency bounds the round (a DFT: ~9 us)
+        // go first so that they run beside the bandwidth-bound blocks instead of behind them; then the small glue; then
+        // the big grids, longest first.
+        struct Pending { int kind, gx, gy, what, lo, cnt; size_t lds, off; };
+        std::vector<Pending> pending;
         auto entry = [&](int kind, int gx, int gy, size_t lds, int what, size_t off) {
-          if (rl.args.n == ssn::MAX_ROUND_ENTRIES) close();
-          ssn::RoundEntry& e = rl.args.e[rl.args.n];
-          e.kind = kind; e.first = rl.n_blocks; e.gx = std::max(1, gx); e.gy = std::max(1, gy); e.args = nullptr;
-          fixes.push_back(Fix{round_launches.size(), rl.args.n, what, off});
-          rl.n_blocks += e.gx * e.gy;
-          rl.lds = std::max(rl.lds, lds);
-          rl.args.n += 1;
+          Pending q{kind, std::max(1, gx), std::max(1, gy), what, 0, 0, lds, off};
+          q.lo = part_cnt < 0 ? 0 : part_lo;
+          q.cnt = part_cnt < 0 ? q.gx * q.gy : std::min(part_cnt, q.gx * q.gy - q.lo);
+          pending.push_back(q);
+        };
+        auto flush_entries = [&]() {
+          auto prio = [](const Pending& q) { return q.kind == ssn::RK_DFT ? 0 : (q.kind == ssn::RK_GATE || q.kind == ssn::RK_ARGMAX) ? 1 : q.kind == ssn::RK_GLUE ? 2 : 3; };
+          std::stable_sort(pending.begin(), pending.end(), [&](const Pending& a, const Pending& b) {
+            if (prio(a) != prio(b)) return prio(a) < prio(b);
+            return prio(a) == 3 && a.cnt > b.cnt;
+          });
+          for (const Pending& q : pending) {
+            if (rl.args.n == ssn::MAX_ROUND_ENTRIES) close();
+            ssn::RoundEntry& e = rl.args.e[rl.args.n];
+            e.kind = q.kind; e.first = rl.n_blocks; e.gx = q.gx; e.gy = q.gy; e.args = nullptr; e.lo = q.lo; e.cnt = q.cnt;
+            fixes.push_back(Fix{round_launches.size(), rl.args.n, q.what, q.off});
+            rl.n_blocks += e.cnt;
+            rl.lds = std::max(rl.lds, q.lds);
+            rl.args.n += 1;
+          }
+          pending.clear();
         };
         // glue: one entry for all chunked micro-operators of the round
+        part_lo = 0; part_cnt = -1;
         const size_t map_begin = glue_map.size();
         for (const Inst* in : by_round[(size_t)r]) {
           const Unit& u = units[(size_t)in->unit];
@@ -1466,6 +1648,7 @@ struct Sim final : ssn_sim {
         if (glue_map.size() > map_begin) entry(ssn::RK_GLUE, (int)(glue_map.size() - map_begin), 1, 64, 1, map_begin);
         for (const Inst* in : by_round[(size_t)r]) {
           const Unit& u = units[(size_t)in->unit];
+          part_lo = in->lo; part_cnt = in->cnt;
           if (u.mop >= 0) {
             const MOp& op = mops[(size_t)u.mop];
             if (op.kind == ssn::M_GATE) entry(ssn::RK_GATE, 1, 1, 64, 2, (size_t)u.mop);
@@ -1487,11 +1670,8 @@ struct Sim final : ssn_sim {
               break;
             case IT_ENS: {
               const ssn::EnsArgs<T>& a = it.ens;
-              int kind = -1;
-              if (a.fast == 1 && a.din == 3 && a.dout == 4) kind = ssn::RK_ENS_3_4_S;
-              else if (a.fast == 1 && a.din == 3 && a.dout == 5) kind = ssn::RK_ENS_3_5_S;
-              else if (a.fast == 2 && a.din == 1 && a.dout == 1) kind = ssn::RK_ENS_1_1_D;
-              if (kind >= 0 && !a.defer && !a.xrows && !(flags & 4194304)) {
+              const int kind = ens_round_kind(a);
+              if (kind >= 0) {
                 if (ao < 0) ao = (long long)put(&a, sizeof a);
                 entry(kind, a.K * a.P, 1, 512, 0, (size_t)ao);
                 continue;
@@ -1541,6 +1721,7 @@ struct Sim final : ssn_sim {
           plain.push_back(l);
         }
         for (const Launch& l : plain) out.push_back(l);      // the plain launches first (ensemble arrays: the long ones), then the round's grid
+        flush_entries();
         close();
       }
     };
@@ -1554,7 +1735,7 @@ struct Sim final : ssn_sim {
       int r = in_phase1 ? phase1_base : 0;
       for (size_t v = 0; v < u; ++v)
         if (one[v].round >= r && hazard(units[u].acc, units[v].acc)) r = one[v].round + 1;
-      one.push_back(Inst{(int)u, 0, r});
+      one.push_back(Inst{(int)u, 0, r, 0, -1});
       n_rounds = std::max(n_rounds, r + 1);
     }
     launch_list.clear();
@@ -1590,9 +1771,27 @@ struct Sim final : ssn_sim {
           const size_t lo = st > 0 ? (size_t)(st - 1) * per : 0, hi = all.size();
           for (size_t v = lo; v < hi; ++v)
             if (all[v].round >= r && hazard(acc_nc[(size_t)u], acc_nc[(size_t)all[v].unit])) r = all[v].round + 1;
-          all.push_back(Inst{u, st, r});
+          all.push_back(Inst{u, st, r, 0, -1});
           nr = std::max(nr, r + 1);
         }
+      if (getenv("SSN_DEBUG_PLAN")) {
+        // the chain of binding hazards behind the last instance: what the steady-state period is made of
+        size_t cur = 0;
+        for (size_t i = 0; i < all.size(); ++i) if (all[i].round >= all[cur].round) cur = i;
+        fprintf(stderr, "[ssn] critical chain (backwards from the last round):\n");
+        for (int hop = 0; hop < 40 && all[cur].round > 0; ++hop) {
+          const Unit& u = units[(size_t)all[cur].unit];
+          if (u.mop >= 0) fprintf(stderr, "[ssn]   round %3d step %2d micro %d/%lld dst %lld\n", all[cur].round, all[cur].sub, mops[(size_t)u.mop].kind, (long long)mops[(size_t)u.mop].len, (long long)mops[(size_t)u.mop].dst);
+          else fprintf(stderr, "[ssn]   round %3d step %2d item %d type %d rows %d cols %d\n", all[cur].round, all[cur].sub, u.item, items[(size_t)u.item].type, items[(size_t)u.item].rows, items[(size_t)u.item].cols);
+          size_t prev = cur;
+          for (size_t v = cur; v-- > 0;)
+            if (all[v].round == all[cur].round - 1 && hazard(acc_nc[(size_t)all[cur].unit], acc_nc[(size_t)all[v].unit])) { prev = v; break; }
+          if (prev == cur) break;
+          cur = prev;
+        }
+      }
+      if (!(flags & 16777216)) balance_rounds(all, nr, per, [&](int a, int b) { return hazard(acc_nc[(size_t)a], acc_nc[(size_t)b]); },
+                                              [&](int u, double* us, double* lat, int* blocks) { unit_cost(units[(size_t)u].mop, units[(size_t)u].item, us, lat, blocks); });
       emit(all, nr, graph_list);
       graph_rounds = nr;
       launches_per_step = ((int)graph_list.size() + G - 1) / G;       // (average of the replayed sequence)
@@ -1611,7 +1810,40 @@ struct Sim final : ssn_sim {
       else if (f.what == 1) e.args = d_map + f.off;
       else e.args = d_mops + f.off;
     }
+    // persistent grid for the pipelined sequence, when every launch of it is a round
+    persist_rounds = 0;
+    bool all_rounds = !graph_list.empty();
+    for (const Launch& l : graph_list) all_rounds = all_rounds && l.rl >= 0;
+    if (all_rounds && graph_list.size() >= 2 && (flags & 67108864)) {      // opt-in: measured 411 vs 142 us per timestep at SLAM config 3
+      std::vector<ssn::RoundArgs<T>> ra;
+      std::vector<int> nb;
+      size_t lds = 64;
+      for (const Launch& l : graph_list) {
+        ra.push_back(round_launches[(size_t)l.rl].args);
+        nb.push_back(round_launches[(size_t)l.rl].n_blocks);
+        lds = std::max(lds, round_launches[(size_t)l.rl].lds);
+      }
+      int per_cu = 0, cus = 0;
+      HIPCHK(ssn::persistent_capacity<T>(lds, &per_cu));
+      HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+      const char* env_occ = getenv("SSN_PERSIST_WGS_PER_CU");
+      if (env_occ) per_cu = std::max(1, std::min(per_cu, atoi(env_occ)));
+      if (per_cu >= 1 && cus >= 8) {
+        CHK(dmalloc(&d_persist_rounds, (int64_t)(ra.size() * sizeof(ssn::RoundArgs<T>))));
+        round_bufs.push_back(d_persist_rounds);
+        CHK(dmalloc(&d_persist_blocks, (int64_t)(nb.size() * sizeof(int))));
+        round_bufs.push_back(d_persist_blocks);
+        CHK(dmalloc(&d_persist_ctl, (int64_t)ssn::PERSIST_CTL_BYTES));
+        round_bufs.push_back(d_persist_ctl);
+        HIPCHK(hipMemcpy(d_persist_rounds, ra.data(), ra.size() * sizeof(ssn::RoundArgs<T>), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_persist_blocks, nb.data(), nb.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(d_persist_ctl, 0, ssn::PERSIST_CTL_BYTES));
+        persist_rounds = (int)ra.size(); persist_grid = per_cu * cus; persist_lds = lds;
+        launches_per_step = 1;
+      }
+    }
     if (getenv("SSN_DEBUG_PLAN")) {
+      fprintf(stderr, "[ssn] persistent grid: %d rounds, %d workgroups, %zu B LDS\n", persist_rounds, persist_grid, persist_lds);
       fprintf(stderr, "[ssn] round plan: %zu units in %d rounds, %d launches per timestep; %d timesteps pipelined: %d rounds, %zu launches\n",
               units.size(), n_rounds, launches_unpipelined, G, graph_rounds, graph_list.size());
       for (const Launch& l : launch_list) {
@@ -1630,7 +1862,7 @@ struct Sim final : ssn_sim {
         if (l.rl < 0) { fprintf(stderr, "[ssn]   pipelined: plain item %d type %d\n", l.item, items[(size_t)l.item].type); continue; }
         const RoundLaunch& rl = round_launches[(size_t)l.rl];
         fprintf(stderr, "[ssn]   pipelined round %3d: %6d blocks, %5zu B LDS:", rl.round, rl.n_blocks, rl.lds);
-        for (int q = 0; q < rl.args.n; ++q) fprintf(stderr, " %d[%d]", rl.args.e[q].kind, rl.args.e[q].gx * rl.args.e[q].gy);
+        for (int q = 0; q < rl.args.n; ++q) fprintf(stderr, " %d[%d]", rl.args.e[q].kind, rl.args.e[q].cnt);
         fprintf(stderr, "\n");
       }
     }
@@ -1897,6 +2129,8 @@ struct Sim final : ssn_sim {
       return hipGetLastError();
     }
     if (round_mode) {
+      if (count == steps_per_graph && persist_rounds > 0)
+        return ssn::launch_rounds<T>(stream, d_persist_rounds, d_persist_blocks, persist_rounds, persist_grid, persist_lds, d_persist_ctl, d_ctx, (long long)count);
       if (count == steps_per_graph && !graph_list.empty()) {
         for (const Launch& l : graph_list) { hipError_t e = launch_one(l); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, (long long)count);
@@ -2141,7 +2375,21 @@ struct Sim final : ssn_sim {
         HIPCHK(hipGetLastError());
       } else if (profile == 2) {
         // every launch of every timestep between its own event pair (plain eager launches, no graph)
-        for (int64_t s = 0; s < B && round_mode; ++s)
+        int64_t s_piped = 0;
+        for (; round_mode && !graph_list.empty() && s_piped + steps_per_graph <= B; s_piped += steps_per_graph) {
+          // the pipelined sequence a step graph replays, launch by launch
+          for (const Launch& l : graph_list) {
+            HIPCHK(hipEventRecord(ev_pool[ev_used], stream));
+            HIPCHK(launch_one(l));
+            HIPCHK(hipEventRecord(ev_pool[ev_used + 1], stream));
+            ev_types.push_back(l.rl >= 0 ? (int)IT_ROUND : items[(size_t)l.item].type);
+            ev_items.push_back(l.rl >= 0 ? (int)items.size() + l.rl : l.item);
+            ev_used += 2;
+          }
+          hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, (long long)steps_per_graph);
+          HIPCHK(hipGetLastError());
+        }
+        for (int64_t s = s_piped; s < B && round_mode; ++s)
           for (const Launch& l : launch_list) {
             if (l.rl < 0 && items[(size_t)l.item].merged) continue;
             HIPCHK(hipEventRecord(ev_pool[ev_used], stream));
@@ -2241,6 +2489,12 @@ struct Sim final : ssn_sim {
     steps_done += n;
     ssn::StepCtx ctx;
     HIPCHK(hipMemcpy(&ctx, d_ctx, sizeof ctx, hipMemcpyDeviceToHost));
+    if (d_persist_ctl) {
+      int perr = 0;
+      HIPCHK(hipMemcpy(&perr, (const unsigned char*)d_persist_ctl + ssn::PERSIST_CTL_ERROR_OFFSET, sizeof perr, hipMemcpyDeviceToHost));
+      if (perr) return fail(SSN_EHIP, "a grid barrier of the persistent step kernel timed out (workgroups not co-resident?); results are invalid - "
+                                      "rerun without flag 67108864 (one launch per round)");
+    }
     if (ctx.step != steps_done) return fail(SSN_EHIP, "device step counter %lld != host %lld", (long long)ctx.step, (long long)steps_done);
     if (ctx.probe_overflow) return fail(SSN_EINVAL, "probe storage overflow: call ssn_reserve_probes before ssn_run_steps");
     return SSN_OK;

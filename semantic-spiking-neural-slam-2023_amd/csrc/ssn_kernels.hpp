@@ -887,6 +887,24 @@ __device__ __forceinline__ void matvec_body(const MatvecArgs<T>& ma, const int b
   T* xs = reinterpret_cast<T*>(ssn_mv_dyn);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = (bx * 4 + wave) * RW;
+  const bool active = r0 < rows;               // (a wave past the last row still takes part in the slab barriers)
+  const T* wr[RW];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) wr[q] = Wm + (size_t)min(r0 + q, rows - 1) * ld;
+  T s[RW];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) s[q] = T(0);
+  const int n_vec = cols / W;
+  // The first trip's row loads are issued before the source vector is staged: the stage (global -> LDS -> barrier,
+  // ~2 us) would otherwise pass with no matrix load in flight - a quarter of a 1015-column row's time.  (An all-zero
+  // source still skips the rest of the matrix.)
+  constexpr bool PRE = XLDS && RW > 1;
+  T w0[RW][W];
+  const bool have0 = PRE && active && lane < n_vec;
+  if (have0) {
+#pragma unroll
+    for (int q = 0; q < RW; ++q) *(vec*)w0[q] = *(const vec*)(wr[q] + (size_t)lane * W);
+  }
   if (XLDS) {
     int nz = 0;
     for (int c = threadIdx.x; c < cols; c += 256) {
@@ -900,16 +918,8 @@ __device__ __forceinline__ void matvec_body(const MatvecArgs<T>& ma, const int b
       return;
     }
   }
-  const bool active = r0 < rows;               // (a wave past the last row still takes part in the slab barriers)
-  const T* wr[RW];
-#pragma unroll
-  for (int q = 0; q < RW; ++q) wr[q] = Wm + (size_t)min(r0 + q, rows - 1) * ld;
-  T s[RW];
-#pragma unroll
-  for (int q = 0; q < RW; ++q) s[q] = T(0);
-  const int n_vec = cols / W;
-  auto accumulate = [&](int c0, int nv) {      // columns [c0, c0 + nv W) of the rows against xs[0, nv W)
-    for (int v = lane; v < nv; v += 64 * CU) {
+  auto accumulate = [&](int c0, int nv, int v_first) {      // columns [c0, c0 + nv W) of the rows against xs[0, nv W)
+    for (int v = v_first; v < nv; v += 64 * CU) {
       T w[RW][CU][W], xv[CU][W];
 #pragma unroll
       for (int u = 0; u < CU; ++u)
@@ -930,7 +940,15 @@ __device__ __forceinline__ void matvec_body(const MatvecArgs<T>& ma, const int b
   };
   if (XLDS) {
     if (!active) return;
-    accumulate(0, n_vec);
+    if (have0) {
+      T xv[W];
+      *(vec*)xv = *(const vec*)(xs + (size_t)lane * W);
+#pragma unroll
+      for (int q = 0; q < RW; ++q)
+#pragma unroll
+        for (int j = 0; j < W; ++j) s[q] += w0[q][j] * xv[j];
+    }
+    accumulate(0, n_vec, PRE ? lane + 64 : lane);
   } else {
     for (int c0 = 0; c0 < n_vec * W; c0 += SLAB) {
       const int cn = min(SLAB, n_vec * W - c0);
@@ -938,7 +956,7 @@ __device__ __forceinline__ void matvec_body(const MatvecArgs<T>& ma, const int b
       int nz = 0;
       for (int c = threadIdx.x; c < cn; c += 256) { const T v = sig_src[c0 + c]; xs[c] = v; nz |= (v != T(0)); }
       nz = __syncthreads_or(nz);
-      if (active && nz) accumulate(c0, cn / W);      // an all-zero slab adds nothing
+      if (active && nz) accumulate(c0, cn / W, lane);      // an all-zero slab adds nothing
     }
     if (!active) return;
   }
@@ -1660,6 +1678,8 @@ namespace ssn {
   template hipError_t launch_batch_elementwise<T>(hipStream_t, const BatchOpList<T>&);                      \
   template hipError_t launch_convert_in<T>(hipStream_t, const double*, T*, int64_t, int64_t, int64_t);      \
   template hipError_t launch_convert_out<T>(hipStream_t, const T*, double*, int64_t, int64_t, int64_t);      \
-  template hipError_t launch_round<T>(hipStream_t, const RoundArgs<T>&, int, size_t);
+  template hipError_t launch_round<T>(hipStream_t, const RoundArgs<T>&, int, size_t);                        \
+  template hipError_t persistent_capacity<T>(size_t, int*);                                                  \
+  template hipError_t launch_rounds<T>(hipStream_t, const RoundArgs<T>*, const int*, int, int, size_t, PersistCtl*, StepCtx*, long long);
 
 }  // namespace ssn

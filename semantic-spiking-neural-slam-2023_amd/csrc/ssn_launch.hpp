@@ -213,7 +213,7 @@ enum RoundKind {
   RK_ENS_3_4_S, RK_ENS_3_5_S, RK_ENS_1_1_D      // k_ensarray<din, dout, spike-sparse | dense decoders>
 };
 struct GlueBlock { int op; int chunk; };        // micro-operator index (into RoundArgs::mops); chunk of it (low 24 bits), timestep offset (high 8)
-struct RoundEntry { int kind; int first; int gx; int gy; const void* args; };
+struct RoundEntry { int kind; int first; int gx; int gy; const void* args; int lo; int cnt; };   // blocks [lo, lo + cnt) of the gx x gy grid
 constexpr int MAX_ROUND_ENTRIES = 96;
 template <typename T>
 struct RoundArgs {
@@ -225,6 +225,12 @@ struct RoundArgs {
   RoundEntry e[MAX_ROUND_ENTRIES];
 };
 template <typename T> hipError_t launch_round(hipStream_t, const RoundArgs<T>&, int n_blocks, size_t lds_bytes);
+struct PersistCtl;      // grid-barrier state of the persistent variant (ssn_round.hpp)
+template <typename T> hipError_t persistent_capacity(size_t lds_bytes, int* blocks_per_cu);
+template <typename T> hipError_t launch_rounds(hipStream_t, const RoundArgs<T>* rounds, const int* n_blocks, int n_rounds, int grid, size_t lds_bytes,
+                                               PersistCtl* ctl, StepCtx* ctx, long long steps);
+constexpr size_t PERSIST_CTL_BYTES = 9 * 32 * 4 + 16;
+constexpr size_t PERSIST_CTL_ERROR_OFFSET = 9 * 32 * 4;
 // elements (rows for the reductions) of a micro-operator that one block of a round handles
 constexpr int GLUE_CHUNK = 1024;
 constexpr int GLUE_ROWS = 256;

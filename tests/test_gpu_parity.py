@@ -382,23 +382,46 @@ def test_dft_kernel_matches_the_transform_matrices(Simulator):
 
 def test_slam_optin_plans_equal_default(Simulator):
     """The A/B switches of ssn_model_desc.flags select alternative plans of the same operators: same trajectory as the
-    default plan (f64; bit-equal where the summation order is the same)."""
+    default plan (f64; bit-equal where the summation order is the same).  Default: rounds (k_round), the 16 timesteps of a
+    step graph software-pipelined; 2097152 selects the round-1 plan (one launch per operator / per program)."""
     sm = _small_slam(weights_every=None)
     model = build(sm.model)
-    outs = {}
-    for flags in (0, 256, 1024, 4096, 8192, 65536, 131072, 262144, 1048576):
+    ref = OracleSimulator(model)
+    ref.run_steps(120)
+    OLD = 2097152
+    outs, launches = {}, {}
+    for flags in (0, 1024, 8192, 4194304, 8388608, 16777216, 33554432, 67108864,
+                  OLD, OLD | 256, OLD | 4096, OLD | 65536, OLD | 131072, OLD | 1048576, 262144):
         with Simulator(None, model=model, dtype="f64", flags=flags) as sim:
-            sim.run_steps(120)
+            sim.run_steps(120)             # 7 graph replays of 16 pipelined steps + 8 steps launched one round at a time
             outs[flags] = sim.data[sm.probe]
+            launches[flags] = sim.counters()["launches_per_step"]
+    np.testing.assert_allclose(outs[0], ref.probe_data(0), atol=1e-9, rtol=0)
     np.testing.assert_allclose(outs[1024], outs[0], atol=1e-12, rtol=0)   # spike list rebuilt in the product kernel: other chunking
-    for flags in (256,            # independent branches of a timestep forked over several streams inside the step graph
+    np.testing.assert_allclose(outs[8192], outs[0], atol=1e-12, rtol=0)   # finish operator vs direct write of one-workgroup ensembles
+    for flags in (4194304,        # ensemble arrays launched on their own vs as bodies of the round's grid
+                  8388608,        # one timestep's rounds at a time vs 16 timesteps software-pipelined
+                  16777216,       # no splitting of heavy operators over the rounds of their slack window
+                  33554432,       # merged element-wise operators kept whole vs cut at the other operators' range endpoints
+                  67108864,       # all rounds of a graph in one persistent grid with grid barriers
+                  262144):        # one launch per element-wise operator of the batched stages
+        np.testing.assert_array_equal(outs[flags], outs[0], err_msg=str(flags))
+    np.testing.assert_allclose(outs[OLD], outs[0], atol=1e-12, rtol=0)       # (the gate's dot product sums 16 wave partials there, 4 here)
+    for extra in (256,            # independent branches of a timestep forked over several streams inside the step graph
                   4096,           # one launch per operator vs batched neighbours
-                  8192,           # finish operator vs direct write of one-workgroup ensembles
                   65536,          # a barrier at every level change vs elided barriers
                   131072,         # head program kept whole vs its long first level run grid-wide
-                  262144,         # one launch per element-wise operator of the batched stages
                   1048576):       # programs left in operator order vs sunk into the next program
-        np.testing.assert_array_equal(outs[flags], outs[0], err_msg=str(flags))
+        np.testing.assert_array_equal(outs[OLD | extra], outs[OLD], err_msg=str(extra))
+    assert launches[0] < launches[8388608] < launches[OLD]
+    # f32 (the f64 clean-up product is an ordered kernel outside the round grid, so the persistent variant needs f32 to engage)
+    f32 = {}
+    for flags in (0, 67108864):
+        with Simulator(None, model=model, dtype="f32", flags=flags) as sim:
+            sim.run_steps(120)
+            f32[flags] = (sim.data[sm.probe], sim.counters()["launches_per_step"])
+    np.testing.assert_array_equal(f32[67108864][0], f32[0][0])
+    assert f32[67108864][1] == 1 and f32[0][1] > 1
 
 
 def test_feedforward_model_runs_fully_batched(Simulator):

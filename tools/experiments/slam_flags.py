@@ -6,20 +6,22 @@ from sspslam_amd import harness as H
 from sspslam_amd.builder import build
 from sspslam_amd.simulator import Simulator
 flag_sets = [int(x) for x in sys.argv[1:]] or [0, 256]
+SPG = [int(x) for x in os.environ.get("SSN_SPG", "0").split(",")]
 s = H.make_ssp_space(2, 1015)
 path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
 sm = H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=10000, mem_n_neurons=10150, circonv_n_neurons=100, view_rad=0.2)
 bm = build(sm.model, n_eval_points=4000)
-for fl in flag_sets:
-    sim = Simulator(None, model=bm, dtype="f32", flags=fl)
+for fl, spg in [(f, g) for f in flag_sets for g in SPG]:
+    sim = Simulator(None, model=bm, dtype="f32", flags=fl, steps_per_graph=spg)
     sim.prepare(1500)
     sim.run_steps(128, collect=False)
     t0 = time.perf_counter()
     sim.run_steps(512, collect=False)
     wall = time.perf_counter() - t0
     c = sim.counters()
-    print(f"flags {fl}: {1e6 * wall / 512:.1f} us/step, {c['launches_per_step']} launches", flush=True)
-    sim.run_steps(64, profile=2, collect=False)
-    kt = sim.kernel_times()
-    print("   ", {k: (n // 64, round(1e3 * ms / 64, 1)) for k, (n, ms) in sorted(kt.items(), key=lambda kv: -kv[1][1])}, flush=True)
+    print(f"flags {fl} spg {spg}: {1e6 * wall / 512:.1f} us/step, {c['launches_per_step']} launches", flush=True)
+    if os.environ.get("SSN_KT"):
+        sim.run_steps(64, profile=2, collect=False)
+        kt = sim.kernel_times()
+        print("   ", {k: (n // 64, round(1e3 * ms / 64, 1)) for k, (n, ms) in sorted(kt.items(), key=lambda kv: -kv[1][1])}, flush=True)
     sim.close()
