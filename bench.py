@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--slam-steps", type=int, default=512, help="timed timesteps of the SLAMNetwork leg (0 = skip the leg)")
     ap.add_argument("--slam-cpu-steps", type=int, default=20, help="timed oracle timesteps of the SLAM leg (after 10 warm-up)")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--plan", default="auto", choices=["auto", "block", "stream"],
+                    help="N > 1: plan of each rank's VCO shard - the whole-block kernel (one workgroup per VCO), one streaming launch "
+                         "per timestep (an ensemble over several workgroups), or whichever is faster at this shard size (timed on "
+                         "one block before the timed region, the slowest rank's time decides)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path with several ranks sharing one GPU (RCCL needs one GPU per rank)")
@@ -137,7 +141,9 @@ def slam_leg(args, H, build, Simulator, OracleSimulator, dt):
         out.update(value=round(args.slam_steps * dt / wall, 4), unit="sim-sec/wall-sec", timesteps_timed=args.slam_steps,
                    us_per_timestep=round(1e6 * wall / args.slam_steps, 2), launches_per_timestep=c["launches_per_step"],
                    device_us_per_timestep=round(1e3 * c["last_run_ms"] / args.slam_steps, 2))
-        sim.run_steps(64, profile=2, collect=False)            # per-kernel device time: eager launches between event pairs
+        out["plan"] = ("rounds: every operator in the earliest round its data hazards allow, one heterogeneous grid (k_round) per "
+                       "round; the 16 timesteps of a step graph software-pipelined")
+        sim.run_steps(64, profile=2, collect=False)            # device time of the pipelined sequence, launch by launch (eager, event pairs)
         kt = sim.kernel_times()
         out["kernels_us_per_timestep"] = {nm: {"launches_per_timestep": round(n / 64, 2), "us": round(1e3 * ms / 64, 2)}
                                           for nm, (n, ms) in sorted(kt.items(), key=lambda kv: -kv[1][1])}
@@ -158,6 +164,19 @@ def slam_leg(args, H, build, Simulator, OracleSimulator, dt):
             out["parity"] = {"window_timesteps": k, "max_cosine_error": float(ce.max()),
                              "max_abs_diff": float(np.abs(got[:k] - want[:k]).max()), "bar": 1e-3}
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    # the same model under the per-operator plan (flag 2097152: one launch per big operator, k_program for the small ones):
+    # its event pairs give the device time per kernel, which the round grid does not separate
+    with Simulator(None, model=model, dtype="f32", flags=2097152) as sim:
+        sim.prepare(64 + 128 + 64)
+        sim.run_steps(64, collect=False)
+        t0 = time.perf_counter()
+        sim.run_steps(128, collect=False)
+        wall = time.perf_counter() - t0
+        sim.run_steps(64, profile=2, collect=False)
+        kt = sim.kernel_times()
+        out["per_operator_plan"] = {"us_per_timestep": round(1e6 * wall / 128, 2), "launches_per_timestep": sim.counters()["launches_per_step"],
+                                    "kernels_us_per_timestep": {nm: {"launches_per_timestep": round(n / 64, 2), "us": round(1e3 * ms / 64, 2)}
+                                                                for nm, (n, ms) in sorted(kt.items(), key=lambda kv: -kv[1][1])}}
     return out
 
 
@@ -217,9 +236,13 @@ def main():
         for turn in range(world if shared else 1):
             if not shared or turn == rank:
                 runner = ShardedPathIntegration(pm, rank, world, dt=dt, dtype=args.dtype, device=local_rank,
-                                                n_eval_points=args.eval_points, block=args.block, block_steps=args.sim_block)
+                                                n_eval_points=args.eval_points, block=args.block, block_steps=args.sim_block,
+                                                flags=128 if args.plan == "stream" else 0)
             if shared:
                 dist.barrier()
+        plan_seconds = None
+        if args.plan == "auto":
+            plan_seconds = runner.choose_plan((0, 128), steps=args.block)      # collective; outside the timed region
         sim, model = runner.sim, runner.model
     build_s = time.time() - t0
 
@@ -268,6 +291,10 @@ def main():
                    "build_seconds": round(build_s, 1)},
     }
 
+    if world > 1:
+        out["config"]["shard_plan"] = {"chosen": "streaming launch per timestep (flag 128)" if runner._flags == 128 else "planner default (k_ens_block where a VCO fits a workgroup)",
+                                       "vcos_per_rank": runner.hi - runner.lo,
+                                       "seconds_per_block": {str(k): round(v, 6) for k, v in (plan_seconds or {}).items()}}
     if rank == 0 and world == 1:
         # ---- roofline: HIP events around every launch of the dominant kernel in the timed region ------
         c = sim.counters()

@@ -111,7 +111,7 @@ typedef struct ssn_model_desc {
   int32_t n_buffers;
   int32_t n_ops;
   int32_t n_probes;
-  int32_t steps_per_graph;            /* timesteps captured per hipGraph; 0 = library default (16), 1 = no graph */
+  int32_t steps_per_graph;            /* timesteps captured per hipGraph (at most 64); 0 = library default (16), 1 = no graph */
   const ssn_buffer_desc* buffers;
   const ssn_op_desc* ops;
   const ssn_probe_desc* probes;
@@ -152,6 +152,20 @@ typedef struct ssn_model_desc {
                                          524288 = clean-up similarities always from the pass over the table (no factored grid),
                                          1048576 = programs stay where the operator order put them (no sinking of a program
                                               into the next one past operators that do not depend on it).
+                                         2097152 = no rounds: one launch per big operator and one k_program launch per run of
+                                              small ones (the round-1 plan; flags 256, 4096, 65536, 131072 and 1048576 only act
+                                              together with this one).  Default: every operator takes the earliest round its data
+                                              hazards allow and a round is ONE heterogeneous grid (k_round),
+                                         4194304 = ensemble arrays are launched on their own, not as bodies of the round's grid,
+                                         8388608 = the rounds of one timestep at a time (default: the steps_per_graph timesteps of a
+                                              step graph are software-pipelined - an operator of step s + 1 may share a round with
+                                              operators of step s),
+                                         16777216 = heavy operators stay whole (default: the pipelined plan may run the blocks of a
+                                              bandwidth-bound operator in pieces over the rounds of its slack window),
+                                         33554432 = merged element-wise operators stay whole (default: cut at the range endpoints of
+                                              the other operators, so that each piece has its own hazards),
+                                         67108864 = all rounds of a step graph in one persistent grid with grid barriers (k_rounds;
+                                              measured 3x slower than one launch per round, DESIGN.md - opt-in).
                                          (Round 1's opt-in experiments 32, 64, 2048, 16384, 32768 - all measured slower - were removed.) */
 } ssn_model_desc;
 

@@ -52,8 +52,9 @@ class _BlockFeed:
 class ShardedPathIntegration:
     def __init__(self, pm, rank, world, dt=0.001, dtype="f32", device=0, n_eval_points=None, block=1000,
                  sim_factory=None, dist=None, gather_device=None, async_readout=True, block_steps=0,
-                 device_exchange=None, defer_readout=None, gather_every=4):
-        """``pm``: object from ``harness.make_pathint_model`` (model, pathintegrator, probe)."""
+                 device_exchange=None, defer_readout=None, gather_every=4, flags=0):
+        """``pm``: object from ``harness.make_pathint_model`` (model, pathintegrator, probe).  ``flags``: plan switches
+        of the shard's simulator (``ssn_model_desc.flags``; see ``choose_plan``)."""
         if dist is None:
             import torch.distributed as dist
         self.dist, self.rank, self.world, self.dt, self.block = dist, rank, world, dt, int(block)
@@ -64,8 +65,9 @@ class ShardedPathIntegration:
         if sim_factory is None:
             from .simulator import Simulator
 
-            def sim_factory(model):
-                return Simulator(None, model=model, dtype=dtype, device=device, block_steps=block_steps)
+            def sim_factory(model, flags=flags):
+                return Simulator(None, model=model, dtype=dtype, device=device, block_steps=block_steps, flags=flags)
+        self._sim_factory, self._flags = sim_factory, flags
         self.gather_device = gather_device
         self.dtype = dtype
         self.device_exchange = device_exchange     # None: automatic (RCCL backend + HIP simulator); True/False: forced
@@ -118,6 +120,42 @@ class ShardedPathIntegration:
             self._worker = threading.Thread(target=self._readout_loop, daemon=True)
             self._worker.start()
         self._warm = False
+
+    def choose_plan(self, candidates=(0, 128), steps=None):
+        """Time one block of this rank's shard under each candidate plan (simulator flags: 0 = the planner's choice -
+        the whole-block kernel k_ens_block where a VCO fits one workgroup; 128 = one k_ensarray launch per timestep,
+        which splits an ensemble over several workgroups and so fills the chip when a shard has fewer VCOs than the GPU
+        has CUs) and keep the fastest.  Decided collectively - the slowest rank's time counts - so every rank must call
+        it, before ``prepare``.  Returns {flags: seconds per block}."""
+        import time
+        steps = int(steps or self.block)
+        sims, seconds = {self._flags: self.sim}, {}
+        for fl in candidates:
+            if fl not in sims:
+                sims[fl] = self._sim_factory(self.model, flags=fl)
+            sim = sims[fl]
+            sim.prepare(2 * steps)
+            sim.run_steps(steps, collect=False)
+            t0 = time.perf_counter()
+            sim.run_steps(steps, collect=False)
+            wall = time.perf_counter() - t0
+            if self.world > 1 and self.dist.is_initialized():
+                import torch
+                t = torch.tensor([wall], dtype=torch.float64)
+                if self.dist.get_backend() == "nccl":
+                    t = t.cuda()
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                wall = float(t.item())
+            seconds[fl] = wall
+            sim.reset()
+            if hasattr(sim, "clear_probe_data"):
+                sim.clear_probe_data()
+        best = min(seconds, key=seconds.get)
+        for fl, sim in sims.items():
+            if fl != best and hasattr(sim, "close"):
+                sim.close()
+        self.sim, self._flags = sims[best], best
+        return seconds
 
     def prepare(self, n_steps):
         self.sim.prepare(n_steps)

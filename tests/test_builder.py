@@ -198,3 +198,32 @@ def test_cleanup_operator_carries_the_grid_factors():
         op = next(o for o in net(native).ops if o["kind"] == "cleanup")
         assert "g_dft" not in op and op["cols"] == 55
 
+
+
+def test_glue_collapse_keeps_the_trajectory_and_cuts_the_levels():
+    """builder.collapse (glue.py): chains of fill / axpy / copy operators between the big operators of the per-timestep
+    core are folded into lincomb operators.  Same trajectory, decoders and encoders as the uncollapsed list (the oracle
+    executes both; sums are re-associated, so equal to rounding), fewer dependency levels, and no axpy left that reads
+    an accumulator only glue wrote."""
+    from sspslam_amd import harness as H
+    from oracle import OracleSimulator
+    s = H.make_ssp_space(2, 55)
+    path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
+    res = {}
+    for collapse in (False, True):
+        sm = H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=60, mem_n_neurons=120, circonv_n_neurons=30, view_rad=0.6)
+        m = build(sm.model, collapse=collapse)
+        core = [o for o in m.ops if o["stage"] == 1]
+        sim = OracleSimulator(m)
+        sim.run_steps(150)
+        am = sm.slam.assomemory
+        res[collapse] = (sim.probe_data(0), sim.buf[m.params[am.conn_out].learned_buffer].copy(),
+                         sim.buf[m.params[am.memory].encoder_buffer].copy(), len({o["level"] for o in core}), core, m.stats)
+    np.testing.assert_allclose(res[True][0], res[False][0], atol=1e-12, rtol=0)
+    np.testing.assert_allclose(res[True][1], res[False][1], atol=1e-14, rtol=1e-10)
+    np.testing.assert_allclose(res[True][2], res[False][2], atol=1e-13, rtol=1e-10)
+    assert np.abs(res[True][1]).max() > 0
+    assert res[True][3] <= res[False][3] - 5, (res[True][3], res[False][3])
+    assert any(o["kind"] == "lincomb" for o in res[True][4]) and not any(o["kind"] == "lincomb" for o in res[False][4])
+    st = res[True][5]
+    assert st["glue_inlined_segments"] > 0 and st["glue_glue_out"] < st["glue_glue_in"]
