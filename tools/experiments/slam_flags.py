@@ -7,11 +7,15 @@ from sspslam_amd.builder import build
 from sspslam_amd.simulator import Simulator
 flag_sets = [int(x) for x in sys.argv[1:]] or [0, 256]
 SPG = [int(x) for x in os.environ.get("SSN_SPG", "0").split(",")]
+SWEEPS = [x for x in os.environ.get("SSN_SWEEPS", "").split(",")]
 s = H.make_ssp_space(2, 1015)
 path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
 sm = H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=10000, mem_n_neurons=10150, circonv_n_neurons=100, view_rad=0.2)
 bm = build(sm.model, n_eval_points=4000)
-for fl, spg in [(f, g) for f in flag_sets for g in SPG]:
+for fl, spg, sw in [(f, g, w) for f in flag_sets for g in SPG for w in SWEEPS]:
+    os.environ.pop("SSN_ENS_SWEEPS", None)
+    if sw:
+        os.environ["SSN_ENS_SWEEPS"] = sw
     sim = Simulator(None, model=bm, dtype="f32", flags=fl, steps_per_graph=spg)
     sim.prepare(1500)
     sim.run_steps(128, collect=False)
@@ -19,7 +23,7 @@ for fl, spg in [(f, g) for f in flag_sets for g in SPG]:
     sim.run_steps(512, collect=False)
     wall = time.perf_counter() - t0
     c = sim.counters()
-    print(f"flags {fl} spg {spg}: {1e6 * wall / 512:.1f} us/step, {c['launches_per_step']} launches", flush=True)
+    print(f"flags {fl} spg {spg} sweeps {sw or '-'}: {1e6 * wall / 512:.1f} us/step, {c['launches_per_step']} launches", flush=True)
     if os.environ.get("SSN_KT"):
         sim.run_steps(64, profile=2, collect=False)
         kt = sim.kernel_times()
