@@ -564,7 +564,7 @@ template <typename T>
 hipError_t launch_dft(hipStream_t s, const DftBatch& b, int count) {
   int N = 0;
   for (int i = 0; i < count; ++i) N = std::max(N, b.a[i].M > 0 ? b.a[i].M : b.a[i].N);
-  const int threads = N >= 1024 ? 1024 : (N + 63) / 64 * 64;
+  const int threads = std::min(1024, std::max(64, ((N + 3) / 4 + 63) / 64 * 64));      // four output points per thread (dft_stockham)
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 6400 * 3 * (int)sizeof(float2));

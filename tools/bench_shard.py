@@ -1,6 +1,6 @@
 """Per-rank step time of the VCO-sharded path integrator, measured on one GPU: builds shard `rank` of `world`
 of the config-2 model and times its core (no exchange, no read-out).  usage: bench_shard.py world [flags...]
-A flag value >= 1000 means: flags 0 with SSN_BLOCK_CLUSTER = value - 1000 (workgroups per VCO)."""
+(flags: ssn_model_desc.flags, e.g. 0 = whole-block kernel, 128 = one streaming launch per timestep)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,7 +11,7 @@ from sspslam_amd.simulator import Simulator
 from sspslam_amd.sharding import shard_range
 
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-flag_list = [int(f) for f in sys.argv[2:]] or [0, 16]
+flag_list = [int(f) for f in sys.argv[2:]] or [0, 128]
 space = H.make_ssp_space(2, 1015)
 path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
 pm = H.make_pathint_model(space, path, vels, 10000, seed=0)
@@ -23,11 +23,7 @@ t0 = time.time()
 model = build(pm.model, n_eval_points=1000, vco_shard=(0, world), probes=[p], prune=True)
 print("shard 0/%d: VCOs [%d,%d) built in %.1fs" % (world, lo, hi, time.time() - t0), flush=True)
 for flags in flag_list:
-    os.environ.pop("SSN_BLOCK_CLUSTER", None)
-    if flags >= 1000:
-        os.environ["SSN_BLOCK_CLUSTER"] = str(flags - 1000)
     tag = flags
-    flags = 0 if flags >= 1000 else flags
     sim = Simulator(None, model=model, dtype="f32", flags=flags)
     sim.prepare(6000)
     sim.run_steps(1000, collect=False)
