@@ -165,7 +165,12 @@ typedef struct ssn_model_desc {
                                          33554432 = merged element-wise operators stay whole (default: cut at the range endpoints of
                                               the other operators, so that each piece has its own hazards),
                                          67108864 = all rounds of a step graph in one persistent grid with grid barriers (k_rounds;
-                                              measured 3x slower than one launch per round, DESIGN.md - opt-in).
+                                              measured 3x slower than one launch per round, DESIGN.md - opt-in),
+                                         134217728 = no chains (default: an element-wise micro-operator whose only hazards inside a
+                                              round are on identical element ranges joins that round and runs behind its
+                                              predecessor in the same block),
+                                         268435456 = k_dft also for chirp-z (Bluestein) transforms of 2048 points and more
+                                              (default: their dense matrix - one workgroup needs 40 us for such a transform).
                                          (Round 1's opt-in experiments 32, 64, 2048, 16384, 32768 - all measured slower - were removed.) */
 } ssn_model_desc;
 

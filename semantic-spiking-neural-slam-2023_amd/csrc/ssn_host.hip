@@ -1033,7 +1033,10 @@ struct Sim final : ssn_sim {
         case SSN_OP_MATVEC: {
           const Buf& w = bufs[o.i[4]];
           ssn::DftArgs da{};
-          if (o.i[6] && sizeof(T) == 4 && !(flags & 512) && plan_dft(o, &da) == SSN_OK && da.N) {
+          // (a chirp-z transform of M >= 2048 points is three long FFTs on ONE workgroup - 40 us at d = 1801 - against
+          //  ~7 us for its 26 MB matrix spread over the chip: the matrix is used there unless flag 268435456 asks for the FFT)
+          if (o.i[6] && sizeof(T) == 4 && !(flags & 512) && plan_dft(o, &da) == SSN_OK && da.N &&
+              (da.M < 2048 || (flags & 268435456))) {
             // the matrix is a real-DFT map of a circular-convolution network: mixed-radix FFT instead of a GEMV
             flush();
             Item it; it.type = IT_DFT; it.dft = da;
@@ -1587,11 +1590,68 @@ struct Sim final : ssn_sim {
     round_launches.clear();
 
     // One instance of a unit: (unit, timestep offset inside the launch sequence, round).
-    struct Inst { int unit; int sub; int round; int lo = 0; int cnt = -1; };      // blocks [lo, lo + cnt) of the unit's grid (cnt < 0: all)
+    struct Inst { int unit; int sub; int round; int lo = 0; int cnt = -1; int chain = -1; };      // blocks [lo, lo + cnt) of the unit's grid (cnt < 0: all)
+    // Chains: an element-wise micro-operator whose only hazards inside a round are with other element-wise micro-operators
+    // on the SAME elements (equal ranges: a filter update behind the reduction it filters, the next step's input hand-off
+    // behind that update) joins their round - one block then runs the chain's operators back to back on 256 elements, the
+    // same thread on the same index in program order, with no barrier and no launch between them.
+    auto chainable = [&](const Unit& u) {
+      if (u.mop < 0 || (flags & 134217728)) return false;
+      switch (mops[(size_t)u.mop].kind) {
+        case ssn::M_FILL: case ssn::M_AXPY_INC: case ssn::M_AXPY_SET: case ssn::M_LOWPASS: case ssn::M_LINCOMB: case ssn::M_TABLE:
+        case ssn::M_ROW_IN: case ssn::M_ROW_OUT: case ssn::M_PROBE: case ssn::M_REDUCE_SET: case ssn::M_REDUCE_INC: return true;
+        default: return false;
+      }
+    };
+    // 0: no hazard, 1: hazards only on identical signal ranges (element-aligned), 2: any other hazard
+    auto conflict_kind = [&](const std::vector<Rng>& x, const std::vector<Rng>& y) {
+      int kind = 0;
+      for (const Rng& p : x)
+        for (const Rng& q : y)
+          if (p.space == q.space && p.lo < q.hi && q.lo < p.hi && (p.w || q.w)) {
+            if (p.space == (const void*)sig && p.lo == q.lo && p.hi == q.hi) kind = std::max(kind, 1);
+            else return 2;
+          }
+      return kind;
+    };
+    // round of a new instance given the instances it may conflict with; joins a chain where it can
+    auto place = [&](std::vector<Inst>& placed, size_t from, int unit, const std::vector<std::vector<Rng>>& accs, int base_round,
+                     std::vector<std::vector<int>>& chains) {
+      const Unit& uu = units[(size_t)unit];
+      const bool can = chainable(uu);
+      const long long len = can ? (long long)mops[(size_t)uu.mop].len : 0;
+      int r_hard = base_round, r_soft = -1;
+      std::vector<size_t> soft;
+      for (size_t v = from; v < placed.size(); ++v) {
+        if (placed[v].round < r_hard && placed[v].round < r_soft) continue;      // can neither raise a bound nor be a chain partner
+        const Unit& vv = units[(size_t)placed[v].unit];
+        const bool both = can && chainable(vv) && (long long)mops[(size_t)vv.mop].len == len;
+        const int k = both ? conflict_kind(accs[(size_t)unit], accs[(size_t)placed[v].unit])
+                           : (hazard(accs[(size_t)unit], accs[(size_t)placed[v].unit]) ? 2 : 0);
+        if (k == 2) r_hard = std::max(r_hard, placed[v].round + 1);
+        else if (k == 1) { r_soft = std::max(r_soft, placed[v].round); soft.push_back(v); }
+      }
+      Inst in{unit, 0, std::max(r_hard, r_soft), 0, -1, -1};
+      if (r_soft >= 0 && r_soft >= r_hard) {
+        int chain = -2;
+        for (size_t v : soft) {
+          if (placed[v].round != r_soft) continue;
+          if (placed[v].chain < 0) { placed[v].chain = (int)chains.size(); chains.push_back({(int)v}); }
+          if (chain == -2) chain = placed[v].chain;
+          else if (chain != placed[v].chain) chain = -3;
+        }
+        if (chain >= 0) { in.chain = chain; chains[(size_t)chain].push_back((int)placed.size()); }
+        else in.round = r_soft + 1;            // element-aligned with members of two chains: a round of its own
+      }
+      placed.push_back(in);
+      return in.round;
+    };
     // Launch sequence of a set of instances grouped by round (instances of one round are mutually independent).
-    auto emit = [&](const std::vector<Inst>& insts, int n_rounds, std::vector<Launch>& out) {
+    std::vector<int> chain_tab;
+    auto emit = [&](const std::vector<Inst>& insts, int n_rounds, std::vector<Launch>& out, const std::vector<std::vector<int>>& chains) {
       std::vector<std::vector<const Inst*>> by_round((size_t)n_rounds);
       for (const Inst& in : insts) by_round[(size_t)in.round].push_back(&in);
+      auto in_chain = [&](const Inst* in) { return in->chain >= 0 && chains[(size_t)in->chain].size() >= 2; };
       for (int r = 0; r < n_rounds; ++r) {
         RoundLaunch rl;
         rl.round = r;
@@ -1644,6 +1704,16 @@ struct Sim final : ssn_sim {
           if (u.mop < 0) continue;
           const MOp& op = mops[(size_t)u.mop];
           if (op.kind == ssn::M_GATE || op.kind == ssn::M_ARGMAX_GATHER) continue;
+          if (in_chain(in)) {
+            const std::vector<int>& members = chains[(size_t)in->chain];
+            if (&insts[(size_t)members[0]] != in) continue;                 // emitted with its chain's first member
+            const int ofs = (int)chain_tab.size();
+            chain_tab.push_back((int)members.size());
+            for (int mi : members) { chain_tab.push_back(units[(size_t)insts[(size_t)mi].unit].mop); chain_tab.push_back(insts[(size_t)mi].sub); }
+            const int blocks = (int)std::max<long long>(1, (op.len + ssn::GLUE_ROWS - 1) / ssn::GLUE_ROWS);
+            for (int c = 0; c < blocks; ++c) glue_map.push_back(ssn::GlueBlock{-(ofs + 1), c});
+            continue;
+          }
           const long long per = glue_row_kind(op.kind) ? ssn::GLUE_ROWS : ssn::GLUE_CHUNK;
           const int chunks = (int)std::max<long long>(1, (op.len + per - 1) / per);
           for (int c = 0; c < chunks; ++c) glue_map.push_back(ssn::GlueBlock{u.mop, c | (in->sub << 24)});
@@ -1733,16 +1803,24 @@ struct Sim final : ssn_sim {
     std::vector<Inst> one;
     int n_rounds = 0, phase1_base = 0;
     bool in_phase1 = false;
+    std::vector<std::vector<Rng>> acc_all(units.size());
+    for (size_t u = 0; u < units.size(); ++u) acc_all[u] = units[u].acc;
+    std::vector<std::vector<int>> chains_one;
+    size_t phase1_from = 0;
     for (size_t u = 0; u < units.size(); ++u) {
-      if (units[u].phase == 1 && !in_phase1) { in_phase1 = true; phase1_base = n_rounds; }
-      int r = in_phase1 ? phase1_base : 0;
-      for (size_t v = 0; v < u; ++v)
-        if (one[v].round >= r && hazard(units[u].acc, units[v].acc)) r = one[v].round + 1;
-      one.push_back(Inst{(int)u, 0, r, 0, -1});
+      if (units[u].phase == 1 && !in_phase1) { in_phase1 = true; phase1_base = n_rounds; phase1_from = one.size(); }
+      // (no chain across the exchange: a phase-1 instance only sees soft hazards with phase-1 instances; hard ones with all)
+      int r = place(one, 0, (int)u, acc_all, in_phase1 ? phase1_base : 0, chains_one);
+      if (in_phase1 && one.back().chain >= 0 && (size_t)chains_one[(size_t)one.back().chain][0] < phase1_from) {
+        // joined a chain that started before the exchange: undo, take the first round of phase 1 instead
+        chains_one[(size_t)one.back().chain].pop_back();
+        one.back().chain = -1; one.back().round = std::max(r, phase1_base);
+        r = one.back().round;
+      }
       n_rounds = std::max(n_rounds, r + 1);
     }
     launch_list.clear();
-    emit(one, n_rounds, launch_list);
+    emit(one, n_rounds, launch_list, chains_one);
     launches_per_step = (int)launch_list.size();
     const int launches_unpipelined = launches_per_step;
 
@@ -1764,17 +1842,16 @@ struct Sim final : ssn_sim {
       std::vector<std::vector<Rng>> acc_nc(units.size());     // access lists without the clock
       for (int u : keep) { if (units[(size_t)u].mop >= 0) micro_access(acc_nc[(size_t)u], mops[(size_t)units[(size_t)u].mop], false); else acc_nc[(size_t)u] = units[(size_t)u].acc; }
       std::vector<Inst> all;
+      std::vector<std::vector<int>> chains_all;
       all.reserve(keep.size() * (size_t)G);
       int nr = 0;
       const size_t per = keep.size();
       for (int st = 0; st < G; ++st)
         for (size_t q = 0; q < per; ++q) {
           const int u = keep[q];
-          int r = 0;
-          const size_t lo = st > 0 ? (size_t)(st - 1) * per : 0, hi = all.size();
-          for (size_t v = lo; v < hi; ++v)
-            if (all[v].round >= r && hazard(acc_nc[(size_t)u], acc_nc[(size_t)all[v].unit])) r = all[v].round + 1;
-          all.push_back(Inst{u, st, r, 0, -1});
+          const size_t lo = st > 0 ? (size_t)(st - 1) * per : 0;
+          const int r = place(all, lo, u, acc_nc, 0, chains_all);
+          all.back().sub = st;
           nr = std::max(nr, r + 1);
         }
       if (getenv("SSN_DEBUG_PLAN")) {
@@ -1795,7 +1872,7 @@ struct Sim final : ssn_sim {
       }
       if (!(flags & 16777216)) balance_rounds(all, nr, per, [&](int a, int b) { return hazard(acc_nc[(size_t)a], acc_nc[(size_t)b]); },
                                               [&](int u, double* us, double* lat, int* blocks) { unit_cost(units[(size_t)u].mop, units[(size_t)u].item, us, lat, blocks); });
-      emit(all, nr, graph_list);
+      emit(all, nr, graph_list, chains_all);
       graph_rounds = nr;
       launches_per_step = ((int)graph_list.size() + G - 1) / G;       // (average of the replayed sequence)
     }
@@ -1807,6 +1884,11 @@ struct Sim final : ssn_sim {
     round_bufs.push_back(d_map);
     if (!arena.empty()) HIPCHK(hipMemcpy(d_arena, arena.data(), arena.size(), hipMemcpyHostToDevice));
     if (!glue_map.empty()) HIPCHK(hipMemcpy(d_map, glue_map.data(), glue_map.size() * sizeof(ssn::GlueBlock), hipMemcpyHostToDevice));
+    int* d_chain = nullptr;
+    CHK(dmalloc(&d_chain, (int64_t)(chain_tab.size() + 1) * 4));
+    round_bufs.push_back(d_chain);
+    if (!chain_tab.empty()) HIPCHK(hipMemcpy(d_chain, chain_tab.data(), chain_tab.size() * 4, hipMemcpyHostToDevice));
+    for (RoundLaunch& rl : round_launches) rl.args.chain = d_chain;
     for (const Fix& f : fixes) {
       ssn::RoundEntry& e = round_launches[f.rl].args.e[f.entry];
       if (f.what == 0) e.args = (const unsigned char*)d_arena + f.off;

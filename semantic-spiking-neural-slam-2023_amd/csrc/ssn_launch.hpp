@@ -213,6 +213,10 @@ enum RoundKind {
   RK_ENS_3_4_S, RK_ENS_3_5_S, RK_ENS_1_1_D      // k_ensarray<din, dout, spike-sparse | dense decoders>
 };
 struct GlueBlock { int op; int chunk; };        // micro-operator index (into RoundArgs::mops); chunk of it (low 24 bits), timestep offset (high 8)
+// op < 0: a CHAIN of element-aligned micro-operators - RoundArgs::chain[-op - 1 ...] = {n, op_0, sub_0, ..., op_{n-1}, sub_{n-1}} -
+// run back to back by this block on elements [chunk * GLUE_ROWS, ...): a dependent operator whose every shared element
+// sits at the same index (a filter update behind the reduction it filters, next step's input hand-off behind that update)
+// needs no barrier and no launch of its own when the same thread handles the same index in program order.
 struct RoundEntry { int kind; int first; int gx; int gy; const void* args; int lo; int cnt; };   // blocks [lo, lo + cnt) of the gx x gy grid
 constexpr int MAX_ROUND_ENTRIES = 96;
 template <typename T>
@@ -220,6 +224,7 @@ struct RoundArgs {
   int n;
   int pad;
   const MicroOp<T>* mops;
+  const int* chain;
   T* sig;
   StepCtx* ctx;
   RoundEntry e[MAX_ROUND_ENTRIES];

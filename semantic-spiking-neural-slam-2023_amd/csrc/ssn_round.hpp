@@ -25,17 +25,19 @@ namespace ssn {
 
 // One chunk of one micro-operator.  Element-wise kinds: elements [chunk * GLUE_CHUNK, ...) - four per thread,
 // loads before stores; row kinds (reductions, ensemble finish, small matvec): rows [chunk * GLUE_ROWS, ...), one per thread.
-template <typename T>
-__device__ __forceinline__ void glue_body(const MicroOp<T>& op, const int chunk, const int sub, T* __restrict__ sig, StepCtx* __restrict__ ctx) {
+template <typename T, bool ROWS = false>
+__device__ __forceinline__ void glue_body(const MicroOp<T>& op, const int chunk, const int sub, T* sig, StepCtx* __restrict__ ctx) {
   // sub: timestep offset of this instance inside a pipelined launch sequence (the clock advances once per sequence)
+  // ROWS: member of a chain - element-wise kinds handle element chunk * GLUE_ROWS + tid only, like the row kinds
   const int tid = threadIdx.x;
+  constexpr int U = ROWS ? 1 : 4;
   auto ew = [&](auto load, auto store) {
-    const long long base = (long long)chunk * GLUE_CHUNK;
-    T v[4];
+    const long long base = (long long)chunk * (ROWS ? GLUE_ROWS : GLUE_CHUNK);
+    T v[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const long long i = base + u * 256 + tid; if (i < op.len) v[u] = load(i); }
+    for (int u = 0; u < U; ++u) { const long long i = base + u * 256 + tid; if (i < op.len) v[u] = load(i); }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const long long i = base + u * 256 + tid; if (i < op.len) store(i, v[u]); }
+    for (int u = 0; u < U; ++u) { const long long i = base + u * 256 + tid; if (i < op.len) store(i, v[u]); }
   };
   switch (op.kind) {
     case M_FILL:
@@ -57,18 +59,18 @@ __device__ __forceinline__ void glue_body(const MicroOp<T>& op, const int chunk,
       const LinTerm<T>* const t = (const LinTerm<T>*)op.p0;
       const int nt = (int)op.i0;
       T* const d = sig + op.dst;
-      const long long base = (long long)chunk * GLUE_CHUNK;
-      T acc[4];
+      const long long base = (long long)chunk * (ROWS ? GLUE_ROWS : GLUE_CHUNK);
+      T acc[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] = op.c;
+      for (int u = 0; u < U; ++u) acc[u] = op.c;
       for (int k = 0; k < nt; ++k) {
         const T alpha = t[k].alpha;
         const T* const x = sig + t[k].src;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const long long i = base + u * 256 + tid; if (i < op.len) acc[u] += alpha * x[i]; }
+        for (int u = 0; u < U; ++u) { const long long i = base + u * 256 + tid; if (i < op.len) acc[u] += alpha * x[i]; }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         const long long i = base + u * 256 + tid;
         if (i < op.len) d[i] = (op.a != T(0) ? op.a * d[i] : T(0)) + op.b * acc[u];
       }
@@ -235,7 +237,13 @@ __device__ __forceinline__ void round_block(const RoundArgs<T>& ra, int vb, unsi
   switch (e.kind) {
     case RK_GLUE: {
       const GlueBlock gb = ((const GlueBlock*)e.args)[vb];
-      glue_body<T>(ra.mops[gb.op], gb.chunk & 0xffffff, gb.chunk >> 24, ra.sig, ra.ctx);
+      if (gb.op >= 0) {
+        glue_body<T>(ra.mops[gb.op], gb.chunk & 0xffffff, gb.chunk >> 24, ra.sig, ra.ctx);
+      } else {
+        const int* ch = ra.chain + (-gb.op - 1);
+        const int n = ch[0];
+        for (int q = 0; q < n; ++q) glue_body<T, true>(ra.mops[ch[1 + 2 * q]], gb.chunk, ch[2 + 2 * q], ra.sig, ra.ctx);
+      }
       break;
     }
     case RK_GATE: gate_body<T>(*(const MicroOp<T>*)e.args, ra.sig, smem); break;

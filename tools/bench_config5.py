@@ -41,19 +41,23 @@ print("build %.1fs" % (time.time() - t0), bm.stats, flush=True)
 if build_only:
     sys.exit(0)
 from sspslam_amd.simulator import Simulator
-t0 = time.time()
-sim = Simulator(None, model=bm, dtype="f32")
-sim.prepare(2 * steps + 64)
-print("upload + tabulate %.1fs" % (time.time() - t0), flush=True)
-sim.run_steps(steps, collect=False)
-t0 = time.time(); sim.run_steps(steps, collect=False); el = time.time() - t0
-c = sim.counters()
-out = sim.data[sm.probe]
-real = sm.real_ssp[:out.shape[0]]
-sims = np.sum(out * real, axis=1) / np.maximum(np.linalg.norm(out, axis=1), 1e-12)
-table_gb = sm.slam.sample_ssps.size * 4 / 1e9
-print("%.3f sim-s/wall-s (%.1f us/step), launches/step %d, device GB %.1f; clean-up table %.2f GB (a pass over it every step would need %.0f GB/s); "
-      "similarity to the true SSP after 0.2 s: min %.4f mean %.4f" %
-      (steps * 1e-3 / el, el / steps * 1e6, c["launches_per_step"], c["device_bytes"] / 1e9, table_gb,
-       table_gb / (el / steps), sims[200:].min(), sims[200:].mean()), flush=True)
-sim.close()
+for flags in [int(f) for f in os.environ.get("SSN_FLAGS", "0").split(",")]:      # plan switches to compare in one process
+    t0 = time.time()
+    sim = Simulator(None, model=bm, dtype="f32", flags=flags)
+    sim.prepare(2 * steps + 64)
+    print("flags %d: upload + tabulate %.1fs" % (flags, time.time() - t0), flush=True)
+    sim.run_steps(steps, collect=False)
+    t0 = time.time(); sim.run_steps(steps, collect=False); el = time.time() - t0
+    c = sim.counters()
+    out = sim.data[sm.probe]
+    real = sm.real_ssp[:out.shape[0]]
+    sims = np.sum(out * real, axis=1) / np.maximum(np.linalg.norm(out, axis=1), 1e-12)
+    table_gb = sm.slam.sample_ssps.size * 4 / 1e9
+    print("flags %d: %.3f sim-s/wall-s (%.1f us/step), launches/step %d, device GB %.1f; clean-up table %.2f GB (a pass over it every step would need %.0f GB/s); "
+          "similarity to the true SSP after 0.2 s: min %.4f mean %.4f" %
+          (flags, steps * 1e-3 / el, el / steps * 1e6, c["launches_per_step"], c["device_bytes"] / 1e9, table_gb,
+           table_gb / (el / steps), sims[200:].min(), sims[200:].mean()), flush=True)
+    if os.environ.get("SSN_KT"):
+        sim.run_steps(32, profile=2, collect=False)
+        print("   ", {k: (n // 32, round(1e3 * ms / 32, 1)) for k, (n, ms) in sorted(sim.kernel_times().items(), key=lambda kv: -kv[1][1])}, flush=True)
+    sim.close()
