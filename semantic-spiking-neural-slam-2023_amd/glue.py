@@ -56,8 +56,8 @@ def collapse_glue(ops, model, op_access, protected):
     """``ops``: unscheduled operators of the core stage (dicts).  ``protected``: signal ranges other stages or probes
     touch.  Returns the rewritten list (``seq`` keeps creation order for the scheduler) and a stats dict."""
     glue = [o for o in ops if o["kind"] in ("fill", "axpy") and not o.get("partial_zero")]
-    hard = [o for o in ops if not (o["kind"] in ("fill", "axpy") and not o.get("partial_zero"))]
-    stats = {"glue_in": len(glue), "glue_out": len(glue), "inlined_segments": 0}
+    hard = [dict(o) for o in ops if not (o["kind"] in ("fill", "axpy") and not o.get("partial_zero"))]
+    stats = {"glue_in": len(glue), "glue_out": len(glue), "inlined_segments": 0, "retargeted_inputs": 0}
     if not any(o["kind"] == "axpy" for o in glue):
         return ops, stats
     hard_acc = [_sig_ranges(op_access(o, model)) for o in hard]
@@ -91,14 +91,14 @@ def collapse_glue(ops, model, op_access, protected):
 
     # ---- per-segment facts -----------------------------------------------------------------------------------------------
     hard_w = np.zeros(n_seg, bool)
-    hard_r = np.zeros(n_seg, bool)
+    hard_r = np.zeros(n_seg, np.int64)           # number of readers other than glue (big operators, filters, probes, other stages)
     for w, rd in hard_acc:
         for lo, hi in w:
             hard_w[list(seg.cover(lo, hi))] = True
         for lo, hi in rd:
-            hard_r[list(seg.cover(lo, hi))] = True
+            hard_r[list(seg.cover(lo, hi))] += 1
     for lo, hi in protected:
-        hard_r[list(seg.cover(lo, hi))] = True
+        hard_r[list(seg.cover(lo, hi))] += 1
     pieces = [[] for _ in range(n_seg)]          # per destination segment: (seq, "fill", value) | (seq, mode, alpha, src segment)
     for o in glue:
         d0 = o["dst"]
@@ -113,7 +113,7 @@ def collapse_glue(ops, model, op_access, protected):
     n_sets = np.array([sum(1 for p in ps if p[1] in ("fill", "set")) for ps in pieces])
     has_glue = np.array([len(ps) > 0 for ps in pieces])
     pure = has_glue & ~hard_w & (n_sets == 1)
-    inlinable = pure & ~hard_r
+    inlinable = pure & (hard_r == 0)
 
     # ---- expressions ---------------------------------------------------------------------------------------------------
     memo = {}
@@ -138,6 +138,50 @@ def collapse_glue(ops, model, op_access, protected):
                 terms[j] = terms.get(j, 0.0) + val
         memo[i] = (c, terms)
         return memo[i]
+
+    # ---- copy propagation ------------------------------------------------------------------------------------------------
+    # An operator whose whole input vector is a plain copy of another signal (a pass-through node handing a filter state
+    # or a clean-up result on: `x = 1.0 * s`) reads that signal itself.  The copy then has one reader fewer and disappears
+    # if that was the last one; on the device it is one dependency level - one launch - less in front of the operator.
+    # Reads precede updates within a timestep, so a filter state read directly is still the previous step's value.
+    input_field = {"matvec": ("src", "cols"), "cleanup": ("src", "cols"), "lowpass": ("src", "len"), "neurons": ("j", "n")}
+    changed = True
+    while changed:
+        changed = False
+        memo.clear()
+        inlinable[:] = pure & (hard_r == 0)
+        for o in hard:
+            f = input_field.get(o["kind"])
+            if f is None:
+                continue
+            lo0, ln = o[f[0]], o[f[1]]
+            segs = list(seg.cover(lo0, lo0 + ln))
+            off = None
+            for i in segs:
+                if not pure[i]:
+                    off = None
+                    break
+                c, terms = expr(i)
+                if c != 0.0 or len(terms) != 1:
+                    off = None
+                    break
+                (j, a), = terms.items()
+                d = seg.span(j)[0] - seg.span(i)[0]
+                if a != 1.0 or (off is not None and d != off):
+                    off = None
+                    break
+                off = d
+            if off is None or off == 0:
+                continue
+            src_segs = list(seg.cover(lo0 + off, lo0 + off + ln))
+            hard_r[segs] -= 1
+            hard_r[src_segs] += 1
+            o[f[0]] = lo0 + off
+            stats["retargeted_inputs"] += 1
+            changed = True
+            break                     # expressions depend on which copies are still read: start over
+    memo.clear()
+    inlinable[:] = pure & (hard_r == 0)
 
     out = list(hard)
     new = []                                     # (dst lo, len, self coefficient, const, ((src lo, alpha), ...), seq)
