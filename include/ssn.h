@@ -164,8 +164,6 @@ typedef struct ssn_model_desc {
                                               bandwidth-bound operator in pieces over the rounds of its slack window),
                                          33554432 = merged element-wise operators stay whole (default: cut at the range endpoints of
                                               the other operators, so that each piece has its own hazards),
-                                         67108864 = all rounds of a step graph in one persistent grid with grid barriers (k_rounds;
-                                              measured 3x slower than one launch per round, DESIGN.md - opt-in),
                                          134217728 = no chains (default: an element-wise micro-operator whose only hazards inside a
                                               round are on identical element ranges joins that round and runs behind its
                                               predecessor in the same block),

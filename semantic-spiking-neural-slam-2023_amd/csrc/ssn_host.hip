@@ -173,12 +173,7 @@ struct Sim final : ssn_sim {
   std::vector<Launch> graph_list;             // steps_per_graph timesteps, software-pipelined (empty: replay launch_list)
   int graph_rounds = 0;
   std::vector<void*> round_bufs;
-  // persistent variant of the pipelined sequence (k_rounds): all its rounds in one resident grid
-  ssn::RoundArgs<T>* d_persist_rounds = nullptr;
-  int* d_persist_blocks = nullptr;
-  ssn::PersistCtl* d_persist_ctl = nullptr;
-  int persist_rounds = 0, persist_grid = 0;
-  size_t persist_lds = 0;
+
   std::vector<hipStream_t> side_streams;
   std::vector<hipEvent_t> dag_events;
   ssn::StepCtx* d_ctx = nullptr;
@@ -1895,40 +1890,7 @@ struct Sim final : ssn_sim {
       else if (f.what == 1) e.args = d_map + f.off;
       else e.args = d_mops + f.off;
     }
-    // persistent grid for the pipelined sequence, when every launch of it is a round
-    persist_rounds = 0;
-    bool all_rounds = !graph_list.empty();
-    for (const Launch& l : graph_list) all_rounds = all_rounds && l.rl >= 0;
-    if (all_rounds && graph_list.size() >= 2 && (flags & 67108864)) {      // opt-in: measured 411 vs 142 us per timestep at SLAM config 3
-      std::vector<ssn::RoundArgs<T>> ra;
-      std::vector<int> nb;
-      size_t lds = 64;
-      for (const Launch& l : graph_list) {
-        ra.push_back(round_launches[(size_t)l.rl].args);
-        nb.push_back(round_launches[(size_t)l.rl].n_blocks);
-        lds = std::max(lds, round_launches[(size_t)l.rl].lds);
-      }
-      int per_cu = 0, cus = 0;
-      HIPCHK(ssn::persistent_capacity<T>(lds, &per_cu));
-      HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-      const char* env_occ = getenv("SSN_PERSIST_WGS_PER_CU");
-      if (env_occ) per_cu = std::max(1, std::min(per_cu, atoi(env_occ)));
-      if (per_cu >= 1 && cus >= 8) {
-        CHK(dmalloc(&d_persist_rounds, (int64_t)(ra.size() * sizeof(ssn::RoundArgs<T>))));
-        round_bufs.push_back(d_persist_rounds);
-        CHK(dmalloc(&d_persist_blocks, (int64_t)(nb.size() * sizeof(int))));
-        round_bufs.push_back(d_persist_blocks);
-        CHK(dmalloc(&d_persist_ctl, (int64_t)ssn::PERSIST_CTL_BYTES));
-        round_bufs.push_back(d_persist_ctl);
-        HIPCHK(hipMemcpy(d_persist_rounds, ra.data(), ra.size() * sizeof(ssn::RoundArgs<T>), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d_persist_blocks, nb.data(), nb.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(hipMemset(d_persist_ctl, 0, ssn::PERSIST_CTL_BYTES));
-        persist_rounds = (int)ra.size(); persist_grid = per_cu * cus; persist_lds = lds;
-        launches_per_step = 1;
-      }
-    }
     if (getenv("SSN_DEBUG_PLAN")) {
-      fprintf(stderr, "[ssn] persistent grid: %d rounds, %d workgroups, %zu B LDS\n", persist_rounds, persist_grid, persist_lds);
       fprintf(stderr, "[ssn] round plan: %zu units in %d rounds, %d launches per timestep; %d timesteps pipelined: %d rounds, %zu launches\n",
               units.size(), n_rounds, launches_unpipelined, G, graph_rounds, graph_list.size());
       for (const Launch& l : launch_list) {
@@ -2214,8 +2176,6 @@ struct Sim final : ssn_sim {
       return hipGetLastError();
     }
     if (round_mode) {
-      if (count == steps_per_graph && persist_rounds > 0)
-        return ssn::launch_rounds<T>(stream, d_persist_rounds, d_persist_blocks, persist_rounds, persist_grid, persist_lds, d_persist_ctl, d_ctx, (long long)count);
       if (count == steps_per_graph && !graph_list.empty()) {
         for (const Launch& l : graph_list) { hipError_t e = launch_one(l); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, (long long)count);
@@ -2574,12 +2534,6 @@ struct Sim final : ssn_sim {
     steps_done += n;
     ssn::StepCtx ctx;
     HIPCHK(hipMemcpy(&ctx, d_ctx, sizeof ctx, hipMemcpyDeviceToHost));
-    if (d_persist_ctl) {
-      int perr = 0;
-      HIPCHK(hipMemcpy(&perr, (const unsigned char*)d_persist_ctl + ssn::PERSIST_CTL_ERROR_OFFSET, sizeof perr, hipMemcpyDeviceToHost));
-      if (perr) return fail(SSN_EHIP, "a grid barrier of the persistent step kernel timed out (workgroups not co-resident?); results are invalid - "
-                                      "rerun without flag 67108864 (one launch per round)");
-    }
     if (ctx.step != steps_done) return fail(SSN_EHIP, "device step counter %lld != host %lld", (long long)ctx.step, (long long)steps_done);
     if (ctx.probe_overflow) return fail(SSN_EINVAL, "probe storage overflow: call ssn_reserve_probes before ssn_run_steps");
     return SSN_OK;

@@ -1678,8 +1678,6 @@ namespace ssn {
   template hipError_t launch_batch_elementwise<T>(hipStream_t, const BatchOpList<T>&);                      \
   template hipError_t launch_convert_in<T>(hipStream_t, const double*, T*, int64_t, int64_t, int64_t);      \
   template hipError_t launch_convert_out<T>(hipStream_t, const T*, double*, int64_t, int64_t, int64_t);      \
-  template hipError_t launch_round<T>(hipStream_t, const RoundArgs<T>&, int, size_t);                        \
-  template hipError_t persistent_capacity<T>(size_t, int*);                                                  \
-  template hipError_t launch_rounds<T>(hipStream_t, const RoundArgs<T>*, const int*, int, int, size_t, PersistCtl*, StepCtx*, long long);
+  template hipError_t launch_round<T>(hipStream_t, const RoundArgs<T>&, int, size_t);
 
 }  // namespace ssn

@@ -230,12 +230,6 @@ struct RoundArgs {
   RoundEntry e[MAX_ROUND_ENTRIES];
 };
 template <typename T> hipError_t launch_round(hipStream_t, const RoundArgs<T>&, int n_blocks, size_t lds_bytes);
-struct PersistCtl;      // grid-barrier state of the persistent variant (ssn_round.hpp)
-template <typename T> hipError_t persistent_capacity(size_t lds_bytes, int* blocks_per_cu);
-template <typename T> hipError_t launch_rounds(hipStream_t, const RoundArgs<T>* rounds, const int* n_blocks, int n_rounds, int grid, size_t lds_bytes,
-                                               PersistCtl* ctl, StepCtx* ctx, long long steps);
-constexpr size_t PERSIST_CTL_BYTES = 9 * 32 * 4 + 16;
-constexpr size_t PERSIST_CTL_ERROR_OFFSET = 9 * 32 * 4;
 // elements (rows for the reductions) of a micro-operator that one block of a round handles
 constexpr int GLUE_CHUNK = 1024;
 constexpr int GLUE_ROWS = 256;

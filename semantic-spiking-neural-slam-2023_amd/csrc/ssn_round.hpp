@@ -270,76 +270,10 @@ __global__ __launch_bounds__(256) void k_round(RoundArgs<T> ra) {
   round_block<T>(ra, (int)blockIdx.x, ssn_round_smem);
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_rounds: ALL rounds of a pipelined launch sequence in one persistent grid.  Between two k_round launches the chip
-// drains and refills (~8 us per round at SLAM config 3, a third of the step); here every workgroup stays resident, takes
-// the blocks  blockIdx.x, blockIdx.x + gridDim.x, ...  of each round and meets the others at a grid barrier:
-//   release fence -> one atomic on its group's counter (8 groups, one cache line each; the last arrival of a group bumps
-//   the global counter) -> poll the global counter -> acquire fence.
-// The grid is sized by the host to what is resident at once (occupancy x CUs) - a workgroup that is not resident would
-// never arrive.  Polls are bounded: a barrier that does not complete within ~0.2 s raises PersistCtl::error and lets the
-// grid run out (results are then invalid; the host reports the error instead of hanging the GPU).
-// ---------------------------------------------------------------------------------------------
-struct PersistCtl {
-  unsigned int arrived[9 * 32];     // [0]: groups done with the current barrier (cumulative); [32 * (1 + g)]: arrivals of group g (cumulative)
-  int error;
-};
-
-__device__ __forceinline__ void grid_barrier(PersistCtl* ctl, unsigned gen) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const unsigned grp = blockIdx.x & 7u;
-    const unsigned members = (gridDim.x + 7u - grp) / 8u;
-    const unsigned v = atomicAdd(&ctl->arrived[32 * (1 + grp)], 1u);
-    if (v + 1u == gen * members) atomicAdd(&ctl->arrived[0], 1u);
-    unsigned spins = 0;
-    while (__hip_atomic_load(&ctl->arrived[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen * 8u) {
-      __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 1023u) == 0 && (spins > (1u << 20) || __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-        __hip_atomic_store(&ctl->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // give up: every other workgroup follows within 1024 polls
-        break;
-      }
-    }
-    __threadfence();
-  }
-  __syncthreads();
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_rounds(const RoundArgs<T>* __restrict__ rounds, const int* __restrict__ n_blocks, int n_rounds, PersistCtl* ctl) {
-  extern __shared__ __align__(16) unsigned char ssn_round_smem[];
-  for (int r = 0; r < n_rounds; ++r) {
-    const int nb = n_blocks[r];
-    for (int vb = (int)blockIdx.x; vb < nb; vb += (int)gridDim.x) {
-      round_block<T>(rounds[r], vb, ssn_round_smem);
-      __syncthreads();                        // (the next block reuses the workgroup memory)
-    }
-    if (r + 1 < n_rounds) grid_barrier(ctl, (unsigned)(r + 1));
-  }
-}
-// resets the barrier counters behind a k_rounds launch (stream order) and advances the clock
-template <typename T>
-__global__ void k_rounds_finish(PersistCtl* ctl, StepCtx* ctx, long long steps) {
-  if (threadIdx.x < 9) ctl->arrived[32 * threadIdx.x] = 0u;
-  if (threadIdx.x == 0) ctx->step += steps;
-}
-
-template <typename T>
-hipError_t persistent_capacity(size_t lds_bytes, int* blocks_per_cu) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rounds<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  if (e != hipSuccess) return e;
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_rounds<T>, 256, std::max<size_t>(lds_bytes, 64));
-}
-template <typename T>
-hipError_t launch_rounds(hipStream_t s, const RoundArgs<T>* rounds, const int* n_blocks, int n_rounds, int grid, size_t lds_bytes,
-                         PersistCtl* ctl, StepCtx* ctx, long long steps) {
-  hipLaunchKernelGGL((k_rounds<T>), dim3((unsigned)grid), dim3(256), std::max<size_t>(lds_bytes, 64), s, rounds, n_blocks, n_rounds, ctl);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_rounds_finish<T>), dim3(1), dim3(64), 0, s, ctl, ctx, steps);
-  return hipGetLastError();
-}
+// (A persistent variant - all rounds of a step graph in one resident grid with grid barriers - was built, tested and
+//  measured in round 2: 411 us per timestep against 142 us with one launch per round at SLAM config 3, because every
+//  workgroup's release / acquire fence is a write-back + invalidate of its XCD's whole L2; the barrier measurements are
+//  in tools/grid_barrier.hip and profiles/round2_grid_barrier.txt.  It was removed.)
 
 template <typename T>
 hipError_t launch_round(hipStream_t s, const RoundArgs<T>& ra, int n_blocks, size_t lds_bytes) {
