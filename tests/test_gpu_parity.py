@@ -699,8 +699,11 @@ class _ThreadDist:
 
     def all_reduce(self, t, op=None):
         import torch
+        torch.cuda.synchronize()
         got = self._meet(t.clone())
-        t.copy_(torch.stack(got).max(dim=0).values)
+        st = torch.stack([g.to(t.device) for g in got])
+        t.copy_(st.max(dim=0).values if op == "max" else st.sum(dim=0))
+        torch.cuda.synchronize()
 
     def all_gather(self, outs, t):
         for o, g in zip(outs, self._meet(t.clone())):
@@ -744,6 +747,53 @@ def test_device_exchange_with_three_ranks_in_one_process(Simulator):
         t.join(timeout=600)
     assert not errors, errors
     np.testing.assert_allclose(results["out"], ref.probe_data(0), atol=1e-9, rtol=0)
+    for r in runners:
+        r.close()
+
+
+def test_sharded_slam_device_exchange_with_two_ranks_in_one_process(Simulator):
+    """The neuron-sharded SLAMNetwork through the DEVICE exchange path (what RCCL ranks run: ssn_exchange_pack into a
+    device buffer -> all-reduce of that buffer -> ssn_exchange_unpack, between ssn_run_phase(0) and (1)), with two ranks
+    living in one process and a stand-in communicator that sums the device tensors: trajectory and gathered PES decoders
+    equal the unsharded oracle run."""
+    import threading
+    from sspslam_amd.sharding import ShardedSLAM
+    steps, world = 150, 2
+    sm0 = _small_slam(weights_every=None)
+    model = build(sm0.model)
+    ref = OracleSimulator(model)
+    ref.run_steps(steps)
+    W_ref = ref.buf[model.params[sm0.slam.assomemory.conn_out].learned_buffer]
+    fake = _ThreadDist(world)
+    sms = [_small_slam(weights_every=None) for _ in range(world)]
+    runners = [ShardedSLAM(sms[rank], rank, world, dtype="f64", dist=fake) for rank in range(world)]
+    assert all(len(r.model.exchange) > 0 for r in runners)
+    results, errors = {}, []
+
+    def work(rank):
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            fake.local.rank = rank
+            r = runners[rank]
+            r.prepare(steps)
+            r.run_steps(steps)
+            W = r.learned_decoders(sms[rank].slam.assomemory.conn_out)
+            if rank == 0:
+                results["out"], results["W"] = r.probe_data(), W
+        except BaseException as e:               # noqa: BLE001
+            errors.append((rank, e))
+            fake.barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(rank,)) for rank in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    np.testing.assert_allclose(results["out"], ref.probe_data(0), atol=1e-9, rtol=0)
+    np.testing.assert_allclose(results["W"], W_ref, atol=1e-12, rtol=1e-9)
+    assert np.abs(W_ref).max() > 1e-6
     for r in runners:
         r.close()
 
