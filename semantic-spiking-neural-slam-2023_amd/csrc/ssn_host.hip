@@ -17,9 +17,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <map>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ssn.h"
@@ -127,6 +129,10 @@ struct Sim final : ssn_sim {
   int device = 0;
   double dt = 0.001;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;          // downloads (see download())
+  void* dl_stage = nullptr;                   // pinned host staging of download()
+  int64_t dl_cap = 0;
+  std::mutex dl_mutex;
   int64_t n_sig = 0;
   T* sig = nullptr;
   std::vector<double> sig_init;
@@ -241,6 +247,8 @@ struct Sim final : ssn_sim {
     if (d_ctx) hipFree(d_ctx);
     if (d_tables) hipFree(d_tables);
     if (d_pslots) hipFree(d_pslots);
+    if (copy_stream) { hipStreamSynchronize(copy_stream); hipStreamDestroy(copy_stream); }
+    if (dl_stage) hipHostFree(dl_stage);
     if (stream) hipStreamDestroy(stream);
   }
 
@@ -266,16 +274,33 @@ struct Sim final : ssn_sim {
     return SSN_OK;
   }
 
+  // Device -> host as float64.  The values travel in the simulator's own type into a pinned host buffer (a DMA copy on a
+  // stream of its own: no kernel, so it does not queue behind a compute kernel that owns every CU, and no pageable
+  // staging) and are widened on the host by a few threads.  A caller thread may therefore fetch the probe samples of the
+  // timesteps that are done while another thread's ssn_run_steps steps the next ones (simulator.py does, chunk by
+  // chunk).  Everything read here was completed by a call that synchronised the compute stream before it returned.
   int download(const T* src, double* dst, int64_t rows, int64_t cols, int64_t ld) {
     const int64_t n = rows * cols;
     if (n == 0) return SSN_OK;
-    double* stage = nullptr;
-    HIPCHK(hipMalloc((void**)&stage, (size_t)n * sizeof(double)));
-    hipError_t e = ssn::launch_convert_out<T>(stream, src, stage, rows, cols, ld);
-    if (e == hipSuccess) e = hipMemcpyAsync(dst, stage, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    hipFree(stage);
-    HIPCHK(e);
+    std::lock_guard<std::mutex> lock(dl_mutex);
+    if (!copy_stream) HIPCHK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    if (n > dl_cap) {
+      if (dl_stage) { HIPCHK(hipStreamSynchronize(copy_stream)); hipHostFree(dl_stage); dl_stage = nullptr; }
+      const int64_t want = std::max<int64_t>(n, 1 << 20);
+      HIPCHK(hipHostMalloc((void**)&dl_stage, (size_t)want * sizeof(T), hipHostMallocDefault));
+      dl_cap = want;
+    }
+    T* h = (T*)dl_stage;
+    if (ld == cols) HIPCHK(hipMemcpyAsync(h, src, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, copy_stream));
+    else HIPCHK(hipMemcpy2DAsync(h, (size_t)cols * sizeof(T), src, (size_t)ld * sizeof(T), (size_t)cols * sizeof(T), (size_t)rows, hipMemcpyDeviceToHost, copy_stream));
+    HIPCHK(hipStreamSynchronize(copy_stream));
+    auto widen = [h, dst](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) dst[i] = (double)h[i]; };
+    const int nt = n >= (1 << 21) ? 4 : 1;
+    if (nt == 1) { widen(0, n); return SSN_OK; }
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(widen, n * t / nt, n * (t + 1) / nt);
+    widen(0, n / nt);
+    for (auto& th : pool) th.join();
     return SSN_OK;
   }
 
@@ -319,6 +344,7 @@ struct Sim final : ssn_sim {
       T* tmp = nullptr;
       HIPCHK(hipMalloc((void**)&tmp, (size_t)(b.rows * b.ld) * sizeof(T)));
       hipError_t e = ssn::launch_transpose<T>(stream, (const T*)b.d, tmp, (int)b.cols, (int)b.rows, (int)b.ldt, (int)b.ld);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);          // (download() copies on its own stream)
       int rc = e == hipSuccess ? download(tmp, dst, b.rows, b.cols, b.ld) : SSN_OK;
       hipFree(tmp);
       HIPCHK(e);
@@ -336,6 +362,7 @@ struct Sim final : ssn_sim {
       // (the f32 whole-block kernel keeps -(R - dt) in the state word of a refractory neuron, every other kernel -R)
       e = ssn::launch_state_unpack<T>(stream, words, tmp, b.rows * b.ld, b.packed == 2, (fused_block && sizeof(T) == 4) ? (T)dt : T(0));
     }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);            // (download() copies on its own stream)
     int rc = e == hipSuccess ? download(tmp, dst, b.rows, b.cols, b.ld) : SSN_OK;
     hipFree(tmp);
     HIPCHK(e);

@@ -334,10 +334,19 @@ class Simulator:
                 self._fetched = {}
                 self._reserved_until = self.n_steps + steps
                 pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_CHUNK, steps))
+                if collect:
+                    # the samples of chunk k are fetched (float64, straight into one array per probe) on a helper thread
+                    # while the device steps chunk k + 1: the library downloads on its own stream
+                    self._bulk = {}
+                    for key, (kind, j, p) in self._probe_index.items():
+                        if kind == "sig":
+                            cap = (self.n_steps + steps) // p["every"] - self.n_steps // p["every"]
+                            self._bulk[key] = np.empty((cap, p["width"]), dtype=np.float64)
             else:
                 self.prepare(steps)
         buf_probes = [(k, v[2]) for k, v in self._probe_index.items() if v[0] == "buf"]
         done = 0
+        collector = None
         while done < steps:
             # Probes of learned signals ("weights", "scaled_encoders"): nengo adds a learning rule's delta to its target at
             # the START of the next timestep (`target += delta` is an inc, the delta an update - SURVEY Appendix A.7 / A.8),
@@ -369,6 +378,12 @@ class Simulator:
             self._check(self._lib.ssn_run_steps(self._h, chunk, int(profile)))
             self.n_steps += chunk
             done += chunk
+            if getattr(self, "_bulk", None) is not None and done < steps:
+                import threading
+                if collector is not None:
+                    collector.join()
+                collector = threading.Thread(target=self._collect_bulk)
+                collector.start()
             if worker is not None:
                 worker.join()
                 if "r" not in box:
@@ -376,6 +391,19 @@ class Simulator:
                 pipelined = box["r"]
                 if self.n_steps != pipelined[0]:          # a weight-probe boundary cut the chunk short: re-tabulate from here
                     pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_CHUNK, steps - done))
+        if collector is not None:
+            collector.join()
+        if getattr(self, "_bulk", None) is not None:
+            self._collect_bulk()                     # the last chunk
+            if self._bulk_error is not None:
+                err, self._bulk_error = self._bulk_error, None
+                self._bulk = None
+                raise err
+            for key, arr in self._bulk.items():
+                n = self._fetched.get(key, 0)
+                if n:
+                    self._chunks[key].append(arr[:n])
+            self._bulk = None
         self._uncollected = True
         if collect:
             self._collect()
@@ -386,6 +414,23 @@ class Simulator:
         if isinstance(b, tuple):
             return self.model.params[p["ens"]].encoder_buffer
         return b
+
+    _bulk = None
+    _bulk_error = None
+
+    def _collect_bulk(self):
+        """Fetch the samples completed so far into the per-probe arrays of a pipelined run (helper thread)."""
+        try:
+            for key, arr in self._bulk.items():
+                kind, j, p = self._probe_index[key]
+                n = min(int(self._lib.ssn_probe_count(self._h, j)), arr.shape[0])
+                have = self._fetched.get(key, 0)
+                if n <= have:
+                    continue
+                self._check(self._lib.ssn_read_probe(self._h, j, arr[have:].ctypes.data, have, n - have))
+                self._fetched[key] = n
+        except BaseException as e:               # noqa: BLE001 - surfaced by run_steps on the caller's thread
+            self._bulk_error = e
 
     def _collect(self):
         """Fetch the probe samples produced since the last fetch (incremental within a reservation)."""
@@ -410,7 +455,11 @@ class Simulator:
         if not chunks:
             width = p.get("width")
             return np.zeros((0, width)) if width else np.zeros((0,) + tuple(p["shape"]))
-        return np.concatenate(chunks, axis=0)
+        if len(chunks) == 1:
+            return chunks[0]                 # (a pipelined run fetched straight into one array: no 80 MB copy)
+        merged = np.concatenate(chunks, axis=0)
+        self._chunks[key] = [merged]         # later reads of sim.data[probe] reuse it
+        return merged
 
     def probe_tail(self, key, n):
         """The last ``n`` samples of a probe without concatenating the whole history."""

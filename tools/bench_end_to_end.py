@@ -9,7 +9,7 @@ from sspslam_amd.simulator import Simulator
 
 T = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
 s = H.make_ssp_space(2, 1015)
-path, vels = H.make_random_path(3 * max(T, 10.0) + 3.0, limit=0.1, seed=0)
+path, vels = H.make_random_path(5 * max(T, 10.0) + 3.0, limit=0.1, seed=0)
 pm = H.make_pathint_model(s, path, vels, 10000)
 bm = build(pm.model, n_eval_points=4000)
 sim = Simulator(None, model=bm, dtype="f32")
@@ -27,3 +27,19 @@ sim.run_steps(steps)                       # unprepared: tabulation of chunk k+1
 out = sim.data[pm.probe]
 t1 = time.perf_counter()
 print("T = %.0f s: plain run_steps + data (pipelined tabulation): %.1f ms -> %.1f sim-s/wall-s end to end" % (T, (t1 - t0) * 1e3, T / (t1 - t0)), flush=True)
+
+# the same with a per-phase timeline of the pipelined path
+import threading
+sim.clear_probe_data()
+orig_run, orig_coll = sim._lib.ssn_run_steps, sim._collect_bulk
+marks = []
+def timed_collect():
+    a = time.perf_counter(); orig_coll(); marks.append(("collect", a, time.perf_counter()))
+sim._collect_bulk = timed_collect
+t0 = time.perf_counter()
+sim.run_steps(steps)
+t1 = time.perf_counter()
+out = sim.data[pm.probe]
+t2 = time.perf_counter()
+print("pipelined run_steps %.1f ms + data[probe] %.1f ms; helper-thread fetches: %s" %
+      ((t1 - t0) * 1e3, (t2 - t1) * 1e3, ", ".join("%.1f-%.1f ms" % ((a - t0) * 1e3, (b - t0) * 1e3) for _, a, b in marks)), flush=True)
