@@ -1881,13 +1881,16 @@ struct Sim final : ssn_sim {
         size_t cur = 0;
         for (size_t i = 0; i < all.size(); ++i) if (all[i].round >= all[cur].round) cur = i;
         fprintf(stderr, "[ssn] critical chain (backwards from the last round):\n");
-        for (int hop = 0; hop < 40 && all[cur].round > 0; ++hop) {
+        for (int hop = 0; hop < 70 && all[cur].round > 0; ++hop) {
           const Unit& u = units[(size_t)all[cur].unit];
           if (u.mop >= 0) fprintf(stderr, "[ssn]   round %3d step %2d micro %d/%lld dst %lld\n", all[cur].round, all[cur].sub, mops[(size_t)u.mop].kind, (long long)mops[(size_t)u.mop].len, (long long)mops[(size_t)u.mop].dst);
           else fprintf(stderr, "[ssn]   round %3d step %2d item %d type %d rows %d cols %d\n", all[cur].round, all[cur].sub, u.item, items[(size_t)u.item].type, items[(size_t)u.item].rows, items[(size_t)u.item].cols);
           size_t prev = cur;
           for (size_t v = cur; v-- > 0;)
             if (all[v].round == all[cur].round - 1 && hazard(acc_nc[(size_t)all[cur].unit], acc_nc[(size_t)all[v].unit])) { prev = v; break; }
+          if (prev == cur)          // a chain member: its predecessor sits in the same round, in the same block
+            for (size_t v = cur; v-- > 0;)
+              if (all[v].round == all[cur].round && all[v].chain >= 0 && all[v].chain == all[cur].chain) { prev = v; break; }
           if (prev == cur) break;
           cur = prev;
         }
