@@ -421,6 +421,8 @@ class ShardedSLAM:
             self.dist.all_reduce(t)
 
     def _exchange(self):
+        if self.world == 1:
+            return                                   # a single rank's sums are complete
         dev = self.world > 1 and self.dist.is_initialized() and self.dist.get_backend() == "nccl" and hasattr(self.sim, "exchange_pack")
         if not dev:
             self.sim.exchange_host(self._allreduce_host)
