@@ -915,7 +915,7 @@ class Builder:
             ops = prune_ops(ops, m)
         r_allocs = [(base["R"] + off, ln) for off, ln in self.r_allocs]
         collapse = None
-        if self.collapse and self.neuron_shard is None:
+        if self.collapse:
             def collapse(sub, protected):
                 sub, st = collapse_glue(sub, m, op_access, protected)
                 m.stats.update({"glue_" + k: v for k, v in st.items()})
@@ -1106,6 +1106,18 @@ def shard_phases(model, shard):
             else:
                 full[d] |= full[sr]
                 part[d] |= part[sr]
+        elif k == "lincomb":         # folded glue: linear, so partial where any of its sources is
+            d = slice(o["dst"], o["dst"] + o["len"])
+            f_new = np.full(o["len"], o["const"] != 0.0)
+            p_new = np.zeros(o["len"], bool)
+            for src in o["srcs"]:
+                f_new |= full[src:src + o["len"]]
+                p_new |= part[src:src + o["len"]]
+            if o["self"]:
+                full[d] |= f_new
+                part[d] |= p_new
+            else:
+                full[d], part[d] = f_new, p_new
         elif k == "matvec":
             d = slice(o["dst"], o["dst"] + o["rows"])
             sr = slice(o["src"], o["src"] + o["cols"])
