@@ -234,7 +234,8 @@ int ssn_read_buffer(ssn_sim* sim, int32_t buffer_id, double* dst, int64_t count)
 int ssn_write_buffer(ssn_sim* sim, int32_t buffer_id, const double* src, int64_t count);
 
 /* Neuron-sharded models: one half of a timestep (phase 0: everything up to the exchange; phase 1: the updates, probe
- * sampling, step counter).  Blocking.  ssn_run_steps refuses such models. */
+ * sampling, step counter; phase 2 = phase 1 followed by phase 0 of the next timestep in one launch, for the inside of a
+ * run: 0, x, 2, x, 2, ..., x, 1 with x the caller's exchange).  Blocking.  ssn_run_steps refuses such models. */
 int ssn_run_phase(ssn_sim* sim, int32_t phase);
 /* Elements of the exchange (sum of the range lengths); copy them to / from one contiguous device buffer of the simulator's dtype. */
 int64_t ssn_exchange_size(ssn_sim* sim);

@@ -210,8 +210,8 @@ struct Sim final : ssn_sim {
   std::vector<ssn_range> exchange;
   bool phased = false;
   int next_phase = 0;
-  hipGraphExec_t phase_exec[2] = {nullptr, nullptr};
-  hipGraph_t phase_graph[2] = {nullptr, nullptr};
+  hipGraphExec_t phase_exec[3] = {nullptr, nullptr, nullptr};      // [2]: phase 1 of a timestep followed by phase 0 of the next
+  hipGraph_t phase_graph[3] = {nullptr, nullptr, nullptr};
   static constexpr int N_ITEM_TYPES = 16;
   double type_ms[N_ITEM_TYPES] = {};             // profile = 2: device time per plan-item type
   int64_t type_launches[N_ITEM_TYPES] = {};
@@ -223,7 +223,7 @@ struct Sim final : ssn_sim {
     if (stream) hipStreamSynchronize(stream);
     if (graph_exec) hipGraphExecDestroy(graph_exec);
     if (graph) hipGraphDestroy(graph);
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 3; ++h) {
       if (phase_exec[h]) hipGraphExecDestroy(phase_exec[h]);
       if (phase_graph[h]) hipGraphDestroy(phase_graph[h]);
     }
@@ -2315,9 +2315,10 @@ struct Sim final : ssn_sim {
   int capture() {
     if (phased) {             // one graph per half of the timestep
       if (fused_core || core_empty) return fail(SSN_EUNSUPPORTED, "neuron-sharded models run on the generic per-timestep plan");
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < 3; ++h) {        // [2]: phase 1 of a timestep + phase 0 of the next one in one launch
         HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        hipError_t e = launch_phase(h);
+        hipError_t e = launch_phase(h == 2 ? 1 : h);
+        if (h == 2 && e == hipSuccess) e = launch_phase(0);
         hipError_t e2 = hipStreamEndCapture(stream, &phase_graph[h]);
         HIPCHK(e);
         HIPCHK(e2);
@@ -2370,11 +2371,12 @@ struct Sim final : ssn_sim {
   int run_phase(int phase) override {
     HIPCHK(hipSetDevice(device));
     if (!phased) return fail(SSN_EINVAL, "ssn_run_phase: the model has no exchange ranges (use ssn_run_steps)");
-    if (phase != next_phase) return fail(SSN_EINVAL, "ssn_run_phase(%d): phase %d is due", phase, next_phase);
+    if (phase < 0 || phase > 2) return fail(SSN_EINVAL, "ssn_run_phase(%d): 0, 1 or 2 (= 1 followed by the next timestep's 0)", phase);
+    if ((phase == 2 ? 1 : phase) != next_phase) return fail(SSN_EINVAL, "ssn_run_phase(%d): phase %d is due", phase, next_phase);
     HIPCHK(hipGraphLaunch(phase_exec[phase], stream));
     HIPCHK(hipStreamSynchronize(stream));
-    next_phase = 1 - phase;
-    if (phase == 1) {
+    next_phase = phase == 0 ? 1 : (phase == 1 ? 0 : 1);
+    if (phase >= 1) {
       steps_done += 1;
       if (steps_done % 64 == 0 || steps_done == reserve_first + reserve_n) {      // (a device -> host round trip: not on every timestep)
         ssn::StepCtx ctx;

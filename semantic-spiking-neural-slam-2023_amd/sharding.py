@@ -442,10 +442,13 @@ class ShardedSLAM:
 
     def run_steps(self, n):
         if hasattr(self.sim, "run_phase"):
-            for _ in range(int(n)):
+            n = int(n)
+            if n > 0:
                 self.sim.run_phase(0)
-                self._exchange()
-                self.sim.run_phase(1)
+                for i in range(n):
+                    self._exchange()
+                    # the updates of this timestep and the next one up to its exchange share a launch (one host round trip)
+                    self.sim.run_phase(2 if i + 1 < n else 1)
         else:
             self.sim.run_steps(n)
         self.n_steps += int(n)
