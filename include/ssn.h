@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSN_ABI_VERSION 4
+#define SSN_ABI_VERSION 5
 
 enum ssn_status {
   SSN_OK = 0,

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSN_HIP_LIB") or os.path.join(_HERE, "libssn_hip.so")     # override: A/B builds of the library
 
-SSN_ABI_VERSION = 4
+SSN_ABI_VERSION = 5
 SSN_F32, SSN_F64 = 0, 1
 SSN_BUF_REAL, SSN_BUF_I32 = 0, 1
 NEURON_CODE = {"lif": 0, "lifrate": 1, "relu": 2}

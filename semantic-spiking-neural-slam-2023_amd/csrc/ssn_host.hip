@@ -2821,6 +2821,6 @@ int ssn_device_count(void) {
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 const char* ssn_last_error(void) { return g_err.c_str(); }
-const char* ssn_version(void) { return "libssn_hip 0.5 (gfx950, ABI 4)"; }
+const char* ssn_version(void) { return "libssn_hip 0.6 (gfx950, ABI 5)"; }
 
 }  // extern "C"
