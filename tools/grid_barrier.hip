@@ -2,7 +2,7 @@
 // fences it needs.  A persistent grid of G workgroups runs R rounds: every workgroup writes its round number into its own
 // 256-byte slot, passes the barrier, then reads the slot of a workgroup on ANOTHER XCD and counts stale values.
 //
-//   variant 0  thread 0 of every workgroup: __threadfence() - atomic - poll - __threadfence()      (k_rounds today)
+//   variant 0  thread 0 of every workgroup: __threadfence() - atomic - poll - __threadfence()      (what the removed persistent variant of k_round did)
 //   variant 1  every workgroup: s_waitcnt vmcnt(0); only the LAST arrival of an XCD group writes the group's L2 back
 //              (buffer_wbl2 sc1) and, once all groups are done, invalidates it (buffer_inv sc1) and releases its group;
 //              the others then invalidate only their L1 (buffer_inv sc0)
