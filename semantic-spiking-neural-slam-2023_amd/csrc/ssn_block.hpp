@@ -158,6 +158,34 @@ __device__ inline f32x2 lif_packed_step_f32x2(f32x2 J, f32x2& s, const LifConstV
 __device__ inline float bits_f(unsigned int x) { return __builtin_bit_cast(float, x); }
 __device__ inline unsigned int f_bits(float x) { return __builtin_bit_cast(unsigned int, x); }
 
+#ifdef SSN_BLOCK_STAMPS
+// diagnostic build only (make F32_EXTRA=-DSSN_BLOCK_STAMPS, tools/block_stamps.py): shader-clock stamps (s_memtime) between the
+// sections of a timestep of the f32 time loop, summed per wave and added up over all waves at the end of the launch:
+//   [0] input assembly (LDS row read, v_readlane of the filter states)   [1] neuron groups (encode, LIF step, decode)
+//   [2] wave reduction + publication of the wave sums in LDS              [3] wait at the workgroup barrier
+//   [4] totals over the waves, filter update, hand-off to the post stage  [5] wave-timesteps counted
+//   [6] / [7] s_memtime / s_memrealtime ticks of workgroup 0's time loop (shader clock = 100 MHz * [6] / [7])
+__device__ unsigned long long g_block_stamps[8];
+inline hipError_t read_block_stamps(unsigned long long* out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_stamps), sizeof(unsigned long long) * 8);
+  if (e == hipSuccess && reset) {
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_block_stamps), z, sizeof z);
+  }
+  return e;
+}
+#define SSN_BSTAMP(var)                                                                          \
+  do {                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory");                \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  } while (0)
+#define SSN_BSTAMP_ADD(i, a, b) bst[i] += (b) - (a)
+#else
+#define SSN_BSTAMP(var) do {} while (0)
+#define SSN_BSTAMP_ADD(i, a, b) do {} while (0)
+#endif
+
 // Neurons are dealt to threads in groups of PK adjacent neurons (PK = 2 for f32: one 64-bit register pair,
 // 1 for f64): neuron index of (group g, thread tid, component c) = (g * nthr + tid) * PK + c - coalesced.
 //
@@ -320,6 +348,10 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
 #pragma unroll
       for (int d = 0; d < LDSW; ++d) en[u][d] = *lds_group(d, u);
   }
+#ifdef SSN_BLOCK_STAMPS
+  unsigned long long bst[5] = {0, 0, 0, 0, 0}, bt0 = 0, bt1 = 0, bt2 = 0, bt3 = 0, bt4 = 0, bt5 = 0, bm0 = 0, br0 = 0;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(bm0), "=s"(br0) :: "memory");
+#endif
   for (int j0 = 0; j0 < a.B; j0 += CH) {
     const int cn = min(CH, a.B - j0);
     __syncthreads();                         // previous chunk: every wave is past its last xs read / os write
@@ -336,6 +368,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
     __syncthreads();
 
     for (int jj = 0; jj < cn; ++jj) {
+      SSN_BSTAMP(bt0);
       T xin[XP];
       if constexpr (sizeof(T) == 4) *(float4*)xin = *(const float4*)xs[jj];
       else { *(double2*)xin = *(const double2*)xs[jj]; *(double2*)(xin + 2) = *(const double2*)(xs[jj] + 2); }
@@ -358,6 +391,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
           x[d] = xr[d] >= 0 ? xin[d] + xa[d] * st : xin[d];
         }
       }
+      SSN_BSTAMP(bt1);
       G accg[DOUT];
 #pragma unroll
       for (int r = 0; r < DOUT; ++r) accg[r] = G(0);
@@ -437,6 +471,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
 #endif
       }
       const int par = jj & 1;
+      SSN_BSTAMP(bt2);
       if constexpr (F32) {
         float acc[DOUT];
 #pragma unroll
@@ -462,7 +497,9 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
             for (int r = 0; r < DOUT; ++r) red[par][r * 16 + wave] = acc[r];
           }
         }
+        SSN_BSTAMP(bt3);
         __syncthreads();
+        SSN_BSTAMP(bt4);
         v0 = row_sum_dpp(red[par][lane]);                          // row r of every wave: total of decoded row r
         F0 = __builtin_fmaf(la0, F0, lb0 * v0);                    // rows without a filter: la = lb = 0
         if constexpr (DOUT > 4) {
@@ -473,6 +510,9 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
           if ((lane & 15) == 0 && (lane >> 4) < DOUT) os[jj][lane >> 4] = v0;
           if (DOUT > 4 && lane == 0) os[jj][4] = v1;
         }
+        SSN_BSTAMP(bt5);
+        SSN_BSTAMP_ADD(0, bt0, bt1); SSN_BSTAMP_ADD(1, bt1, bt2); SSN_BSTAMP_ADD(2, bt2, bt3); SSN_BSTAMP_ADD(3, bt3, bt4);
+        SSN_BSTAMP_ADD(4, bt4, bt5);
       } else {
         T acc[DOUT];
 #pragma unroll
@@ -501,6 +541,17 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
       }
     }
   }
+#ifdef SSN_BLOCK_STAMPS
+  if constexpr (F32) {
+    unsigned long long bm1, br1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(bm1), "=s"(br1) :: "memory");
+    if (lane == 0) {
+      for (int i = 0; i < 5; ++i) atomicAdd(&g_block_stamps[i], bst[i]);
+      atomicAdd(&g_block_stamps[5], (unsigned long long)a.B);
+      if (k == 0 && wave == 0) { atomicAdd(&g_block_stamps[6], bm1 - bm0); atomicAdd(&g_block_stamps[7], br1 - br0); }
+    }
+  }
+#endif
   __syncthreads();
   {                                          // last chunk's decoded rows
     const int j0 = (a.B - 1) / CH * CH, cn = a.B - j0;

@@ -5,3 +5,6 @@ namespace ssn { SSN_INSTANTIATE(float) }
 #ifdef SSN_PROGRAM_STAMPS
 extern "C" int ssn_debug_program_stamps(unsigned long long* out, int n) { return (int)ssn::read_program_stamps(out, n); }
 #endif
+#ifdef SSN_BLOCK_STAMPS
+extern "C" int ssn_debug_block_stamps(unsigned long long* out, int reset) { return (int)ssn::read_block_stamps(out, reset); }
+#endif

@@ -145,6 +145,38 @@ def collapse_glue(ops, model, op_access, protected):
     # if that was the last one; on the device it is one dependency level - one launch - less in front of the operator.
     # Reads precede updates within a timestep, so a filter state read directly is still the previous step's value.
     input_field = {"matvec": ("src", "cols"), "cleanup": ("src", "cols"), "lowpass": ("src", "len"), "neurons": ("j", "n")}
+    filters = [o for o in hard if o["kind"] == "lowpass"]
+
+    def _resolved_sources(lo, ln):
+        """Signal ranges a read of [lo, lo + ln) really depends on: pure glue segments are looked through."""
+        out_r = []
+        for i in seg.cover(lo, lo + ln):
+            if pure[i]:
+                try:
+                    _, terms = expr(i)
+                except ValueError:
+                    terms = {}
+                out_r.extend(seg.span(j) for j in terms)
+            else:
+                out_r.append(seg.span(i))
+        return out_r
+
+    def _closes_update_cycle(op, new_lo, ln):
+        """Would `op` (a filter: it reads its source, then updates its state) reading [new_lo, new_lo + ln) directly sit on a
+        cycle of filters that read each other's STATE?  The scheduler orders every reader of a state before the state's
+        update, so filter A reading B's state and B reading A's (two pass-through nodes joined by synapses in both
+        directions) has no order; with the copy in between, the copy is the reader and both filters update afterwards."""
+        seen, todo = set(), [(new_lo, new_lo + ln)]
+        while todo:
+            lo, hi = todo.pop()
+            for f in filters:
+                if id(f) in seen or f["dst"] >= hi or f["dst"] + f["len"] <= lo:
+                    continue
+                if f is op:
+                    return True
+                seen.add(id(f))
+                todo.extend(_resolved_sources(f["src"], f["len"]))
+        return False
     changed = True
     while changed:
         changed = False
@@ -173,6 +205,8 @@ def collapse_glue(ops, model, op_access, protected):
                 off = d
             if off is None or off == 0:
                 continue
+            if o["kind"] == "lowpass" and _closes_update_cycle(o, lo0 + off, ln):
+                continue              # keep the copy: two filters reading each other's state directly cannot be ordered
             src_segs = list(seg.cover(lo0 + off, lo0 + off + ln))
             hard_r[segs] -= 1
             hard_r[src_segs] += 1

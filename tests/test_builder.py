@@ -227,3 +227,34 @@ def test_glue_collapse_keeps_the_trajectory_and_cuts_the_levels():
     assert any(o["kind"] == "lincomb" for o in res[True][4]) and not any(o["kind"] == "lincomb" for o in res[False][4])
     st = res[True][5]
     assert st["glue_inlined_segments"] > 0 and st["glue_glue_out"] < st["glue_glue_in"]
+
+
+def test_two_pass_through_nodes_joined_by_synapses_in_both_directions():
+    """ADVICE r2 (glue.py copy propagation): a -> b through Lowpass(10 ms) and b -> a through Lowpass(20 ms), a and b
+    pass-through nodes.  Retargeting both filters onto each other's STATE leaves the scheduler a cycle (each must read the
+    other's state before that state is updated); the copy has to stay.  Both builds step to the same trajectory."""
+    def net():
+        with nengo.Network(seed=1) as m:
+            drive = nengo.Node(lambda t: [np.sin(8 * t), np.cos(5 * t)])
+            a = nengo.Node(size_in=2, label="a")
+            b = nengo.Node(size_in=2, label="b")
+            nengo.Connection(drive, a, synapse=None)
+            nengo.Connection(a, b, synapse=0.01)
+            nengo.Connection(b, a, synapse=0.02, transform=0.5)
+            pa, pb = nengo.Probe(a), nengo.Probe(b)
+        return m
+    res = {}
+    for collapse in (False, True):
+        model = build(net(), collapse=collapse)             # (used to raise "operator graph has a cycle within one timestep")
+        sim = OracleSimulator(model)
+        sim.run_steps(200)
+        res[collapse] = (sim.probe_data(0), sim.probe_data(1))
+    assert np.abs(res[False][1]).max() > 0.05
+    for x, y in zip(res[True], res[False]):
+        np.testing.assert_allclose(x, y, atol=1e-13, rtol=0)
+    # the retargeting itself still happens where no such cycle exists (the SLAM network: 10 inputs)
+    from sspslam_amd import harness as H
+    s = H.make_ssp_space(2, 55)
+    path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
+    sm = H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=60, mem_n_neurons=120, circonv_n_neurons=30, view_rad=0.6)
+    assert build(sm.model).stats["glue_retargeted_inputs"] >= 10

@@ -180,8 +180,16 @@ static void run(int threads, int iters, float* sink, unsigned long long* d_c, un
   const double med = (double)c[waves / 2], medr = (double)r[waves / 2];
   const int wps = threads / 256;      // waves per SIMD
   const double mhz = med / medr * 100.0;
-  printf("%-86s waves/SIMD %d  cycles/inst/wave %6.2f  SIMD cycles per wave-instruction %5.2f  clock %4.0f MHz  kernel %.3f ms\n",
-         kind_name[KIND], wps, med / n_inst, med / n_inst / wps, mhz, ms);
+  // Two bases.  (a) per-wave stamps: the MEDIAN wave's s_memtime ticks per instruction, divided by the resident waves - only
+  //     right when the waves of a SIMD share it evenly.  They do not at 3 waves per SIMD: the issue arbiter serves two of the
+  //     three and the third runs once one of them has finished (min / max columns: the slow waves take ~1.5x the median), so
+  //     the median understates the SIMD's time per instruction.  (b) the launch's wall time (HIP events) over all the
+  //     instructions a SIMD issued: ns of SIMD time per wave-instruction, whatever the arbitration and whatever the clock
+  //     did under load - the basis bench.py prices the roofline with.
+  const double ns_simd = 1e6 * ms / (n_inst * wps);
+  printf("%-86s waves/SIMD %d  cycles/inst/wave %6.2f  SIMD cycles per wave-instruction %5.2f  clock %4.0f MHz  kernel %.3f ms  "
+         "wave cycles/inst min %6.2f max %6.2f  SIMD ns per wave-instruction (kernel time) %.3f\n",
+         kind_name[KIND], wps, med / n_inst, med / n_inst / wps, mhz, ms, (double)c[0] / n_inst, (double)c[waves - 1] / n_inst, ns_simd);
   hipEventDestroy(e0); hipEventDestroy(e1);
 }
 
