@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSN_ABI_VERSION 5
+#define SSN_ABI_VERSION 6
 
 enum ssn_status {
   SSN_OK = 0,
@@ -241,6 +241,34 @@ int ssn_run_phase(ssn_sim* sim, int32_t phase);
 int64_t ssn_exchange_size(ssn_sim* sim);
 int ssn_exchange_pack(ssn_sim* sim, void* dst_dev);
 int ssn_exchange_unpack(ssn_sim* sim, const void* src_dev);
+
+/* Stream-ordered stepping of a neuron-sharded model: no host synchronisation per timestep (SURVEY 8b "no callbacks into Python
+ * from the step loop", 8e; the loop it serves closes every timestep: reference networks/slam.py:259,306-307).  Enqueues, as ONE
+ * graph launch on `hip_stream` (a hipStream_t of the caller - the stream its collective is ordered on, e.g. the current stream of
+ * torch.distributed's RCCL backend; NULL = the simulator's own stream), and returns without waiting:
+ *   [phase 1 / 2: exchange_buf (the all-reduced sums) -> the exchange ranges]  the phase's kernels
+ *   [phase 0 / 2: the exchange ranges (this rank's partial sums) -> exchange_buf]
+ * exchange_buf: device buffer of ssn_exchange_size() elements of the simulator's dtype, the same pointer throughout a run (it is
+ * captured into the graphs); NULL when the caller does not exchange (a single rank).  A run is
+ *   ssn_phase_async(0), [collective on hip_stream], ssn_phase_async(2), [collective], ..., ssn_phase_async(1), ssn_phase_sync. */
+int ssn_phase_async(ssn_sim* sim, int32_t phase, void* exchange_buf, void* hip_stream);
+/* Waits for everything ssn_phase_async enqueued on that stream; checks the device step counter and the probe-overflow flag. */
+int ssn_phase_sync(ssn_sim* sim, void* hip_stream);
+
+/* Measurement aid for the roofline of the VALU-bound whole-block kernel (bench.py; not on the step path): `iters` x 64 independent
+ * wave64 instructions of one kind per wave, one workgroup of 256 x waves_per_simd threads on every CU; reports the nanoseconds of
+ * SIMD time per wave instruction from the launch's HIP-event time (and the shader clock during the launch, s_memtime ticks per
+ * 100 MHz s_memrealtime tick).  csrc/ssn_probe.hip. */
+enum ssn_probe_kind {
+  SSN_PROBE_PK_FMA = 0, SSN_PROBE_PK_MUL = 1, SSN_PROBE_PK_ADD = 2,   /* v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32            */
+  SSN_PROBE_TRANS = 3,                                                /* v_rcp_f32 (v_log_f32 issues at the same rate)        */
+  SSN_PROBE_FMA = 4, SSN_PROBE_ADD = 5,                               /* v_fma_f32; v_add_f32 (v_mul_f32, v_sub_f32)          */
+  SSN_PROBE_DPP = 6, SSN_PROBE_MOV = 7, SSN_PROBE_READLANE = 8,       /* v_add_f32_dpp; v_mov_b32; v_readlane_b32             */
+  SSN_PROBE_CNDMASK = 9, SSN_PROBE_OTHER = 10,                        /* v_cndmask_b32 (vcc); v_max_i32 (every other VALU op) */
+  SSN_PROBE_N_KINDS = 11
+};
+int ssn_probe_issue_rate(int32_t device, int32_t kind, int32_t waves_per_simd, int32_t iters,
+                         double* ns_per_wave_instruction, double* shader_mhz);
 
 int ssn_get_counters(ssn_sim* sim, ssn_counters* out);
 /* Fills at most `capacity` entries; returns the number of kernels with timed launches (or a negative status). */

@@ -9,12 +9,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSN_HIP_LIB") or os.path.join(_HERE, "libssn_hip.so")     # override: A/B builds of the library
 
-SSN_ABI_VERSION = 5
+SSN_ABI_VERSION = 6
 SSN_F32, SSN_F64 = 0, 1
 SSN_BUF_REAL, SSN_BUF_I32 = 0, 1
 NEURON_CODE = {"lif": 0, "lifrate": 1, "relu": 2}
 OP_CODE = {"fill": 1, "table": 2, "axpy": 3, "matvec": 4, "lowpass": 5, "ensarray": 6, "neurons": 7,
            "pes": 8, "voja": 9, "cleanup": 10, "gate": 11, "lincomb": 12}
+PROBE_KINDS = {"v_pk_fma_f32": 0, "v_pk_mul_f32": 1, "v_pk_add_f32": 2, "trans": 3, "v_fma_f32": 4, "v_add_f32": 5, "dpp": 6,
+               "v_mov_b32": 7, "lane": 8, "v_cndmask_b32": 9, "other": 10}
 STATUS = {0: "SSN_OK", -1: "SSN_EINVAL", -2: "SSN_EHIP", -3: "SSN_ERCCL", -4: "SSN_ENOMEM", -5: "SSN_EUNSUPPORTED"}
 
 
@@ -77,6 +79,9 @@ EXPORTS = {
     "ssn_exchange_size": (C.c_int64, [C.c_void_p]),
     "ssn_exchange_pack": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ssn_exchange_unpack": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ssn_phase_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "ssn_phase_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ssn_probe_issue_rate": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ssn_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "ssn_get_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTime), C.c_int32]),
     "ssn_n_steps": (C.c_int64, [C.c_void_p]),

@@ -92,17 +92,22 @@ __device__ inline f32x2 pk_mul_clamp01_vv(f32x2 x, f32x2 y) {
   asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "v"(y));
   return r;
 }
-__device__ inline f32x2 pk_fma1_clamp01(f32x2 x, f32x2 y) {          // clamp(x * y + 1)
+__device__ inline f32x2 pk_fma_clamp01_vsv(f32x2 x, f32x2 y, f32x2 z) {          // clamp(x * y + z), y a uniform constant pair
   f32x2 r;
-  asm("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel_hi:[1,1,0] clamp" : "=v"(r) : "v"(x), "s"(y));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(x), "s"(y), "v"(z));
+  return r;
+}
+__device__ inline f32x2 pk_fma_clamp01_vvs(f32x2 x, f32x2 y, f32x2 z) {          // clamp(x * y + z), z a uniform constant pair
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(x), "v"(y), "s"(z));
   return r;
 }
 
 // Branch-free f32 LIF step, TWO neurons per call in the two halves of 64-bit register pairs, built ONLY from packed
 // multiply / add / FMA (v_pk_*_f32: 2 flops per lane per issue slot) plus one v_rcp_f32 and one v_log_f32 per neuron:
 // no compare, no select, no integer min / max.  On gfx950 every non-FMA vector instruction (v_cndmask, v_cmp, v_max_i32,
-// v_med3 ...) costs a full 4-cycle issue slot of its own per NEURON where a packed one serves two (measured:
-// tools/valu_issue_rate.hip, profiles/round2_valu_issue_rate.txt), so the selects of nengo's LIF step (SURVEY
+// v_med3 ...) costs a full issue slot of its own per NEURON where a packed one serves two (v_cndmask: five of them - measured,
+// tools/valu_issue_rate.hip, profiles/round3_valu_issue_rate.txt), so the selects of nengo's LIF step (SURVEY
 // Appendix A.4) are rewritten as exact arithmetic on {0, 1} indicators made with the clamp modifier:
 //
 //   state word s:  s >= 0  voltage of a non-refractory neuron (<= 1);  s < 0  -(R - dt), R = refractory time left at the
@@ -116,13 +121,16 @@ __device__ inline f32x2 pk_fma1_clamp01(f32x2 x, f32x2 y) {          // clamp(x 
 //   em = delta * P(delta)         -expm1(-delta / tau_rc) = x - x^2/2 + x^3/6 - x^4/24, x = delta / tau_rc <= 1/20: the first
 //                                 neglected term is x^4/120 < 5.3e-8 of the result (half an f32 ulp)
 //   V  = V0 + (J - V0) * em
-//   spk = clamp((V - 1) * 2^24)   1 if V > 1 (V - 1 is exact and >= 2^-23 then), else 0;   nspk = clamp(1 - (V - 1) * 2^24)
-//   jm1s = (J - 1) * spk + nspk   J - 1 of a spiking neuron, 1 otherwise: rcp / log never see the junk of silent neurons
-//   u  = -(tau_ref + tau_rc * ln(1 - (V - 1) / jm1s))       new state word of a spiking neuron (tau_ref + t_spike - dt)
-//   Vn = clamp(V * nspk)          voltage of a silent neuron clamped at min_voltage 0 (V <= 1), 0 for a spiking one
-//   s' = spk * u + (mt + Vn)      (spiking: mt = Vn = 0; silent: spk = 0 - exact selects, products with 0 / 1)
+//   spk = clamp((V - 1) * 2^24)   1 if V > 1 (V - 1 is exact and >= 2^-23 then), else 0
+//   nu = clamp(tau_ref + tau_rc * ln(1 - (V - 1) / (J - 1)))      MINUS the new state word of a spiking neuron (tau_ref +
+//                                 t_spike - dt, in [tau_ref - dt, tau_ref] - inside [0, 1] because tau_ref >= dt).  A silent
+//                                 neuron feeds rcp / log whatever its J - 1 and V - 1 are (0, negative: inf, NaN); the clamp
+//                                 turns any of it into a number in [0, 1] (DX10 clamp: NaN -> 0) and spk = 0 discards it -
+//                                 round 2 guarded the operand instead ((J - 1) * spk + nspk): two packed operations more
+//   Vn = clamp(V - spk * 2^24)    voltage of a silent neuron clamped at min_voltage 0 (V <= 1), 0 for a spiking one
+//   s' = (mt + Vn) - spk * nu     (spiking: mt = Vn = 0; silent: spk = 0 - exact selects, products with 0 / 1)
 // Requires dt / tau_rc <= 1/20 and tau_ref >= dt (checked by the host planner).
-struct LifConstV2 { float dt, a1, a2, a3, a4, neg_tau_ln2, neg_tau_ref; };
+struct LifConstV2 { float dt, a1, a2, a3, a4, tau_ln2, tau_ref; };
 
 __device__ inline f32x2 lif_packed_step_f32x2(f32x2 J, f32x2& s, const LifConstV2& c, f32x2 big, f32x2 nbig) {
   const f32x2 V0 = pk_clamp01(s);
@@ -140,18 +148,16 @@ __device__ inline f32x2 lif_packed_step_f32x2(f32x2 J, f32x2& s, const LifConstV
   const f32x2 V = __builtin_elementwise_fma(J - V0, em, V0);
   const f32x2 vm1 = V - 1.0f, jm1 = J - 1.0f;
   const f32x2 spk = pk_mul_clamp01(vm1, big);
-  const f32x2 nspk = pk_fma1_clamp01(vm1, nbig);
-  const f32x2 jm1s = __builtin_elementwise_fma(jm1, spk, nspk);
   f32x2 rc;
-  rc.x = __builtin_amdgcn_rcpf(jm1s.x);
-  rc.y = __builtin_amdgcn_rcpf(jm1s.y);
+  rc.x = __builtin_amdgcn_rcpf(jm1.x);
+  rc.y = __builtin_amdgcn_rcpf(jm1.y);
   const f32x2 omu = __builtin_elementwise_fma(-vm1, rc, (f32x2)(1.0f));     // 1 - (V - 1) / (J - 1)
   f32x2 lg2;
   lg2.x = __builtin_amdgcn_logf(omu.x);
   lg2.y = __builtin_amdgcn_logf(omu.y);
-  const f32x2 u = __builtin_elementwise_fma((f32x2)(c.neg_tau_ln2), lg2, (f32x2)(c.neg_tau_ref));
-  const f32x2 Vn = pk_mul_clamp01_vv(V, nspk);
-  s = __builtin_elementwise_fma(spk, u, mt + Vn);
+  const f32x2 nu = pk_fma_clamp01_vvs(lg2, (f32x2)(c.tau_ln2), (f32x2)(c.tau_ref));
+  const f32x2 Vn = pk_fma_clamp01_vsv(spk, nbig, V);
+  s = __builtin_elementwise_fma(-spk, nu, mt + Vn);
   return spk;
 }
 
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   //  packed instructions of the time loop can take them as their one constant-bus operand)
   auto uni = [](float v) { return bits_f(__builtin_amdgcn_readfirstlane(f_bits(v))); };
   const LifConstV2 lc{uni((float)np.dt), uni(itau), uni(-0.5f * itau * itau), uni(itau * itau * itau / 6.0f),
-                      uni(-itau * itau * itau * itau / 24.0f), uni(-(float)np.tau_rc * 0.6931471805599453f), uni(-(float)np.tau_ref)};
+                      uni(-itau * itau * itau * itau / 24.0f), uni((float)np.tau_rc * 0.6931471805599453f), uni((float)np.tau_ref)};
   const f32x2 big = {16777216.0f, 16777216.0f}, nbig = {-16777216.0f, -16777216.0f};
 
   // ---- parameters and state of this thread's neurons -> registers ---------------------------------------------
@@ -375,11 +381,13 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
       T x[DIN];
       if constexpr (F32) {
         // the filter states the inputs read: row xr[d] of the lane-distributed registers (uniform lane index)
-        const float f1 = bits_f(__builtin_amdgcn_readlane(f_bits(F1), 0));
+        float f1 = 0.0f;
+        if constexpr (DOUT > 4) f1 = bits_f(__builtin_amdgcn_readlane(f_bits(F1), 0));
 #pragma unroll
         for (int d = 0; d < DIN; ++d) {
           const float f0 = bits_f(__builtin_amdgcn_readlane(f_bits(F0), (xr[d] & 3) << 4));
-          const float st = xr[d] >= 4 ? f1 : f0;
+          float st = f0;                                            // (a v_cndmask costs five issue slots: only where a fifth row exists)
+          if constexpr (DOUT > 4) st = xr[d] >= 4 ? f1 : f0;
           x[d] = __builtin_fmaf(xa[d], st, xin[d]);                 // (xa = 0 where no state feeds the input)
         }
       } else {

@@ -44,6 +44,14 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+}  // namespace
+namespace ssn {
+int probe_fail(int code, const char* what, hipError_t e) {
+  return e == hipSuccess ? fail(code, "%s", what) : fail(code, "%s failed: %s", what, hipGetErrorString(e));
+}
+}  // namespace ssn
+namespace {
+
 #define HIPCHK(expr)                                                                              \
   do {                                                                                            \
     hipError_t e__ = (expr);                                                                      \
@@ -89,6 +97,8 @@ struct ssn_sim {
   virtual int run_phase(int phase) = 0;
   virtual int64_t exchange_size() = 0;
   virtual int exchange_copy(void* buf, bool pack) = 0;
+  virtual int phase_async(int phase, void* buf, hipStream_t ext) = 0;
+  virtual int phase_sync(hipStream_t ext) = 0;
   virtual int read_probe(int id, double* dst, void* dst_dev, int64_t first, int64_t count) = 0;
   virtual int64_t probe_count(int id) = 0;
   virtual int rw_signal(int64_t off, int64_t count, double* dst, const double* src) = 0;
@@ -212,6 +222,12 @@ struct Sim final : ssn_sim {
   int next_phase = 0;
   hipGraphExec_t phase_exec[3] = {nullptr, nullptr, nullptr};      // [2]: phase 1 of a timestep followed by phase 0 of the next
   hipGraph_t phase_graph[3] = {nullptr, nullptr, nullptr};
+  // stream-ordered stepping (ssn_phase_async): the same halves with the exchange copies inside the graph, for one exchange
+  // buffer of the caller; launched on the caller's stream, no host synchronisation per timestep
+  hipGraphExec_t async_exec[3] = {nullptr, nullptr, nullptr};
+  hipGraph_t async_graph[3] = {nullptr, nullptr, nullptr};
+  void* async_buf = nullptr;
+  bool async_captured = false, async_active = false;
   static constexpr int N_ITEM_TYPES = 16;
   double type_ms[N_ITEM_TYPES] = {};             // profile = 2: device time per plan-item type
   int64_t type_launches[N_ITEM_TYPES] = {};
@@ -226,6 +242,8 @@ struct Sim final : ssn_sim {
     for (int h = 0; h < 3; ++h) {
       if (phase_exec[h]) hipGraphExecDestroy(phase_exec[h]);
       if (phase_graph[h]) hipGraphDestroy(phase_graph[h]);
+      if (async_exec[h]) hipGraphExecDestroy(async_exec[h]);
+      if (async_graph[h]) hipGraphDestroy(async_graph[h]);
     }
     for (auto& b : bufs) if (b.d) hipFree(b.d);
     for (auto p : table_rows) if (p) hipFree(p);
@@ -2408,6 +2426,71 @@ struct Sim final : ssn_sim {
     return SSN_OK;
   }
 
+  hipError_t exchange_copy_async(void* buf, bool pack, hipStream_t st) {
+    T* b = (T*)buf;
+    for (auto& r : exchange) {
+      const size_t bytes = (size_t)(r.hi - r.lo) * sizeof(T);
+      hipError_t e = pack ? hipMemcpyAsync(b, sig + r.lo, bytes, hipMemcpyDeviceToDevice, st)
+                          : hipMemcpyAsync(sig + r.lo, b, bytes, hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return e;
+      b += r.hi - r.lo;
+    }
+    return hipSuccess;
+  }
+
+  // (Re)capture the three phase graphs with the exchange copies of `buf` inside: [unpack] -> kernels -> [pack].
+  int capture_async(void* buf) {
+    for (int h = 0; h < 3; ++h) {
+      if (async_exec[h]) { hipGraphExecDestroy(async_exec[h]); async_exec[h] = nullptr; }
+      if (async_graph[h]) { hipGraphDestroy(async_graph[h]); async_graph[h] = nullptr; }
+    }
+    for (int h = 0; h < 3; ++h) {
+      HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      hipError_t e = hipSuccess;
+      if (h >= 1 && buf) e = exchange_copy_async(buf, false, stream);
+      if (e == hipSuccess) e = launch_phase(h == 2 ? 1 : h);
+      if (h == 2 && e == hipSuccess) e = launch_phase(0);
+      if (h != 1 && buf && e == hipSuccess) e = exchange_copy_async(buf, true, stream);
+      hipError_t e2 = hipStreamEndCapture(stream, &async_graph[h]);
+      HIPCHK(e);
+      HIPCHK(e2);
+      HIPCHK(hipGraphInstantiate(&async_exec[h], async_graph[h], nullptr, nullptr, 0));
+    }
+    async_buf = buf;
+    async_captured = true;
+    return SSN_OK;
+  }
+
+  int phase_async(int phase, void* buf, hipStream_t ext) override {
+    HIPCHK(hipSetDevice(device));
+    if (!phased) return fail(SSN_EINVAL, "ssn_phase_async: the model has no exchange ranges (use ssn_run_steps)");
+    if (phase < 0 || phase > 2) return fail(SSN_EINVAL, "ssn_phase_async(%d): 0, 1 or 2 (= 1 followed by the next timestep's 0)", phase);
+    if ((phase == 2 ? 1 : phase) != next_phase) return fail(SSN_EINVAL, "ssn_phase_async(%d): phase %d is due", phase, next_phase);
+    if (!async_active) {
+      HIPCHK(hipStreamSynchronize(stream));          // uploads / table updates issued on the simulator's own stream come first
+      if (!async_captured || buf != async_buf) CHK(capture_async(buf));
+      async_active = true;
+    } else if (buf != async_buf) {
+      return fail(SSN_EINVAL, "ssn_phase_async: the exchange buffer changed inside a run (call ssn_phase_sync first)");
+    }
+    HIPCHK(hipGraphLaunch(async_exec[phase], ext ? ext : stream));
+    next_phase = phase == 0 ? 1 : (phase == 1 ? 0 : 1);
+    if (phase >= 1) steps_done += 1;
+    return SSN_OK;
+  }
+
+  int phase_sync(hipStream_t ext) override {
+    HIPCHK(hipSetDevice(device));
+    if (!phased) return fail(SSN_EINVAL, "ssn_phase_sync: the model has no exchange ranges");
+    HIPCHK(hipStreamSynchronize(ext ? ext : stream));
+    async_active = false;
+    ssn::StepCtx ctx;
+    HIPCHK(hipMemcpy(&ctx, d_ctx, sizeof ctx, hipMemcpyDeviceToHost));
+    if (ctx.step != steps_done) return fail(SSN_EHIP, "device step counter %lld != host %lld", (long long)ctx.step, (long long)steps_done);
+    if (ctx.probe_overflow) return fail(SSN_EINVAL, "probe storage overflow: call ssn_reserve_probes before stepping");
+    return SSN_OK;
+  }
+
   int run_steps(int64_t n, int profile) override {
     HIPCHK(hipSetDevice(device));
     if (phased) return fail(SSN_EINVAL, "a neuron-sharded model is stepped with ssn_run_phase (the caller exchanges between the phases)");
@@ -2811,6 +2894,10 @@ int ssn_exchange_unpack(ssn_sim* sim, const void* src_dev) {
   if (!sim || !src_dev) return fail(SSN_EINVAL, "null argument");
   return sim->exchange_copy(const_cast<void*>(src_dev), false);
 }
+int ssn_phase_async(ssn_sim* sim, int32_t phase, void* exchange_buf, void* hip_stream) {
+  return sim ? sim->phase_async(phase, exchange_buf, (hipStream_t)hip_stream) : fail(SSN_EINVAL, "null simulator");
+}
+int ssn_phase_sync(ssn_sim* sim, void* hip_stream) { return sim ? sim->phase_sync((hipStream_t)hip_stream) : fail(SSN_EINVAL, "null simulator"); }
 int ssn_get_kernel_times(ssn_sim* sim, ssn_kernel_time* out, int32_t capacity) {
   if (!sim || (!out && capacity > 0) || capacity < 0) return fail(SSN_EINVAL, "null argument");
   return sim->kernel_times(out, capacity);
@@ -2821,6 +2908,6 @@ int ssn_device_count(void) {
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 const char* ssn_last_error(void) { return g_err.c_str(); }
-const char* ssn_version(void) { return "libssn_hip 0.6 (gfx950, ABI 5)"; }
+const char* ssn_version(void) { return "libssn_hip 0.7 (gfx950, ABI 6)"; }
 
 }  // extern "C"

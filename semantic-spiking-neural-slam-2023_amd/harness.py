@@ -121,13 +121,17 @@ class SlamModel:
 def make_slam_model(ssp_space, path, vels, n_landmarks=10, pi_n_neurons=500, mem_n_neurons=None,
                     circonv_n_neurons=100, view_rad=0.2, update_thres=0.2, shift_rate=0.2,
                     voja_learning_rate=1e-4, pes_learning_rate=5e-3, intercept=0.1, tau_pi=0.05, seed=0,
-                    dt=0.001, init_time=0.05, weights_sample_every=None):
-    """The model of ``run_slam.py:95-195`` (multi-landmark inputs, ``get_slam_input_functions2``)."""
+                    dt=0.001, init_time=0.05, weights_sample_every=None, obj_locs=None):
+    """The model of ``run_slam.py:95-195`` (multi-landmark inputs, ``get_slam_input_functions2``).  ``obj_locs``: landmark
+    positions (default: the script's ``0.9 * 2 * (Rd_sampling - 0.5)``, ``run_slam.py:119``) - tests place a landmark next to the
+    start of the path so that PES and Voja learn from the first timesteps."""
     d = ssp_space.ssp_dim
     domain_dim = ssp_space.domain_dim
     if mem_n_neurons is None:
         mem_n_neurons = 10 * d
-    obj_locs = 0.9 * 2 * (Rd_sampling(n_landmarks, domain_dim, seed=seed) - 0.5)
+    if obj_locs is None:
+        obj_locs = 0.9 * 2 * (Rd_sampling(n_landmarks, domain_dim, seed=seed) - 0.5)
+    obj_locs = np.asarray(obj_locs, dtype=float).reshape(n_landmarks, domain_dim)
     vec_to_landmarks = obj_locs[None, :, :] - path[:, None, :]
     lm_space = SPSpace(n_landmarks, d, seed=seed)
     real_ssp = ssp_space.encode(path)
@@ -160,6 +164,24 @@ def make_slam_model(ssp_space, path, vels, n_landmarks=10, pi_n_neurons=500, mem
     out.model, out.real_ssp, out.ssp_space, out.lm_space = model, real_ssp, ssp_space, lm_space
     out.obj_locs, out.path, out.vels, out.vel_scaling_factor = obj_locs, path, vels, vel_scaling_factor
     return out
+
+
+def make_config3_model(seed=0, T=20.0, dt=0.001, landmark_near_start=True, pi_n_neurons=10000, mem_n_neurons=10150,
+                       circonv_n_neurons=100, n_landmarks=10, ssp_dim=1015, view_rad=0.2, weights_sample_every=None):
+    """BASELINE configs[2]: SLAMNetwork 2-D, ssp_dim 1015, 10 000 neurons per VCO, 10 150 memory neurons, 10 landmarks
+    (reference ``experiments/run_slam.py:24-31,180-185``), on the synthetic path of SURVEY 8d - ONE definition for
+    ``bench.py``'s SLAM leg and the full-size GPU parity test.  ``landmark_near_start``: landmark 0 is moved to 0.07 from the
+    path's first point (inside ``view_rad`` = 0.2), so that the landmark inputs, PES and Voja are live from the first
+    timesteps - with the script's ``Rd_sampling`` positions the first landmark comes into view after ~200 timesteps, past any
+    window the NumPy oracle can follow at this size."""
+    space = make_ssp_space(2, ssp_dim)
+    path, vels = make_random_path(T, dt=dt, limit=0.1, seed=seed)
+    obj = 0.9 * 2 * (Rd_sampling(n_landmarks, 2, seed=seed) - 0.5)
+    if landmark_near_start:
+        obj[0] = path[0] + np.array([0.05, 0.05])
+    return make_slam_model(space, path, vels, n_landmarks=n_landmarks, pi_n_neurons=pi_n_neurons, mem_n_neurons=mem_n_neurons,
+                           circonv_n_neurons=circonv_n_neurons, view_rad=view_rad, seed=seed, dt=dt,
+                           weights_sample_every=weights_sample_every, obj_locs=obj)
 
 
 def make_slamview_model(ssp_space, path, vels, n_landmarks=10, pi_n_neurons=500, mem_n_neurons=None,

@@ -65,7 +65,7 @@ class ShardedPathIntegration:
         if sim_factory is None:
             from .simulator import Simulator
 
-            def sim_factory(model, flags=flags):
+            def sim_factory(model, flags=0):
                 return Simulator(None, model=model, dtype=dtype, device=device, block_steps=block_steps, flags=flags)
         self._sim_factory, self._flags = sim_factory, flags
         self.gather_device = gather_device
@@ -97,7 +97,7 @@ class ShardedPathIntegration:
         probes = [self.osc_probe] if self.osc_probe is not None else []
         self.model = build(pm.model, dt=dt, n_eval_points=n_eval_points, vco_shard=(rank, world),
                            probes=probes, prune=True)
-        self.sim = sim_factory(self.model)
+        self.sim = self._make_sim(self.model, flags)
         # --- rank 0: the read-out replayed from gathered blocks ---------------------------------------
         self.readout = None
         if rank == 0:
@@ -110,7 +110,7 @@ class ShardedPathIntegration:
                 nengo.Connection(src, out, transform=pi.to_SSP)       # default synapse, as pathintegration.py:191
                 self.ro_probe = nengo.Probe(out, synapse=psyn)
             self.readout_model = build(ro, dt=dt)
-            self.readout = sim_factory(self.readout_model)
+            self.readout = self._make_sim(self.readout_model, 0)      # (the shard's plan switches do not concern the read-out)
         self.n_steps = 0
         # rank 0 replays block b through the read-out on a worker thread while every rank already steps
         # block b+1 (the library releases the GIL; the two simulators have their own HIP streams)
@@ -121,6 +121,21 @@ class ShardedPathIntegration:
             self._worker.start()
         self._warm = False
 
+    def _make_sim(self, model, flags):
+        """``sim_factory(model)`` is the documented injection contract (the oracle-backed test factories follow it); a factory
+        that also understands plan switches takes them as ``flags=``."""
+        import inspect
+        try:
+            params = inspect.signature(self._sim_factory).parameters
+            takes_flags = "flags" in params or any(p.kind == p.VAR_KEYWORD for p in params.values())
+        except (TypeError, ValueError):
+            takes_flags = False
+        if takes_flags:
+            return self._sim_factory(model, flags=flags)
+        if flags:
+            raise nengo.BuildError("this simulator factory takes no plan switches (flags=%d asked for)" % flags)
+        return self._sim_factory(model)
+
     def choose_plan(self, candidates=(0, 128), steps=None):
         """Time one block of this rank's shard under each candidate plan (simulator flags: 0 = the planner's choice -
         the whole-block kernel k_ens_block where a VCO fits one workgroup; 128 = one k_ensarray launch per timestep,
@@ -129,11 +144,19 @@ class ShardedPathIntegration:
         it, before ``prepare``.  Returns {flags: seconds per block}."""
         import time
         steps = int(steps or self.block)
-        sims, seconds = {self._flags: self.sim}, {}
-        for fl in candidates:
-            if fl not in sims:
-                sims[fl] = self._sim_factory(self.model, flags=fl)
-            sim = sims[fl]
+        seconds = {}
+        order = [self._flags] + [fl for fl in candidates if fl != self._flags]      # the simulator already built goes first
+        sim = self.sim
+        for n_done, fl in enumerate(order):
+            if fl not in candidates:
+                continue
+            if n_done > 0:
+                # one candidate resident at a time: the previous one is closed before the next is built (a config-4 shard
+                # holds gigabytes of parameters)
+                if hasattr(sim, "close"):
+                    sim.close()
+                sim = self._make_sim(self.model, fl)
+                self.sim, self._flags = sim, fl
             sim.prepare(2 * steps)
             sim.run_steps(steps, collect=False)
             t0 = time.perf_counter()
@@ -147,14 +170,15 @@ class ShardedPathIntegration:
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
                 wall = float(t.item())
             seconds[fl] = wall
-            sim.reset()
+            if hasattr(sim, "reset"):
+                sim.reset()
             if hasattr(sim, "clear_probe_data"):
                 sim.clear_probe_data()
-        best = min(seconds, key=seconds.get)
-        for fl, sim in sims.items():
-            if fl != best and hasattr(sim, "close"):
+        best = min(seconds, key=lambda fl: (seconds[fl], fl))       # (the times were all-reduced: every rank picks the same plan)
+        if best != self._flags:
+            if hasattr(sim, "close"):
                 sim.close()
-        self.sim, self._flags = sims[best], best
+            self.sim, self._flags = self._make_sim(self.model, best), best
         return seconds
 
     def prepare(self, n_steps):
@@ -387,11 +411,13 @@ class ShardedSLAM:
     ``sim_factory(model)`` is injectable: the tests run the orchestration on the NumPy oracle."""
 
     def __init__(self, sm, rank, world, dt=0.001, dtype="f32", device=0, n_eval_points=None, sim_factory=None, dist=None,
-                 replicate=None):
+                 replicate=None, host_loop=False, flags=0):
+        """``host_loop=True`` keeps round 2's loop (one blocking ssn_run_phase and one blocking exchange per timestep) for A/B
+        measurements; the default enqueues the whole run (``run_steps``)."""
         if dist is None:
             import torch.distributed as dist
         self.dist, self.rank, self.world, self.dt, self.dtype = dist, rank, world, dt, dtype
-        self.sm = sm
+        self.sm, self.host_loop = sm, bool(host_loop)
         if replicate is None:
             replicate = [sm.slam.ovc_ens]
         self.model = build(sm.model, dt=dt, n_eval_points=n_eval_points, neuron_shard=(rank, world), replicate=replicate)
@@ -399,7 +425,7 @@ class ShardedSLAM:
             from .simulator import Simulator
 
             def sim_factory(model):
-                return Simulator(None, model=model, dtype=dtype, device=device)
+                return Simulator(None, model=model, dtype=dtype, device=device, flags=flags)
         self.sim = sim_factory(self.model)
         self.n_steps = 0
         self._buf = None
@@ -440,18 +466,73 @@ class ShardedSLAM:
     def prepare(self, n_steps):
         self.sim.prepare(n_steps)
 
+    def _stream_ordered(self):
+        """True when a run can be enqueued without the host in the loop: the HIP simulator, and either a single rank or the
+        RCCL backend (its collectives are ordered on torch's current stream, where the phase graphs are launched too)."""
+        if not hasattr(self.sim, "phase_async") or self.host_loop:
+            return False
+        if self.world == 1:
+            return True
+        return self.dist.is_initialized() and self.dist.get_backend() == "nccl"
+
+    def _agree(self, err):
+        """Every rank learns whether any rank failed before the collectives of a run start (a rank that raised would leave its
+        peers waiting in the first all-reduce until the RCCL watchdog fires)."""
+        failed = err is not None
+        if self.world > 1 and self.dist.is_initialized():
+            import torch
+            flag = torch.tensor([1.0 if failed else 0.0])
+            if self.dist.get_backend() == "nccl":
+                flag = flag.cuda()
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            failed = bool(flag.item() > 0)
+        if failed:
+            raise nengo.SimulationError(f"sharded SLAM run refused on rank {self.rank}" if err is not None else
+                                        "sharded SLAM run refused: another rank failed its pre-flight check") from err
+
     def run_steps(self, n):
-        if hasattr(self.sim, "run_phase"):
-            n = int(n)
-            if n > 0:
-                self.sim.run_phase(0)
-                for i in range(n):
-                    self._exchange()
-                    # the updates of this timestep and the next one up to its exchange share a launch (one host round trip)
-                    self.sim.run_phase(2 if i + 1 < n else 1)
-        else:
+        n = int(n)
+        if n <= 0:
+            return
+        if not hasattr(self.sim, "run_phase"):
             self.sim.run_steps(n)
-        self.n_steps += int(n)
+            self.n_steps += n
+            return
+        err = None
+        if getattr(self.sim, "_prepared_until", 0) < self.sim.n_steps + n:
+            err = nengo.SimulationError(f"rank {self.rank}: call prepare(n_steps) before run_steps (inputs are tabulated ahead of the run)")
+        if self._stream_ordered():
+            # The whole run is enqueued: per timestep ONE graph launch ([unpack the reduced sums] -> updates of step s -> step
+            # s + 1 up to its exchange -> [pack the partial sums]) and ONE all-reduce, all ordered on one stream - Python only
+            # enqueues (SURVEY 8b: nothing calls back into the host from the step loop); the single wait is at the end.
+            import torch
+            buf = None
+            if self.world > 1:
+                try:
+                    if self._buf is None:
+                        tdt = torch.float32 if self.dtype == "f32" else torch.float64
+                        self._buf = torch.zeros(self.sim.exchange_size(), dtype=tdt, device=torch.device("cuda", torch.cuda.current_device()))
+                    buf = self._buf.data_ptr()
+                except Exception as e:               # noqa: BLE001 - agreed on collectively, then re-raised
+                    err = err or e
+                self._agree(err)
+            elif err is not None:
+                raise err
+            stream = torch.cuda.current_stream().cuda_stream
+            self.sim.phase_async(0, buf, stream)
+            for i in range(n):
+                if self.world > 1:
+                    self.dist.all_reduce(self._buf)
+                self.sim.phase_async(2 if i + 1 < n else 1, buf, stream)
+            self.sim.phase_sync(stream)
+        else:
+            self._agree(err)
+            self.sim.run_phase(0)
+            for i in range(n):
+                self._exchange()
+                # the updates of this timestep and the next one up to its exchange share a launch (one host round trip)
+                self.sim.run_phase(2 if i + 1 < n else 1)
+        self.n_steps += n
 
     # -- results ----------------------------------------------------------------------------------------------------
     def probe_data(self, probe=None):

@@ -516,6 +516,19 @@ class Simulator:
             self.n_steps += 1
             self._uncollected = True
 
+    def phase_async(self, phase, exchange_buf_ptr, stream_ptr):
+        """Stream-ordered variant of ``run_phase``: enqueues [unpack] -> the phase -> [pack] as one graph launch on the
+        caller's HIP stream and returns; ``phase_sync`` waits and checks.  No host synchronisation per timestep."""
+        if phase in (0, 2) and self._prepared_until < self.n_steps + (1 if phase == 0 else 2):
+            raise fe.SimulationError("neuron-sharded model: call prepare(n_steps) before stepping")
+        self._check(self._lib.ssn_phase_async(self._h, int(phase), C.c_void_p(exchange_buf_ptr or None), C.c_void_p(stream_ptr or None)))
+        if phase >= 1:
+            self.n_steps += 1
+            self._uncollected = True
+
+    def phase_sync(self, stream_ptr):
+        self._check(self._lib.ssn_phase_sync(self._h, C.c_void_p(stream_ptr or None)))
+
     def exchange_size(self):
         return int(self._lib.ssn_exchange_size(self._h))
 

@@ -11,24 +11,89 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _rates_from_profiles():
+    ns = json.load(open(os.path.join(ROOT, "profiles", "valu_issue_rate.json")))["ns"]
+    name_of = {"trans": "v_rcp_f32", "dpp": "v_add_f32_dpp", "lane": "v_readlane_b32", "other": "v_max_i32"}
+    kinds = ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "trans", "v_fma_f32", "v_add_f32", "dpp", "v_mov_b32", "lane", "v_cndmask_b32", "other")
+    return {k: ns[name_of.get(k, k)] for k in kinds}
+
+
 def test_valu_roofline_is_recomputed_from_profiles():
+    """The VALU-issue roofline of k_ens_block: every vector mnemonic of the time loop (profiles/k_ens_block_isa.json) priced
+    with nanoseconds of SIMD time per wave64 instruction on the kernel-time basis (profiles/valu_issue_rate.json here; bench.py
+    measures the same table in the run) - at the kernel's own waves per SIMD and at the best column of every kind."""
     import bench
     isa = json.load(open(os.path.join(ROOT, "profiles", "k_ens_block_isa.json")))["variants"]["512,20,3"]
-    rates = json.load(open(os.path.join(ROOT, "profiles", "valu_issue_rate.json")))
+    rates = _rates_from_profiles()
     c = {"block_tpb": 512, "block_npt": 20, "block_enc_lds": 3}
     units_per_s = 1.4e12
-    v = bench.valu_roofline(c, units_per_s)
-    cls = isa["by_class"]
-    cycles = (cls["packed"] * rates["v_pk_fma_f32"]["2"] + cls["trans"] * rates["v_rcp_f32"]["2"] +
-              cls["plain_fma"] * rates["v_fma_f32"]["2"] + cls["plain"] * rates["v_max_i32"]["2"])
-    peak = 1024 * 2.4e9 * 64 * 20 / cycles
+    v = bench.valu_roofline(c, units_per_s, rates, "profiles/valu_issue_rate.json", None)
+    ns_own = ns_best = 0.0
+    n_valu = 0
+    for op, n in isa["ops"].items():
+        k = bench.issue_kind(op)
+        if k is None:
+            assert not op.startswith("v_")
+            continue
+        n_valu += n
+        ns_own += n * rates[k]["2"]
+        ns_best += n * min(rates[k].values())
+    assert n_valu == isa["valu_instructions"] == v["valu_instructions_per_wave_timestep"]
+    peak_own, peak_best = 1024 * 64 * 20 / (ns_own * 1e-9), 1024 * 64 * 20 / (ns_best * 1e-9)
     assert v["variant"] == "512,20,3" and v["waves_per_simd"] == 2
-    assert abs(v["peak_neuron_steps_per_s"] - peak) / peak < 1e-3
-    assert abs(v["frac"] - units_per_s / peak) < 2e-3
-    assert v["valu_instructions_per_wave_timestep"] == sum(cls[k] for k in ("packed", "trans", "plain_fma", "plain"))
-    assert abs(isa["valu_per_neuron_step"] * 20 - v["valu_instructions_per_wave_timestep"]) < 1e-6
+    assert abs(v["peak_neuron_steps_per_s"]["kernel_occupancy"] - peak_own) / peak_own < 1e-3
+    assert abs(v["peak_neuron_steps_per_s"]["best_column"] - peak_best) / peak_best < 1e-3
+    assert abs(v["frac"] - units_per_s / peak_best) < 2e-3 and abs(v["frac_at_kernel_occupancy"] - units_per_s / peak_own) < 2e-3
+    assert v["frac"] <= v["frac_at_kernel_occupancy"]               # the quoted fraction is the stricter one
+    assert abs(isa["valu_per_neuron_step"] * 20 - n_valu) < 1e-6
+    # the kinds the loop really contains are all priced from their own measurement
+    assert {"v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "trans"} <= set(v["instructions_by_kind"])
+    assert bench.issue_kind("v_cndmask_b32_e64") == "v_cndmask_b32" and bench.issue_kind("v_add_f32_dpp") == "dpp"
+    assert bench.issue_kind("v_fmac_f32_e32") == "v_fma_f32" and bench.issue_kind("s_nop") is None and bench.issue_kind("ds_read_b64") is None
     # a variant without a committed instruction count is reported as such, not priced with another variant's numbers
-    assert "note" in bench.valu_roofline({"block_tpb": 256, "block_npt": 40, "block_enc_lds": 0}, units_per_s)
+    assert "note" in bench.valu_roofline({"block_tpb": 256, "block_npt": 40, "block_enc_lds": 0}, units_per_s, rates, "x", None)
+
+
+def test_issue_rate_table_does_not_rest_on_the_per_wave_median():
+    """Round 2 priced the roofline with the MEDIAN wave's cycles per instruction; at 3 waves per SIMD the arbiter serves two
+    waves and runs the third afterwards, so the median understated the SIMD's time by a third.  The
+    kernel-time basis must show no such gain from a third wave, and the stamps' spread must show why."""
+    vir = json.load(open(os.path.join(ROOT, "profiles", "valu_issue_rate.json")))
+    ns, spread = vir["ns"]["v_pk_fma_f32"], vir["wave_cycles_per_instruction"]["v_pk_fma_f32"]
+    assert ns["3"] > 0.95 * ns["2"] and min(ns.values()) > 0.85 * ns["2"]          # more waves: a few per cent at most
+    assert spread["3"]["max"] > 1.3 * spread["3"]["median"]                         # the third wave waits
+    assert vir["v_pk_fma_f32"]["3"] < 0.75 * vir["v_pk_fma_f32"]["2"]               # ... which the median-based column hid
+
+
+def test_gpus_flag_starts_the_ranks_itself(tmp_path, monkeypatch):
+    """bench.py --gpus N (N > 1) without a torch.distributed environment launches torch.distributed.run with N ranks itself
+    (VERDICT r2 missing 1: the flag used to be parsed and ignored) and relays rank 0's line; with WORLD_SIZE set (the
+    driver's own launch) it does not re-launch."""
+    import bench
+    calls = {}
+
+    class P:
+        returncode = 0
+        stdout = 'noise\n{"metric": "m", "n_gpus": 4}\n'
+
+    def fake_run(cmd, **kw):
+        calls["cmd"], calls["env"] = cmd, kw.get("env", {})
+        return P()
+    import subprocess as sp
+    monkeypatch.setattr(sp, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    args = bench.parse()
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(args)
+    assert e.value.code == 0
+    cmd = calls["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert "127.0.0.1" in cmd and calls["env"]["MASTER_ADDR"] == "127.0.0.1" and calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main_src = src[src.index("def main():"):]
+    assert main_src.index("launch_ranks(args)") < main_src.index("slam_main(args)")       # before anything imports torch / touches the GPU
+    assert '"WORLD_SIZE" not in os.environ' in main_src
 
 
 @pytest.mark.gpu
@@ -53,3 +118,41 @@ def test_bench_prints_one_contract_line():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["parity"]["max_cosine_error"] < 1e-3 and d["value_end_to_end"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_launches_two_ranks_over_gloo():
+    """`bench.py --gpus 2` from a plain shell (no WORLD_SIZE): two ranks share this GPU over gloo (RCCL needs a GPU per rank),
+    exactly one JSON line comes back, n_gpus == 2 and the shard plan is in the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--ssp-dim", "55",
+                        "--pi-n-neurons", "500", "--steps", "2", "--warmup", "1", "--block", "256", "--cpu-steps", "0", "--slam-steps", "0"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert "x2" in d["config"]["parallelism"] and d["config"]["shard_plan"]["vcos_per_rank"] == 14
+    assert set(d["config"]["shard_plan"]["seconds_per_block"]) == {"0", "128"} and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_slam_workload_one_rank_and_two():
+    """`--workload slam`: configs[2]'s network (at test size) as the headline object - one rank: roofline (HBM), parity window
+    with learning live, cpu_baseline; two ranks (gloo, sharing this GPU): the neuron-sharded runner from the same entry."""
+    common = ["--workload", "slam", "--ssp-dim", "55", "--pi-n-neurons", "100", "--mem-n-neurons", "300", "--circonv-n-neurons", "50",
+              "--steps", "2", "--warmup", "1", "--block", "64", "--slam-cpu-steps", "60"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "SLAMNetwork" in d["config"]["workload"] and d["roofline"]["bound"] == "hbm"
+    assert d["parity"]["max_cosine_error"] < 1e-3 and d["parity"]["learning_live_in_window"] and d["cpu_baseline"]["value"] > 0
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo"] + common,
+                       capture_output=True, text=True, timeout=1200, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "neuron-sharded x2" in d["config"]["parallelism"] and d["value"] > 0

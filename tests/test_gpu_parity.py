@@ -926,6 +926,7 @@ def test_slam_3d_matches_oracle(Simulator):
                            circonv_n_neurons=50, view_rad=0.6, weights_sample_every=0.02)
     with sm.model:
         p_clean = nengo.Probe(sm.slam.gridcells)
+        p_x = nengo.Probe(sm.slam.pathintegrator.output, synapse=0.01)      # the same filter that feeds the clean-up (tau = 0.01)
     model = build(sm.model)
     cl = [o for o in model.ops if o["kind"] == "cleanup"]
     assert [o["rows"] for o in cl] == [100 ** 3] and space.domain_dim == 3
@@ -934,6 +935,11 @@ def test_slam_3d_matches_oracle(Simulator):
     ref.run_steps(60)
     want_clean = ref.probe_data(2)
     assert len({tuple(r) for r in want_clean[20:]}) > 5                 # the cleaned-up position moves during the window
+    S = sm.slam.sample_ssps
+    x_o = ref.probe_data(3)
+    # the clean-up of timestep t + 1 reads the filter state left by timestep t (reads precede updates)
+    for t in range(10, 59):
+        np.testing.assert_array_equal(want_clean[t + 1], S[np.argmax(S @ x_o[t])])
     with Simulator(None, model=model, dtype="f64") as sim:
         sim.run_steps(60)
         np.testing.assert_allclose(sim.data[sm.probe], ref.probe_data(0), atol=1e-9, rtol=0)
@@ -952,10 +958,21 @@ def test_slam_3d_matches_oracle(Simulator):
             sim.run_steps(60)
             ce = H.cosine_error(sim.data[sm.probe][20:], ref.probe_data(0)[20:])
             assert ce.max() < 1e-3, (flags, ce.max())
-            got_clean = sim.data[p_clean]
+            got_clean, x_g = sim.data[p_clean], sim.data[p_x]
             launches.append(sim.counters()["launches_per_step"])
         cc = H.cosine_error(got_clean[5:], want_clean[5:])
         assert (cc < 1e-6).mean() >= 0.7 and cc.max() < 0.05, (flags, (cc < 1e-6).mean(), cc.max())
+        # ... and where the f32 route picks another row than the oracle it must still have picked a maximiser: against the exact
+        # (float64) similarities of the kernel's OWN input vector, the chosen row is within f32 rounding of the best one
+        # (neighbouring grid points are 0.99 similar: the two candidates differ in the sixth digit) - on every timestep
+        worst = 0.0
+        for t in range(10, 59):
+            sims = S @ x_g[t]
+            row = got_clean[t + 1]
+            k = int(np.argmax(S @ row))                      # the grid point the kernel returned (rows are unit vectors)
+            np.testing.assert_allclose(row, S[k], atol=2e-6, rtol=0)
+            worst = max(worst, float(sims.max() - sims[k]) / float(np.linalg.norm(x_g[t])))
+        assert worst < 2e-5, (flags, split, worst)
     assert launches[1] < launches[0] <= launches[1] + 6       # the factored route adds the half-spectrum, left-operand and product launches (and their rounds)
 
 
@@ -1091,7 +1108,7 @@ def test_scaled_encoders_probe_and_map_recall_of_the_learned_encoders(Simulator)
     assert np.abs(E32 - E_ref).max() < 2e-3 * np.abs(E_ref).max()
 
 
-def _gridcell_models():
+def _gridcell_models(pi_n=80, slam_pi_n=60):
     """The two grid-cell population options of the reference: PathIntegration(with_gcs=True) (pathintegration.py:150-154)
     and SLAMNetwork(gc_n_neurons > 0) (slam.py:274-281; encoders from sample_grid_encoders, sspspace.py:733-762)."""
     import sspslam_amd.frontend as fe
@@ -1106,7 +1123,7 @@ def _gridcell_models():
     with fe.Network(seed=2) as pi_model:
         vel = fe.Node(H.indexed_rows_node_fn(vels * scale, 0.001))
         init = fe.Node(H.indexed_rows_node_fn(real_ssp, 0.001, until=0.05))
-        pi = PathIntegration(space, 80, 0.05, scaling_factor=scale, stable=True, with_gcs=True, n_gcs=400)
+        pi = PathIntegration(space, pi_n, 0.05, scaling_factor=scale, stable=True, with_gcs=True, n_gcs=400)
         fe.Connection(vel, pi.velocity_input, synapse=None)
         fe.Connection(init, pi.input, synapse=None)
         p1 = fe.Probe(pi.output, synapse=0.05)
@@ -1117,7 +1134,7 @@ def _gridcell_models():
     with fe.Network(seed=3) as slam_model:
         nodes = [fe.Node(fn) for fn in (f[0], f[6], f[4], f[2])]
         init = fe.Node(lambda t: real_ssp[int((t - 0.001) / 0.001)] if t < 0.05 else np.zeros(space.ssp_dim))
-        slam = SLAMNetwork(space, lm_space, 0.6, 6, 60, 150, 30, vel_scaling_factor=f[1], shift_rate=0.2, gc_n_neurons=120,
+        slam = SLAMNetwork(space, lm_space, 0.6, 6, slam_pi_n, 150, 30, vel_scaling_factor=f[1], shift_rate=0.2, gc_n_neurons=120,
                            intercept=0.1, voja_learning_rate=1e-4, pes_learning_rate=5e-3, update_thres=0.2)
         for n, tgt in zip(nodes, (slam.velocity_input, slam.landmark_vec_ssp, slam.landmark_id_input, slam.no_landmark_in_view)):
             fe.Connection(n, tgt, synapse=None)
@@ -1139,12 +1156,208 @@ def test_gridcell_populations_match_oracle(Simulator):
                 want = ref.probe_data(idx[id(p)])
                 assert np.abs(want).max() > 0
                 np.testing.assert_allclose(sim.data[p], want, atol=1e-9, rtol=0)
-        # f32: populations this small (80 neurons per oscillator) show single spike-time flips - a voltage within an f32 ulp
-        # of threshold crosses one step earlier or later than in f64, and which ones do depends on the rounding of the plan
-        # (fused multiply-adds) - as ~2e-3 transients of a few filter time constants; the 1e-3 bar is checked on populations
-        # of the configs' size (test_slam_at_ssp_dim_1015_matches_oracle).  Here: identical apart from such transients.
+    # f32 at north_star's 1e-3 bar, on oscillator populations that hold it: with 80 (60) neurons per oscillator a single spike
+    # that falls one timestep earlier in f32 than in f64 (a voltage within an ulp of threshold) shows as a ~2e-3 transient of
+    # the decoded vector (round 2 had widened the bar to 5e-3 for that); with 600 neurons per oscillator the same flip weighs
+    # an eighth of that.  Both grid-cell options, all three plans.
+    for net, probes in _gridcell_models(pi_n=600, slam_pi_n=600):
+        model = build(net, n_eval_points=1200)
+        ref = OracleSimulator(model)
+        ref.run_steps(300)
+        idx = {id(p["probe"]): i for i, p in enumerate(model.probes)}
+        want = ref.probe_data(idx[id(probes[0])])
         for flags in (0, 8388608, 2097152):        # pipelined rounds | one timestep's rounds at a time | one launch per operator
             with Simulator(None, model=model, dtype="f32", flags=flags) as sim:
                 sim.run_steps(300)
-                ce = H.cosine_error(sim.data[probes[0]][20:], ref.probe_data(idx[id(probes[0])])[20:])
-                assert np.median(ce) < 1e-9 and ce.max() < 5e-3, (flags, np.median(ce), ce.max())
+                ce = H.cosine_error(sim.data[probes[0]][20:], want[20:])
+                assert ce.max() < 1e-3, (flags, np.median(ce), ce.max())
+
+
+# ---- round 3: the configurations VERDICT r2 listed as untested ------------------------------------------------------------
+def test_config2_full_size_block_kernel_matches_oracle(Simulator):
+    """BASELINE configs[1] at FULL size - 508 VCOs x 10 000 LIF neurons, ssp_dim 1015 - on the default plan, i.e. the
+    whole-block kernel k_ens_block<float,3,4,20,512,3> that the headline number is measured on, against the NumPy oracle of
+    the same built model over 200 timesteps (bench.py compares the same pair in every run; this makes it a test)."""
+    space = H.make_ssp_space(2, 1015)
+    path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
+    pm = H.make_pathint_model(space, path, vels, 10000, seed=0)
+    model = build(pm.model, n_eval_points=4000)
+    assert model.n_neurons == 5080000
+    steps = 200
+    ref = OracleSimulator(model)
+    ref.run_steps(steps)
+    want = ref.probe_data(0)
+    with Simulator(None, model=model, dtype="f32", block_steps=100) as sim:      # two blocks: the carry between launches is covered
+        sim.run_steps(steps)
+        got = sim.data[pm.probe]
+        c = sim.counters()
+    assert c["launches_per_step"] == 0 and (c["block_tpb"], c["block_npt"], c["block_enc_lds"]) == (512, 20, 3)
+    assert c["dominant_units_per_launch"] == 5080000 * 100
+    ce = H.cosine_error(got[20:], want[20:])
+    assert ce.max() < 1e-3 and np.abs(want[20:]).max() > 0.01, ce.max()
+
+
+def test_config3_full_size_with_learning_matches_oracle(Simulator):
+    """BASELINE configs[2] at FULL size (5.53 M neurons: 508 x 10 000 VCO neurons, four 10 150 x 1015 populations, 8 128
+    product ensembles; reference run_slam.py:180-235) with a landmark in view from the first timesteps
+    (harness.make_config3_model), so that the landmark inputs, the two circular convolutions, PES and Voja are LIVE in the
+    window the oracle can follow: f32 fast mode on the default plan (pipelined rounds) within 1e-3 cosine of the oracle over
+    150 timesteps; PES-learned decoders, Voja-moved encoders and map recall (definition (i), run_slam.py:263-268) compared."""
+    import sspslam_amd.frontend as fe
+    sm = H.make_config3_model()
+    model = build(sm.model, n_eval_points=4000)
+    assert model.n_neurons == 5527000
+    am = sm.slam.assomemory
+    wb, eb = model.params[am.conn_out].learned_buffer, model.params[am.memory].encoder_buffer
+    steps = 150
+    ref = OracleSimulator(model)
+    ref.run_steps(steps)
+    want = ref.probe_data(0)
+    W_ref, E_ref, E0 = ref.buf[wb], ref.buf[eb], model.buffers[eb]
+    assert np.abs(W_ref).max() > 0 and np.abs(E_ref - E0).max() > 1e-5           # PES and Voja were at work in the window
+    with Simulator(None, model=model, dtype="f32") as sim:
+        sim.run_steps(steps)
+        got = sim.data[sm.probe]
+        W_gpu, E_gpu = sim.read_buffer(wb), sim.read_buffer(eb)
+        assert sim.counters()["launches_per_step"] <= 8
+    ce = H.cosine_error(got[20:], want[20:])
+    assert ce.max() < 1e-3, ce.max()
+    # learned state: a spike that falls one timestep earlier or later in f32 shifts one neuron's filtered activity, i.e. one
+    # column of the decoders, by a few per cent of that column - so the matrices are compared in norm, the recall in cosine
+    assert np.linalg.norm(W_gpu - W_ref) < 2e-2 * np.linalg.norm(W_ref), np.linalg.norm(W_gpu - W_ref) / np.linalg.norm(W_ref)
+    assert np.linalg.norm((E_gpu - E0) - (E_ref - E0)) < 2e-2 * np.linalg.norm(E_ref - E0)
+    rec_g, pos_g = H.map_recall(sm.ssp_space, sm.lm_space, model.params[am.memory], fe.LIF(), W_gpu)
+    rec_r, pos_r = H.map_recall(sm.ssp_space, sm.lm_space, model.params[am.memory], fe.LIF(), W_ref)
+    seen = np.linalg.norm(rec_r, axis=1) > 1e-3 * np.linalg.norm(rec_r, axis=1).max()
+    assert seen.any()
+    assert H.cosine_error(rec_g[seen], rec_r[seen]).max() < 1e-3
+
+
+def test_sharded_pathint_streaming_plan_and_choose_plan(Simulator):
+    """BASELINE configs[3]'s shard plan at test size: VCOs of 12 000 neurons do not fit a k_ens_block workgroup (capacity
+    10 752), so a rank's shard is stepped by one streaming k_ensarray launch per timestep - also what flags = 128 forces.
+    ShardedPathIntegration(flags=128) and choose_plan (bench.py's default at N > 1: both candidates timed, the faster kept)
+    must step to the oracle's trajectory."""
+    from sspslam_amd.sharding import ShardedPathIntegration
+    kw = dict(ssp_dim=7, n=12000, T=10.0, limit=0.2)
+    model = build(small_pathint(**kw).model, n_eval_points=1500)
+    ref = OracleSimulator(model)
+    ref.run_steps(256)
+    want = ref.probe_data(0)
+    r = ShardedPathIntegration(small_pathint(**kw), 0, 1, dtype="f64", block=128, n_eval_points=1500, flags=128)
+    r.prepare(256)
+    r.run_steps(256)
+    assert r.sim.counters()["launches_per_step"] == 1 and r.sim.counters()["block_tpb"] == 0
+    np.testing.assert_allclose(r.probe_data(), want, atol=1e-9, rtol=0)
+    r.close()
+    # choose_plan on a shard where both plans exist (n = 600: block kernel vs streaming); the chosen one steps on
+    kw = dict(ssp_dim=19, n=600, T=10.0, limit=0.2)
+    model = build(small_pathint(**kw).model)
+    ref = OracleSimulator(model)
+    ref.run_steps(256)
+    r = ShardedPathIntegration(small_pathint(**kw), 0, 1, dtype="f32", block=128)
+    seconds = r.choose_plan((0, 128), steps=128)
+    assert set(seconds) == {0, 128} and all(v > 0 for v in seconds.values())
+    assert r._flags == min(seconds, key=lambda f: (seconds[f], f))
+    assert (r.sim.counters()["launches_per_step"] == 0) == (r._flags == 0)
+    assert r.readout.counters()["launches_per_step"] == 0
+    r.prepare(256)
+    r.run_steps(256)
+    assert H.cosine_error(r.probe_data()[20:], ref.probe_data(0)[20:]).max() < 1e-3
+    r.close()
+
+
+SLAM3D_SHARD_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import torch
+import torch.distributed as dist
+from sspslam_amd import harness as H
+from sspslam_amd.sharding import ShardedSLAM
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+space = H.make_ssp_space(3, ssp_dim=33, rng=np.random.default_rng(3))
+path, vels = H.make_random_path(10.0, limit=0.5, seed=2, domain_dim=3)
+res = {{}}
+for dtype in ("f64", "f32"):
+    for turn in range(world):            # ranks share one GPU here: build (rocSOLVER) one after the other
+        if turn == rank:
+            sm = H.make_slam_model(space, path, vels, n_landmarks=20, pi_n_neurons=100, mem_n_neurons=200, circonv_n_neurons=50,
+                                   view_rad=0.6)
+            r = ShardedSLAM(sm, rank, world, dtype=dtype)
+        dist.barrier()
+    r.prepare({steps})
+    r.run_steps({steps})
+    am = sm.slam.assomemory
+    res[dtype] = r.probe_data()
+    res[dtype + "_W"], res[dtype + "_E"] = r.learned_decoders(am.conn_out), r.learned_encoders(am.memory)
+    res[dtype + "_factored"] = int(any(o["kind"] == "cleanup" and "g_dft" in o for o in r.model.ops))
+    r.close()
+if rank == 0:
+    np.savez({out!r}, **res)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_of_a_neuron_sharded_3d_slam_on_hip(Simulator, tmp_path):
+    """BASELINE configs[4]'s shape in its SHARDED form (configs_untested): the 3-D SLAMNetwork of
+    test_slam_3d_matches_oracle (d = 33, 20 landmarks, the reference's 100-points-per-axis clean-up grid = 10^6 rows,
+    slam.py:209) split over two ranks - f64: trajectory, gathered PES decoders and Voja encoders equal the UNSHARDED oracle
+    run at 1e-9; f32 within the 1e-3 cosine bar with the factored clean-up (half spectrum -> left operand -> MFMA product ->
+    two-stage argmax) running inside the two-phase graphs."""
+    import subprocess
+    import sys
+    steps = 60
+    script, out = tmp_path / "worker.py", tmp_path / "slam3d.npz"
+    script.write_text(SLAM3D_SHARD_WORKER.format(root=ROOT, out=str(out), steps=steps))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29676", str(script)],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    got = np.load(out)
+    space = H.make_ssp_space(3, ssp_dim=33, rng=np.random.default_rng(3))
+    path, vels = H.make_random_path(10.0, limit=0.5, seed=2, domain_dim=3)
+    sm = H.make_slam_model(space, path, vels, n_landmarks=20, pi_n_neurons=100, mem_n_neurons=200, circonv_n_neurons=50, view_rad=0.6)
+    model = build(sm.model)
+    ref = OracleSimulator(model)
+    ref.run_steps(steps)
+    want = ref.probe_data(0)
+    am = sm.slam.assomemory
+    W_ref = ref.buf[model.params[am.conn_out].learned_buffer]
+    E_ref = ref.buf[model.params[am.memory].encoder_buffer]
+    assert int(got["f32_factored"]) == 1
+    np.testing.assert_allclose(got["f64"], want, atol=1e-9, rtol=0)
+    np.testing.assert_allclose(got["f64_W"], W_ref, atol=1e-12, rtol=1e-9)
+    np.testing.assert_allclose(got["f64_E"], E_ref, atol=1e-10, rtol=1e-9)
+    assert H.cosine_error(got["f32"][20:], want[20:]).max() < 1e-3
+
+
+def test_sharded_slam_stream_ordered_run_equals_the_host_loop(Simulator):
+    """ssn_phase_async / ssn_phase_sync (the whole run enqueued on one stream: per timestep ONE graph launch - [unpack] ->
+    updates -> next step up to its exchange -> [pack] - and no host synchronisation) against round 2's loop (a blocking
+    ssn_run_phase and a blocking exchange per timestep), one rank, f64: bit-identical trajectories and learned decoders, and
+    both equal to the oracle."""
+    from sspslam_amd.sharding import ShardedSLAM
+    steps = 120
+    sm0 = _small_slam(weights_every=None)
+    model = build(sm0.model)
+    ref = OracleSimulator(model)
+    ref.run_steps(steps)
+    outs = []
+    for host_loop in (False, True):
+        sm = _small_slam(weights_every=None)
+        r = ShardedSLAM(sm, 0, 1, dtype="f64", host_loop=host_loop)
+        assert r._stream_ordered() == (not host_loop)
+        r.prepare(steps)
+        r.run_steps(70)
+        r.run_steps(steps - 70)                    # two runs: the sequence 0, 2, ..., 1 restarts cleanly
+        outs.append((r.probe_data(), r.learned_decoders(sm.slam.assomemory.conn_out)))
+        with pytest.raises(nengo.SimulationError, match="prepare"):
+            r.run_steps(5)                          # past the prepared window: refused before anything is enqueued
+        r.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_allclose(outs[0][0], ref.probe_data(0), atol=1e-9, rtol=0)

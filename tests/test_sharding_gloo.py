@@ -165,3 +165,85 @@ def test_neuron_sharding_refuses_partial_sums_into_neurons():
     assert ma.exchange == mb.exchange and ma.sig_size == mb.sig_size            # the ranks agree on what they exchange
     assert {o["phase"] for o in ma.ops} == {0, 1}
     assert all(o["kind"] in ("lowpass", "pes", "voja") for o in ma.ops if o["phase"] == 1)
+
+
+PLAN_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import torch.distributed as dist
+from helpers import OracleBackedSimulator, small_pathint
+from sspslam_amd.sharding import ShardedPathIntegration
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+built, closed = [], []
+
+class Timed(OracleBackedSimulator):
+    # a flags-aware factory product: plan 128 is made the slower one on rank 1 only - the collective decision must follow the
+    # slowest rank, and both ranks must end on the same plan
+    def __init__(self, model, flags):
+        super().__init__(model)
+        self.flags = flags
+        built.append(flags)
+    def run_steps(self, n, collect=True, profile=False):
+        if self.flags == 128 and rank == 1:
+            time.sleep(0.3)
+        super().run_steps(n, collect=collect, profile=profile)
+    def reset(self):
+        from oracle import OracleSimulator
+        self.o = OracleSimulator(self.model)
+        self.n_steps = 0
+    def close(self):
+        closed.append(self.flags)
+
+pm = small_pathint(ssp_dim=55, n=30, T=10.0, limit=0.2)
+r = ShardedPathIntegration(pm, rank, world, sim_factory=lambda m, flags=0: Timed(m, flags), block=64)
+seconds = r.choose_plan((0, 128), steps=16)
+assert set(seconds) == {{0, 128}} and seconds[128] >= 0.3 > seconds[0], seconds          # the all-reduced maximum, on every rank
+assert r._flags == 0 and r.sim.flags == 0
+# shard simulators built: flags 0, then 128, then 0 again (the winner); the read-out (rank 0) always with flags 0; never two
+# candidates resident at once: each was closed before the next was built
+shard_built = [f for f in built]
+if rank == 0:
+    assert shard_built.count(128) == 1 and shard_built.count(0) == 3, shard_built        # shard 0, read-out 0, shard 128, shard 0
+else:
+    assert shard_built == [0, 128, 0], shard_built
+assert closed[:2] == [0, 128], closed
+r.run_steps(128)
+if rank == 0:
+    np.save({out!r}, r.probe_data())
+# the documented injection contract sim_factory(model) still works, and refuses plan switches it cannot honour
+r2 = ShardedPathIntegration(small_pathint(ssp_dim=55, n=30, T=10.0, limit=0.2), rank, world, sim_factory=lambda m: OracleBackedSimulator(m), block=64)
+try:
+    r2._make_sim(r2.model, 128)
+    raise SystemExit("a factory without flags accepted a plan switch")
+except Exception as e:
+    assert "plan switches" in str(e), e
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_choose_plan_is_collective_and_keeps_one_candidate_resident():
+    """ShardedPathIntegration.choose_plan (bench.py's default at N > 1): two gloo ranks on a flags-aware
+    oracle-backed factory - both candidates are timed, the slowest rank's time decides, every rank picks the same plan, the
+    read-out simulator ignores the shard's plan switches, and the chosen plan steps to the unsharded oracle's trajectory."""
+    import subprocess
+    from sspslam_amd.builder import build
+    from oracle import OracleSimulator
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import small_pathint
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "probe.npy")
+        script = os.path.join(tmp, "worker.py")
+        with open(script, "w") as f:
+            f.write(PLAN_WORKER.format(root=ROOT, out=out))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29611", script],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        got = np.load(out)
+    ref = OracleSimulator(build(small_pathint(ssp_dim=55, n=30, T=10.0, limit=0.2).model))
+    ref.run_steps(128)
+    np.testing.assert_array_equal(got, ref.probe_data(0))

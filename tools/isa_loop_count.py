@@ -113,6 +113,7 @@ def main():
         "instructions_per_wave_timestep": sum(c.values()), "valu_instructions": valu,
         "by_class": dict(by_class), "issue_slots_4cycle_model": slots4,
         "scratch_ops": sum(n for op, n in c.items() if op.startswith("scratch")),
+        "ops": {op: n for op, n in sorted(c.items())},          # every mnemonic of the loop: bench.py prices the VALU ones one by one
         "top": c.most_common(60),
     }
     if a.npt:

@@ -35,10 +35,15 @@ template <int BITS> __device__ inline unsigned ld_bypass(const unsigned* p) {
   if (BITS == 1) asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
   if (BITS == 2) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
   if (BITS == 3) asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  // 4: invalidate this CU's vector L1, then a plain load: misses the L1, may hit the XCD's L2 (the time loop of k_ens_block
+  //    holds nothing in the L1 that it would miss afterwards)
+  if (BITS == 4) asm volatile("buffer_inv sc0\n\tglobal_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  // 5: a returning atomic OR with 0 at workgroup scope (no sc1): atomics execute in the XCD's L2, never in the L1
+  if (BITS == 5) { const unsigned z = 0; asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p), "v"(z) : "memory"); }
   return v;
 }
 template <int BITS> __device__ inline void st_word(unsigned* p, unsigned v) {
-  if (BITS == 0 || BITS == 1) asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
+  if (BITS == 0 || BITS == 1 || BITS == 4 || BITS == 5) asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
   if (BITS == 2) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
   if (BITS == 3) asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
 }
@@ -54,9 +59,10 @@ __device__ inline float row_sum_dpp(float v) {
 struct Res { unsigned bad, xcc_mismatch, timeout, pad; unsigned long long cycles, real; };
 
 // P members per group; SAME: members on one XCD; BITS: cache bits of the polling loads / publishing stores
-template <int P, int SAME, int BITS>
+template <int P, int SAME, int BITS, int W0>
 __global__ __launch_bounds__(512) void k_exchange(unsigned* slots, int steps, int work, Res* res, float* sink) {
   __shared__ float red[64];
+  __shared__ unsigned bc[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int group, member;
   if (SAME) { const int x = blockIdx.x & 7, j = blockIdx.x >> 3; group = (j / P) * 8 + x; member = j % P; }
@@ -92,15 +98,23 @@ __global__ __launch_bounds__(512) void k_exchange(unsigned* slots, int steps, in
     if (P > 1) {
       // (3) publish
       if (wave == 0 && (lane & 15) == 0) st_word<BITS>(gs + (buf * 16 + member) * 4 + (lane >> 4), __builtin_bit_cast(unsigned, v));
-      // (4) poll
+      // (4) poll (W0: only wave 0 polls and hands the partners' values on through LDS - one more workgroup barrier, an
+      //     eighth of the polling traffic)
       const unsigned* src = gs + (buf * 16 + (lane & 15)) * 4 + (lane >> 4);
       unsigned got = 0, spins = 0;
       const bool mine = (lane & 15) < P;
-      while (true) {
-        if (mine) got = ld_bypass<BITS>(src);
-        const bool wait = mine && got == SENT;
-        if (!__any(wait)) break;
-        if (++spins > (1u << 18)) { timeout = 1; break; }
+      if (!W0 || wave == 0) {
+        while (true) {
+          if (mine) got = ld_bypass<BITS>(src);
+          const bool wait = mine && got == SENT;
+          if (!__any(wait)) break;
+          if (++spins > (1u << 18)) { timeout = 1; break; }
+        }
+      }
+      if (W0) {
+        if (wave == 0) bc[lane] = got;
+        __syncthreads();
+        got = bc[lane];
       }
       v = row_sum_dpp(mine ? __builtin_bit_cast(float, got) : 0.0f);
     }
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(512) void k_exchange(unsigned* slots, int steps, in
   if (blockIdx.x == 0 && tid == 0) { res->cycles = t1 - t0; res->real = r1 - r0; }
 }
 
-template <int P, int SAME, int BITS>
+template <int P, int SAME, int BITS, int W0 = 0>
 static void run(int steps, int work, int n_wg) {
   unsigned* slots; Res* res; float* sink;
   const int groups = n_wg;       // (upper bound)
@@ -132,15 +146,15 @@ static void run(int steps, int work, int n_wg) {
   (void)hipMalloc(&sink, 64);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   (void)hipEventRecord(e0);
-  hipLaunchKernelGGL((k_exchange<P, SAME, BITS>), dim3(n_wg), dim3(512), 0, 0, slots, steps, work, res, sink);
+  hipLaunchKernelGGL((k_exchange<P, SAME, BITS, W0>), dim3(n_wg), dim3(512), 0, 0, slots, steps, work, res, sink);
   (void)hipEventRecord(e1);
   (void)hipDeviceSynchronize();
   float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
   Res h; (void)hipMemcpy(&h, res, sizeof h, hipMemcpyDeviceToHost);
-  static const char* bits[] = {"plain", "sc0", "sc1", "sc0 sc1"};
-  printf("P %d  %-7s  loads/stores %-8s  work %4d  %4d workgroups  %.3f us per timestep (events)  %.0f shader cycles per timestep, clock %.0f MHz  "
+  static const char* bits[] = {"plain", "sc0", "sc1", "sc0 sc1", "inv+ld", "atomic"};
+  printf("P %d  %-7s  %s  loads/stores %-8s  work %4d  %4d workgroups  %.3f us per timestep (events)  %.0f shader cycles per timestep, clock %.0f MHz  "
          "wrong sums %u  timeouts %u  blockIdx%%8 != XCC_ID %u\n",
-         P, SAME ? "one XCD" : "spread", bits[BITS], work, n_wg, 1e3 * ms / steps, (double)h.cycles / steps,
+         P, SAME ? "one XCD" : "spread", W0 ? "wave 0 polls" : "all waves poll", bits[BITS], work, n_wg, 1e3 * ms / steps, (double)h.cycles / steps,
          h.real ? (double)h.cycles / (double)h.real * 100.0 : 0.0, h.bad, h.timeout, h.xcc_mismatch);
   fflush(stdout);
   (void)hipFree(slots); (void)hipFree(res); (void)hipFree(sink);
@@ -151,19 +165,28 @@ int main(int argc, char** argv) {
   // work = trips of 8 packed FMAs per lane: 0 = the bare exchange; 64 ~ a quarter VCO's timestep (512 instructions per wave)
   for (int work : {0, 64}) {
     run<1, 1, 1>(steps, work, 256);
-    run<2, 1, 1>(steps, work, 256);
-    run<4, 1, 1>(steps, work, 256);
-    run<8, 1, 1>(steps, work, 256);
+    run<2, 1, 4>(steps, work, 256);
+    run<4, 1, 4>(steps, work, 256);
+    run<8, 1, 4>(steps, work, 256);
+    run<2, 1, 5>(steps, work, 256);
+    run<4, 1, 5>(steps, work, 256);
+    run<8, 1, 5>(steps, work, 256);
+    run<4, 1, 4, 1>(steps, work, 256);
+    run<4, 1, 5, 1>(steps, work, 256);
     run<2, 1, 3>(steps, work, 256);
     run<4, 1, 3>(steps, work, 256);
+    run<4, 1, 3, 1>(steps, work, 256);
     run<2, 0, 2>(steps, work, 256);
     run<4, 0, 2>(steps, work, 256);
-    run<2, 0, 3>(steps, work, 256);
-    run<4, 0, 3>(steps, work, 256);
-    run<4, 0, 1>(steps, work, 256);     // sc0 across XCDs: expected to read stale data or time out (shows the detector works)
+    run<4, 0, 4>(steps, work, 256);     // L1 invalidate + plain load across XCDs: the other XCD's L2 is not coherent - expected stale (detector check)
+    run<4, 0, 5>(steps, work, 256);     // workgroup-scope atomics across XCDs: likewise
   }
   // fewer workgroups than CUs (an 8-GPU shard holds 64 VCOs x 4 members = 256; a 4-GPU shard 127 x 2 = 254)
-  run<4, 1, 1>(steps, 64, 64);
-  run<2, 1, 1>(steps, 64, 128);
+  run<4, 1, 4>(steps, 64, 64);
+  run<4, 1, 5>(steps, 64, 64);
+  run<2, 1, 4>(steps, 64, 128);
+  run<1, 1, 1>(steps, 256, 256);
+  run<2, 1, 4>(steps, 128, 256);
+  run<2, 1, 5>(steps, 128, 256);
   return 0;
 }
