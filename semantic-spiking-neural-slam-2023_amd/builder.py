@@ -358,15 +358,32 @@ class Builder:
             self.node_out[id(n)] = self.alloc("C", vals.size, init=vals)
 
     def _probe_function_node(self, n):
-        """A Python function node with inputs must map to a kernel; recognise the identity."""
+        """A Python function node with inputs must map to a kernel.  The three such nodes of the reference's networks are
+        recognised from their BEHAVIOUR (random probes), with candidates for their constants taken from the function's closure
+        cells - so the reference's classes run with zero edits (no ``node.native`` hints):
+
+        * the identity (``EnsembleArray.output`` / passthrough lambdas, reference ``pathintegration.py:167``);
+        * the clean-up ``lambda t, x: clean_up_fun(x)`` = ``S[argmax(S @ x)]`` (``slam.py:212-215,270``): S is a 2-D array
+          with ``size_in`` columns found in the closure; every probe must return exactly the row the table product selects;
+        * the gate ``update_state_func`` (``slam.py:233-237,249``): ``rate * (a - b)`` while ``|flag| <= 1e-3`` and
+          ``<a, b> > thres``, zeros otherwise - rate from one probe, thres from the closure's floats (bisection as a
+          fallback), the flag tolerance and random on / off cases checked against ``make_gate``."""
+        fn = n.output
         rs = np.random.RandomState(0)
         try:
-            ok = all(np.array_equal(np.asarray(n.output(0.01 * (i + 1), x)), x)
+            ok = all(np.array_equal(np.asarray(fn(0.01 * (i + 1), x)), x)
                      for i, x in enumerate(rs.randn(3, n.size_in)))
         except Exception:
             ok = False
         if ok and n.size_in == n.size_out:
             return ("identity",)
+        for recognise in (_recognise_cleanup, _recognise_gate):
+            try:
+                native = recognise(fn, n.size_in, n.size_out)
+            except Exception:                    # noqa: BLE001 - a function that does not behave like the pattern
+                native = None
+            if native is not None:
+                return native
         raise fe.BuildError(
             f"{n!r}: Python function nodes with inputs cannot run inside the device step loop; "
             "tag the node with node.native = ('identity',) | ('cleanup', table) | ('gate', d, thres, rate)")
@@ -601,6 +618,12 @@ class Builder:
         if pk != "ensemble":
             raise fe.BuildError(f"cannot connect from {pre_obj!r}")
         e = pre_obj
+        post_obj = _contig(c.post)[0]
+        if _kind(post_obj) == "neurons" and self._is_sharded(post_obj.ensemble) and T.ndim == 2:
+            # (Node -> neurons slices the rows of its transform above; a decoded connection would need its decoders solved for
+            #  this rank's rows only - the reference's inhibition, associativememory.py:47-49, comes from a Node)
+            raise fe.BuildError("a decoded connection with a matrix transform into the neurons of a neuron-sharded ensemble is "
+                                "not supported: replicate the post ensemble (build(..., replicate=[...])) or drive it from a Node")
         if pre_len is None:
             pre_start, pre_len = 0, e.dimensions
         if rule is not None and type(rule).__name__ == "PES":
@@ -1057,6 +1080,99 @@ def prune_ops(ops, model):
     return [o for o, k in zip(ops, keep) if k]
 
 
+def _closure_values(fn, depth=3):
+    """Objects reachable through the closure cells (and defaults) of a function, callables followed ``depth`` levels."""
+    seen, out, todo = set(), [], [(fn, 0)]
+    while todo:
+        f, lvl = todo.pop()
+        if id(f) in seen:
+            continue
+        seen.add(id(f))
+        cells = []
+        for c in (getattr(f, "__closure__", None) or ()):
+            try:
+                cells.append(c.cell_contents)
+            except ValueError:
+                pass
+        cells.extend(getattr(f, "__defaults__", None) or ())
+        for v in cells:
+            out.append(v)
+            if callable(v) and lvl < depth:
+                todo.append((v, lvl + 1))
+    return out
+
+
+def _recognise_cleanup(fn, size_in, size_out):
+    if size_in != size_out:
+        return None
+    tables = [v for v in _closure_values(fn) if isinstance(v, np.ndarray) and v.ndim == 2 and v.shape[1] == size_in and v.shape[0] > 1]
+    rs = np.random.RandomState(1)
+    for S in tables:
+        Sf = np.asarray(S, dtype=float)
+        rows = rs.randint(0, Sf.shape[0], size=4)
+        probes = [Sf[r] + 0.3 * rs.randn(size_in) / np.sqrt(size_in) for r in rows[:3]] + [rs.randn(size_in)]
+        if all(np.array_equal(np.asarray(fn(0.001 * (i + 1), x), dtype=float).reshape(-1), Sf[int(np.argmax(Sf @ x))])
+               for i, x in enumerate(probes)):
+            from .sspspace import grid_factors_from_table
+            return ("cleanup", Sf, grid_factors_from_table(Sf))
+    return None
+
+
+def _recognise_gate(fn, size_in, size_out):
+    d = size_out
+    if size_in != 2 * d + 1 or d < 1:
+        return None
+    e0 = np.zeros(d)
+    e0[0] = 1.0
+
+    def call(a, b, flag):
+        return np.asarray(fn(0.001, np.concatenate([a, b, [flag]])), dtype=float).reshape(-1)
+
+    def on(s, flag=0.0):                     # <s e0, e0> = s exactly
+        return bool(np.any(call(s * e0, e0, flag) != 0.0))
+    rate = None
+    for k in range(1, 12):                   # s - 1 a power of two: the quotient below is exact
+        s_hi = 1.0 + 2.0 ** k
+        o = call(s_hi * e0, e0, 0.0)
+        if o.shape == (d,) and o[0] != 0.0:
+            rate = float(o[0] / (s_hi - 1.0))
+            if np.any(o[1:] != 0.0):
+                return None
+            break
+    if rate is None:
+        return None
+    floats = sorted({float(v) for v in _closure_values(fn) if isinstance(v, (int, float, np.floating, np.integer))
+                     and not isinstance(v, bool)})
+    thres = None
+    for th in floats:
+        if th < s_hi and not on(th) and on(np.nextafter(th, np.inf)):
+            thres = th
+            break
+    if thres is None:                        # no candidate in the closure: bisect the switching point
+        lo, hi = -s_hi, s_hi
+        if on(lo) or not on(hi):
+            return None
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            if mid == lo or mid == hi:
+                break
+            lo, hi = (lo, mid) if on(mid) else (mid, hi)
+        thres = lo
+    if not on(s_hi, 1e-3) or on(s_hi, 2e-3) or not on(s_hi, -1e-3) or on(s_hi, -2e-3):
+        return None                          # (the flag tolerance of np.allclose(flag, 0, atol=1e-3))
+    from .networks.slam import make_gate
+    own = make_gate(d, thres, rate)
+    rs = np.random.RandomState(2)
+    for i in range(6):
+        a, b = rs.randn(d), rs.randn(d)
+        if i % 2 == 0:
+            b = a + 0.1 * rs.randn(d)        # similar vectors: the gate is open when thres is moderate
+        x = np.concatenate([a, b, [0.0 if i < 4 else 10.0]])
+        if not np.array_equal(np.asarray(fn(0.002, x), dtype=float).reshape(-1), np.asarray(own(0.002, x), dtype=float).reshape(-1)):
+            return None
+    return ("gate", d, float(thres), float(rate))
+
+
 def shard_phases(model, shard):
     """Neuron-sharded model (SLAMNetwork on several GPUs): cut the timestep in two around ONE exchange.
 
@@ -1142,6 +1258,7 @@ def shard_phases(model, shard):
             idx = model.buffers[o["dst_idx"]].reshape(-1)
             full[idx], part[idx] = (not o.get("partial_out")), bool(o.get("partial_out"))
         elif k == "neurons":
+            need_full(o["j"], o["n"], "a neuron population")      # (a partial current must never reach the non-linearity)
             sl = slice(o["out"], o["out"] + o["n"])
             full[sl], part[sl] = True, False             # (a rank's own spike vector: local, never exchanged)
         elif k in ("gate", "cleanup"):
@@ -1157,6 +1274,7 @@ def shard_phases(model, shard):
             need_full(o["err"], o["rows"], "the PES error")
         elif k == "voja":
             need_full(o["key"], o["cols"], "the Voja key")
+            need_full(o["learn"], 1, "the Voja learning signal")
     for p in model.probes:
         if "src" in p and part[p["src"]:p["src"] + p["width"]].any():
             exchange.append((p["src"], p["src"] + p["width"]))

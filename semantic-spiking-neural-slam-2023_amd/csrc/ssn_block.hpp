@@ -97,9 +97,13 @@ __device__ inline f32x2 pk_fma_clamp01_vsv(f32x2 x, f32x2 y, f32x2 z) {         
   asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(x), "s"(y), "v"(z));
   return r;
 }
-__device__ inline f32x2 pk_fma_clamp01_vvs(f32x2 x, f32x2 y, f32x2 z) {          // clamp(x * y + z), z a uniform constant pair
+// clamp(x * y + z), z a uniform constant pair, x the RESULT OF A TRANSCENDENTAL (v_log_f32): gfx940-family hardware needs one
+// wait state between a transcendental's write and a non-transcendental VALU read of that register, and the compiler's hazard
+// recognizer does not look inside inline asm - so the wait state is part of the asm (without it the DOUT = 5 variants, whose
+// schedule put the v_log right in front, read the stale register: caught by the sharded-runner f32 test).
+__device__ inline f32x2 pk_fma_clamp01_trans_vvs(f32x2 x, f32x2 y, f32x2 z) {
   f32x2 r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(x), "v"(y), "s"(z));
+  asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(x), "v"(y), "s"(z));
   return r;
 }
 
@@ -155,7 +159,7 @@ __device__ inline f32x2 lif_packed_step_f32x2(f32x2 J, f32x2& s, const LifConstV
   f32x2 lg2;
   lg2.x = __builtin_amdgcn_logf(omu.x);
   lg2.y = __builtin_amdgcn_logf(omu.y);
-  const f32x2 nu = pk_fma_clamp01_vvs(lg2, (f32x2)(c.tau_ln2), (f32x2)(c.tau_ref));
+  const f32x2 nu = pk_fma_clamp01_trans_vvs(lg2, (f32x2)(c.tau_ln2), (f32x2)(c.tau_ref));
   const f32x2 Vn = pk_fma_clamp01_vsv(spk, nbig, V);
   s = __builtin_elementwise_fma(-spk, nu, mt + Vn);
   return spk;
@@ -606,12 +610,11 @@ constexpr int BLOCK_LDS_BYTES = 160 * 1024, BLOCK_STATIC_LDS = 2560;     // CU c
 template <typename T, int DIN, int DOUT, int NPT, int TPB, int LDSW>
 static hipError_t launch_block_variant(hipStream_t s, const BlockArgs<T>& a) {
   const int lds = LDSW * a.threads * NPT * (int)sizeof(T);
-  static bool configured = false;
-  if (LDSW > 0 && !configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ens_block<T, DIN, DOUT, NPT, TPB, LDSW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, BLOCK_LDS_BYTES - BLOCK_STATIC_LDS);
+  static std::atomic<uint64_t> configured{0};
+  if (LDSW > 0) {
+    hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(&k_ens_block<T, DIN, DOUT, NPT, TPB, LDSW>),
+                                            BLOCK_LDS_BYTES - BLOCK_STATIC_LDS, configured);
     if (e != hipSuccess) return e;
-    configured = true;
   }
   hipLaunchKernelGGL((k_ens_block<T, DIN, DOUT, NPT, TPB, LDSW>), dim3((unsigned)a.K), dim3((unsigned)a.threads), lds, s, a);
   return hipGetLastError();

@@ -565,12 +565,8 @@ hipError_t launch_dft(hipStream_t s, const DftBatch& b, int count) {
   int N = 0;
   for (int i = 0; i < count; ++i) N = std::max(N, b.a[i].M > 0 ? b.a[i].M : b.a[i].N);
   const int threads = std::min(1024, std::max(64, ((N + 3) / 4 + 63) / 64 * 64));      // four output points per thread (dft_stockham)
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dft<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 6400 * 3 * (int)sizeof(float2));
-    if (e != hipSuccess) return e;
-    configured = true;
-  }
+  static std::atomic<uint64_t> configured{0};
+  if (hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(&k_dft<0>), 6400 * 3 * (int)sizeof(float2), configured); e != hipSuccess) return e;
   hipLaunchKernelGGL((k_dft<0>), dim3(count), dim3(threads), (size_t)N * 3 * sizeof(float2), s, b);
   return hipGetLastError();
 }

@@ -3,8 +3,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace ssn {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: a process that drives simulators on several GPUs
+// (the `device` argument of ShardedPathIntegration / ShardedSLAM) has to make it once on each of them.  `done` is the
+// launcher's own bit mask of devices already configured (one static per kernel instantiation; any thread may launch).
+inline hipError_t set_max_dynamic_lds_once(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 template <typename T>
 struct NeuronParams {

@@ -277,12 +277,8 @@ __global__ __launch_bounds__(256) void k_round(RoundArgs<T> ra) {
 
 template <typename T>
 hipError_t launch_round(hipStream_t s, const RoundArgs<T>& ra, int n_blocks, size_t lds_bytes) {
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_round<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    if (e != hipSuccess) return e;
-    configured = true;
-  }
+  static std::atomic<uint64_t> configured{0};
+  if (hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(&k_round<T>), 64 * 1024, configured); e != hipSuccess) return e;
   if (lds_bytes > 64 * 1024 || n_blocks <= 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL((k_round<T>), dim3((unsigned)n_blocks), dim3(256), std::max<size_t>(lds_bytes, 64), s, ra);
   return hipGetLastError();

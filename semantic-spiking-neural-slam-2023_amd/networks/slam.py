@@ -70,7 +70,11 @@ class SLAMNetwork(nengo.Network):
         ovc_encoders = ssp_space.encode(ovc_pts)
         self.sample_ssps, self.sample_points = ssp_space.get_sample_pts_and_ssps(100)
         self.clean_up_fun = make_cleanup(self.sample_ssps)
-        self.grid_factors = ssp_space.grid_factors(100) if hasattr(ssp_space, "grid_factors") else None
+        if hasattr(ssp_space, "grid_factors"):
+            self.grid_factors = ssp_space.grid_factors(100)
+        else:                    # (a space object of the reference's own class: the factors are recovered from the table)
+            from ..sspspace import grid_factors_from_table
+            self.grid_factors = grid_factors_from_table(self.sample_ssps)
         unitary = _unitary_fn(ssp_space)
 
         with self:

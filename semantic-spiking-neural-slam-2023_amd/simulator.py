@@ -346,6 +346,25 @@ class Simulator:
                 self.prepare(steps)
         buf_probes = [(k, v[2]) for k, v in self._probe_index.items() if v[0] == "buf"]
         done = 0
+        self._collector = None
+        try:
+            self._step_loop(steps, profile, pipelined, buf_probes)
+        except BaseException:
+            # a failed run must not leave the helper threads or the bulk arrays of the pipelined read-back behind: the next
+            # run_steps would otherwise collect into stale arrays
+            if self._collector is not None:
+                self._collector.join()
+            self._collector, self._bulk, self._bulk_error = None, None, None
+            raise
+        self._uncollected = True
+        if collect:
+            self._collect()
+        self._prepared_until = max(self._prepared_until, self.n_steps)
+
+    _collector = None
+
+    def _step_loop(self, steps, profile, pipelined, buf_probes):
+        done = 0
         collector = None
         while done < steps:
             # Probes of learned signals ("weights", "scaled_encoders"): nengo adds a learning rule's delta to its target at
@@ -370,7 +389,12 @@ class Simulator:
                     import threading
                     box = {}
                     n_next = min(self.PIPELINE_CHUNK, steps - done - chunk)
-                    worker = threading.Thread(target=lambda: box.update(r=self._tabulate_chunk(nxt, n_next)))
+                    def tab(box=box, nxt=nxt, n_next=n_next):
+                        try:
+                            box.update(r=self._tabulate_chunk(nxt, n_next))
+                        except BaseException as e:       # noqa: BLE001 - re-raised on the caller's thread
+                            box["e"] = e
+                    worker = threading.Thread(target=tab)
                     worker.start()
             for _, p in buf_probes:          # stop before the next timestep whose sample is due (taken at the top of the loop)
                 r = (self.n_steps + 1) % p["every"]
@@ -382,17 +406,18 @@ class Simulator:
                 import threading
                 if collector is not None:
                     collector.join()
-                collector = threading.Thread(target=self._collect_bulk)
+                collector = self._collector = threading.Thread(target=self._collect_bulk)
                 collector.start()
             if worker is not None:
                 worker.join()
                 if "r" not in box:
-                    raise fe.SimulationError("evaluating the input nodes for the next chunk failed")
+                    raise fe.SimulationError("evaluating the input nodes for the next chunk failed") from box.get("e")
                 pipelined = box["r"]
                 if self.n_steps != pipelined[0]:          # a weight-probe boundary cut the chunk short: re-tabulate from here
                     pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_CHUNK, steps - done))
         if collector is not None:
             collector.join()
+        self._collector = None
         if getattr(self, "_bulk", None) is not None:
             self._collect_bulk()                     # the last chunk
             if self._bulk_error is not None:
@@ -404,10 +429,6 @@ class Simulator:
                 if n:
                     self._chunks[key].append(arr[:n])
             self._bulk = None
-        self._uncollected = True
-        if collect:
-            self._collect()
-        self._prepared_until = max(self._prepared_until, self.n_steps)
 
     def _probe_buffer_id(self, p):
         b = p["buf"]
@@ -456,10 +477,13 @@ class Simulator:
             width = p.get("width")
             return np.zeros((0, width)) if width else np.zeros((0,) + tuple(p["shape"]))
         if len(chunks) == 1:
-            return chunks[0]                 # (a pipelined run fetched straight into one array: no 80 MB copy)
-        merged = np.concatenate(chunks, axis=0)
-        self._chunks[key] = [merged]         # later reads of sim.data[probe] reuse it
-        return merged
+            out = chunks[0]                  # (a pipelined run fetched straight into one array: no 80 MB copy)
+        else:
+            out = np.concatenate(chunks, axis=0)
+            self._chunks[key] = [out]        # later reads of sim.data[probe] reuse it
+        view = out.view()
+        view.setflags(write=False)           # sim.data hands out read-only views of the simulator's storage, as nengo's does
+        return view
 
     def probe_tail(self, key, n):
         """The last ``n`` samples of a probe without concatenating the whole history."""

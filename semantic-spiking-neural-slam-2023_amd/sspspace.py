@@ -384,3 +384,45 @@ class RandomSSPSpace(SSPSpace):
         A = conjsym(phases)
         super().__init__(domain_dim, A.shape[0], A, domain_bounds=domain_bounds,
                          length_scale=length_scale, rng=rng)
+
+
+def grid_factors_from_table(S, tol=1e-9):
+    """The factor tables of ``HexagonalSSPSpace.grid_factors`` recovered from a clean-up table ALONE (the reference's
+    ``sample_ssps``, ``slam.py:209``: rows ``ifft(exp(i A x_j))`` over a ``np.meshgrid`` of n points per axis), for callers that
+    only hold the table - the reference's own ``SLAMNetwork`` running unmodified.  With F = the half spectrum of a row,
+    ``F[a * n_rest + r] = E1[a] * Erest[r]`` element-wise, so ``lhs[a] = F[a * n_rest]`` and ``rhs[r] = F[r] / F[0]`` reproduce
+    every row's spectrum; n is found by trying rows = n^2, n^3, n^4 and the factorisation is verified on random rows.  Returns
+    the same dict as ``grid_factors`` (factors equal up to a per-bin constant moved from one side to the other), or None."""
+    S = np.asarray(S)
+    rows, d = S.shape
+    if d % 2 == 0 or rows < 4:
+        return None
+    K = (d + 1) // 2
+    rs = np.random.RandomState(0)
+    for dim in (2, 3, 4):
+        n = int(round(rows ** (1.0 / dim)))
+        if n < 2 or n ** dim != rows:
+            continue
+        n_rest = rows // n
+        F_l = np.fft.fft(np.asarray(S[0::n_rest][:n], dtype=float), axis=1)[:, :K]           # rows a * n_rest + 0
+        F_r = np.fft.fft(np.asarray(S[:n_rest], dtype=float), axis=1)[:, :K]                 # rows 0 * n_rest + r
+        if np.any(np.abs(F_r[0]) < 1e-12):
+            continue
+        lhs, rhs = F_l, F_r / F_r[0][None, :]
+        js = rs.randint(0, rows, size=min(64, rows))
+        Fj = np.fft.fft(np.asarray(S[js], dtype=float), axis=1)[:, :K]
+        if np.abs(lhs[js // n_rest] * rhs[js % n_rest] - Fj).max() > tol:
+            continue
+        # rows must be real vectors whose spectrum the half spectrum determines (Hermitian): <S_j, x> = sum_k w_k Re(conj(X_k) F_j[k])
+        w = np.full(K, 2.0 / d)
+        w[0] = 1.0 / d
+
+        def interleave(z):
+            out = np.empty(z.shape[:-1] + (2 * z.shape[-1],))
+            out[..., 0::2], out[..., 1::2] = z.real, z.imag
+            return out
+        W = np.exp(-2j * np.pi * np.outer(np.arange(K), np.arange(d)) / d)
+        dft = np.empty((2 * K, d))
+        dft[0::2], dft[1::2] = W.real, W.imag
+        return {"dft": dft, "lhs": interleave(lhs * w[None, :]), "rhs": interleave(rhs)}
+    return None

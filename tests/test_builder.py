@@ -258,3 +258,76 @@ def test_two_pass_through_nodes_joined_by_synapses_in_both_directions():
     path, vels = H.make_random_path(20.0, limit=0.1, seed=0)
     sm = H.make_slam_model(s, path, vels, n_landmarks=10, pi_n_neurons=60, mem_n_neurons=120, circonv_n_neurons=30, view_rad=0.6)
     assert build(sm.model).stats["glue_retargeted_inputs"] >= 10
+
+
+def test_neuron_shard_refuses_what_it_cannot_split():
+    """ADVICE r2 (builder.shard_phases): a partial sum must never reach a non-linearity un-exchanged, and shapes the shard
+    builder cannot slice are refused with a BuildError instead of an IndexError deep in the lowering."""
+    def net(kind):
+        with nengo.Network(seed=3) as m:
+            u = nengo.Node(lambda t: [np.sin(6 * t), np.cos(6 * t)])
+            a = nengo.Ensemble(40, 2, label="a")
+            b = nengo.Ensemble(30, 2, label="b")
+            nengo.Connection(u, a, synapse=None)
+            if kind == "decoded into neurons":           # Ensemble -> other.neurons through a 30 x 2 matrix
+                nengo.Connection(a, b.neurons, transform=np.ones((30, 2)) * 0.1, synapse=0.01)
+            elif kind == "unfiltered decode into neurons":   # a's partial decoded sum reaches b's currents within the timestep
+                nengo.Connection(a, b, synapse=None)
+            nengo.Probe(b, synapse=0.01)
+        return m
+    with pytest.raises(nengo.BuildError, match="neurons of a neuron-sharded ensemble"):
+        build(net("decoded into neurons"), neuron_shard=(0, 2))
+    with pytest.raises(nengo.BuildError, match="partial sum"):
+        build(net("unfiltered decode into neurons"), neuron_shard=(0, 2))
+    # ... and both are fine when the reading ensemble's source is replicated or the model is not sharded
+    build(net("decoded into neurons"))
+    m = net("unfiltered decode into neurons")
+    build(m, neuron_shard=(0, 2), replicate=[m.ensembles[0]])
+
+
+def test_function_nodes_are_recognised_without_hints():
+    """builder._probe_function_node: the reference's clean-up lambda (slam.py:212-215,270) and gate (slam.py:233-237,249)
+    are recognised from closures + probes; constants come out exactly; look-alikes that behave differently are refused."""
+    from sspslam_amd.builder import _recognise_cleanup, _recognise_gate
+    from sspslam_amd import harness as H
+    from sspslam_amd.sspspace import grid_factors_from_table
+    space = H.make_ssp_space(2, 55)
+    S, _ = space.get_sample_pts_and_ssps(20)
+    d = S.shape[1]
+
+    def clean_up_fun(x):                          # the reference's closure, two levels deep under the node's lambda
+        sims = S @ x
+        return S[np.argmax(sims), :]
+    node_fn = lambda t, x: clean_up_fun(x)        # noqa: E731
+    kind, table, gf = _recognise_cleanup(node_fn, d, d)
+    assert kind == "cleanup" and table is not None and np.array_equal(table, S)
+    g0 = space.grid_factors(20)
+    assert gf is not None and gf["lhs"].shape == g0["lhs"].shape and gf["rhs"].shape == g0["rhs"].shape
+
+    def sims_of(g, x):
+        X = g["dft"] @ x
+        Xc = X[0::2] + 1j * X[1::2]
+        L, R = g["lhs"][:, 0::2] + 1j * g["lhs"][:, 1::2], g["rhs"][:, 0::2] + 1j * g["rhs"][:, 1::2]
+        return np.real((np.conj(Xc)[None, :] * L) @ R.T).reshape(-1)
+    x = np.random.RandomState(5).randn(d)
+    np.testing.assert_allclose(sims_of(gf, x), S @ x, atol=1e-12)
+    np.testing.assert_allclose(sims_of(g0, x), S @ x, atol=1e-12)
+    assert grid_factors_from_table(np.random.RandomState(0).randn(400, 55)) is None        # not a grid of SSPs
+    softer = lambda t, x: S[np.argsort(S @ x)[-2]]                                        # noqa: E731 - second best row
+    assert _recognise_cleanup(softer, d, d) is None
+
+    for thres, rate in ((0.2, 0.2), (0.35, 0.1), (-0.5, 1.5)):
+        def update_state_func(t, x, thres=thres, rate=rate):
+            if np.allclose(x[-1], 0, atol=1e-3) & (np.sum(x[:d] * x[d:-1]) > thres):
+                return rate * (x[:d] - x[d:-1])
+            return np.zeros(d)
+        assert _recognise_gate(update_state_func, 2 * d + 1, d) == ("gate", d, thres, rate)
+    leaky = lambda t, x: 0.2 * (x[:d] - x[d:-1]) if np.sum(x[:d] * x[d:-1]) > 0.2 else 0.01 * x[:d]      # noqa: E731
+    assert _recognise_gate(leaky, 2 * d + 1, d) is None
+    with nengo.Network(seed=0) as m:
+        u = nengo.Node(lambda t: np.ones(d))
+        f = nengo.Node(lambda t, x: np.tanh(x), size_in=d, size_out=d)
+        nengo.Connection(u, f, synapse=None)
+        nengo.Probe(f)
+    with pytest.raises(nengo.BuildError, match="function nodes with inputs"):
+        build(m)
