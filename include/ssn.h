@@ -169,6 +169,8 @@ typedef struct ssn_model_desc {
                                               predecessor in the same block),
                                          268435456 = k_dft also for chirp-z (Bluestein) transforms of 2048 points and more
                                               (default: their dense matrix - one workgroup needs 40 us for such a transform).
+                                         536870912 = the Stockham FFT of rounds 1 - 2 (generic radix-r butterflies through LDS) instead of the
+                                              four-step transform on the matrix cores (two small dense DFTs as f32 MFMA products, round 3).
                                          (Round 1's opt-in experiments 32, 64, 2048, 16384, 32768 - all measured slower - were removed.) */
 } ssn_model_desc;
 

@@ -678,11 +678,99 @@ struct Sim final : ssn_sim {
     return h;
   }
 
+  // ---- four-step transform on the matrix cores (dft4_fft): the split L = N1 * N2 and the two DFT matrices in MFMA lane order ----
+  // cost of a split in MFMA instructions (16 x 16 x 4, two per k step: real and imaginary rows / columns)
+  static long long dft4_cost(int N1, int N2, bool complex_in) {
+    const long long P1 = (N1 + 15) / 16, C1 = (N2 + 15) / 16, N1p = (N1 + 3) / 4 * 4, N2p = (N2 + 3) / 4 * 4;
+    return P1 * C1 * ((complex_in ? 2 : 1) * N1p / 4) * 2 + P1 * C1 * (2 * N2p / 4) * 2;
+  }
+  // best (N1, N2) with N1 * N2 = L, N2 <= 192 (the step-3 matrix is (2 N2)^2 floats); {0, 0} if L has no such divisor pair
+  static std::pair<int, int> dft4_split(int L, bool complex_in) {
+    std::pair<int, int> best{0, 0};
+    long long bc = -1;
+    for (int n1 = 1; n1 <= L; ++n1) {
+      if (L % n1) continue;
+      const int n2 = L / n1;
+      if (n2 > 192 || n1 > 192) continue;
+      const long long c = dft4_cost(n1, n2, complex_in);
+      if (bc < 0 || c < bc) { bc = c; best = {n1, n2}; }
+    }
+    return best;
+  }
+  int dft4_tables(int N1, int N2, const float** g1_out, const float** g2_out) {
+    const int key1 = (1 << 24) + N1 * 4096 + N2, key2 = (1 << 25) + N1 * 4096 + N2;
+    for (auto& t : dft_tables) if (t.first == key1) *g1_out = (const float*)t.second;
+    for (auto& t : dft_tables) if (t.first == key2) *g2_out = (const float*)t.second;
+    if (*g1_out && *g2_out) return SSN_OK;
+    const int P1 = (N1 + 15) / 16, Q2 = (N2 + 15) / 16, N1p = (N1 + 3) / 4 * 4, N2p = (N2 + 3) / 4 * 4;
+    const int KS1 = 2 * N1p / 4, KS3 = 2 * N2p / 4;
+    std::vector<float> g1((size_t)P1 * 2 * KS1 * 64, 0.0f), g2((size_t)Q2 * 2 * KS3 * 64, 0.0f);
+    for (int p = 0; p < P1; ++p)
+      for (int part = 0; part < 2; ++part)
+        for (int ks = 0; ks < KS1; ++ks)
+          for (int l = 0; l < 64; ++l) {
+            const int k1 = 16 * p + (l & 15), k = 4 * ks + (l >> 4);
+            const int n1 = k < N1p ? k : k - N1p;
+            if (k1 >= N1 || n1 >= N1) continue;
+            const double th = 2.0 * M_PI * (double)(((long long)k1 * n1) % N1) / (double)N1;
+            // F = cos - i sin: re out = cos xr + sin xi, im out = -sin xr + cos xi
+            const double v = part == 0 ? (k < N1p ? std::cos(th) : std::sin(th)) : (k < N1p ? -std::sin(th) : std::cos(th));
+            g1[(((size_t)p * 2 + part) * KS1 + ks) * 64 + l] = (float)v;
+          }
+    for (int q = 0; q < Q2; ++q)
+      for (int part = 0; part < 2; ++part)
+        for (int ks = 0; ks < KS3; ++ks)
+          for (int l = 0; l < 64; ++l) {
+            const int k2 = 16 * q + (l & 15), k = 4 * ks + (l >> 4);
+            const int n2 = k < N2p ? k : k - N2p;
+            if (k2 >= N2 || n2 >= N2) continue;
+            const double ph = 2.0 * M_PI * (double)(((long long)k2 * n2) % N2) / (double)N2;
+            // Xr = Br cos + Bi sin, Xi = -Br sin + Bi cos
+            const double v = part == 0 ? (k < N2p ? std::cos(ph) : std::sin(ph)) : (k < N2p ? -std::sin(ph) : std::cos(ph));
+            g2[(((size_t)q * 2 + part) * KS3 + ks) * 64 + l] = (float)v;
+          }
+    float* d1 = nullptr; float* d2 = nullptr;
+    CHK(dmalloc(&d1, (int64_t)g1.size() * 4));
+    CHK(dmalloc(&d2, (int64_t)g2.size() * 4));
+    HIPCHK(hipMemcpy(d1, g1.data(), g1.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d2, g2.data(), g2.size() * 4, hipMemcpyHostToDevice));
+    scratch_bufs.push_back(d1); scratch_bufs.push_back(d2);
+    dft_tables.push_back({key1, (float2*)d1}); dft_tables.push_back({key2, (float2*)d2});
+    *g1_out = d1; *g2_out = d2;
+    return SSN_OK;
+  }
+
   int plan_dft(const ssn_op_desc& o, ssn::DftArgs* a) {
     const int kind = (int)o.i[6];
     const int d = kind == 5 ? (int)o.i[2] : (int)o.i[3];
     *a = ssn::DftArgs{};
     if (d < 8 || d > 6400) return SSN_OK;
+    if (!(flags & 536870912)) {
+      // default since round 3: the four-step transform on the matrix cores; a length without a usable divisor pair (a prime
+      // above 192, or 2 x such a prime ...) goes through Bluestein's convolution of the cheapest length M in [2d - 1, 2d - 1 + 12 %]
+      std::pair<int, int> sp = dft4_split(d, kind == 5);
+      int M = 0;
+      if (!sp.first) {
+        long long bc = -1;
+        for (int c = 2 * d - 1; c <= 6400 && c <= (2 * d - 1) + (2 * d - 1) / 8; ++c) {
+          const std::pair<int, int> s2 = dft4_split(c, true);
+          if (!s2.first) continue;
+          const long long cost = dft4_cost(s2.first, s2.second, true);
+          if (bc < 0 || cost < bc) { bc = cost; M = c; sp = s2; }
+        }
+      }
+      if (sp.first) {
+        const int L = M > 0 ? M : d;
+        float2* tw = nullptr;
+        CHK(dft_table(L, twiddles(L), &tw));
+        if (M > 0) CHK(bluestein_tables(d, M, a));
+        const float* g1 = nullptr; const float* g2 = nullptr;
+        CHK(dft4_tables(sp.first, sp.second, &g1, &g2));
+        a->src = (const float*)(sig + o.i[1]); a->dst = (float*)(sig + o.i[0]); a->tw = tw; a->N = d; a->kind = kind;
+        a->set = (int)o.i[5]; a->nr = 0; a->N1 = sp.first; a->N2 = sp.second; a->g1 = g1; a->g2 = g2;
+        return SSN_OK;
+      }
+    }
     std::vector<int> rad = smooth_radices(d);
     int L = d, M = 0;
     if (rad.empty()) {
@@ -700,7 +788,15 @@ struct Sim final : ssn_sim {
     if (rad.empty() || rad.size() > 12) return SSN_OK;
     float2* tw = nullptr;
     CHK(dft_table(L, twiddles(L), &tw));
-    if (M > 0) {
+    if (M > 0) CHK(bluestein_tables(d, M, a));
+    a->src = (const float*)(sig + o.i[1]); a->dst = (float*)(sig + o.i[0]); a->tw = tw; a->N = d; a->kind = kind;
+    a->set = (int)o.i[5]; a->nr = (int)rad.size();
+    for (size_t i = 0; i < rad.size(); ++i) a->radix[i] = rad[i];
+    return SSN_OK;
+  }
+
+  int bluestein_tables(int d, int M, ssn::DftArgs* a) {
+    {
       // chirp w_n = exp(-i pi n^2 / d) with the phase reduced exactly (n^2 mod 2d), and the spectrum of its wrapped conjugate
       std::vector<float2> w((size_t)d);
       std::vector<double> br((size_t)M, 0.0), bi((size_t)M, 0.0);
@@ -727,12 +823,9 @@ struct Sim final : ssn_sim {
       }
       float2* dw = nullptr; float2* dfb = nullptr;
       CHK(dft_table(-d, w, &dw));
-      CHK(dft_table(-(1 << 20) - d, fb, &dfb));
+      CHK(dft_table(-(1 << 20) - d - (M << 3), fb, &dfb));     // (the spectrum depends on M too: the two engines pick different lengths)
       a->M = M; a->chirp = dw; a->fb = dfb;
     }
-    a->src = (const float*)(sig + o.i[1]); a->dst = (float*)(sig + o.i[0]); a->tw = tw; a->N = d; a->kind = kind;
-    a->set = (int)o.i[5]; a->nr = (int)rad.size();
-    for (size_t i = 0; i < rad.size(); ++i) a->radix[i] = rad[i];
     return SSN_OK;
   }
 
@@ -1687,6 +1780,7 @@ struct Sim final : ssn_sim {
       return in.round;
     };
     // Launch sequence of a set of instances grouped by round (instances of one round are mutually independent).
+    const bool no_interleave = getenv("SSN_ROUND_INTERLEAVE") && atoi(getenv("SSN_ROUND_INTERLEAVE")) == 0;      // A/B knob
     std::vector<int> chain_tab;
     auto emit = [&](const std::vector<Inst>& insts, int n_rounds, std::vector<Launch>& out, const std::vector<std::vector<int>>& chains) {
       std::vector<std::vector<const Inst*>> by_round((size_t)n_rounds);
@@ -1701,6 +1795,23 @@ struct Sim final : ssn_sim {
         std::vector<Launch> plain;
         auto close = [&]() {
           if (rl.args.n == 0) return;
+          // interleaved dispatch of the big grids behind the latency-bound head (RoundArgs::stride)
+          rl.args.head = 0; rl.args.stride = 0;
+          if (!no_interleave) {
+            int head = 0;
+            for (int q = 0; q < rl.args.n; ++q) {
+              const int k = rl.args.e[q].kind;
+              if (k == ssn::RK_DFT || k == ssn::RK_GATE || k == ssn::RK_ARGMAX || k == ssn::RK_GLUE) head = rl.args.e[q].first + rl.args.e[q].cnt;
+              else break;
+            }
+            const long long m = (long long)rl.n_blocks - head;
+            if (m >= 64) {
+              long long st = (long long)(0.6180339887 * (double)m);
+              auto gcd = [](long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a; };
+              while (st > 1 && gcd(st, m) != 1) --st;
+              if (st > 1) { rl.args.head = head; rl.args.stride = (unsigned int)st; }
+            }
+          }
           Launch l; l.rl = (int)round_launches.size(); l.phase = phase;
           round_launches.push_back(rl);
           out.push_back(l);
@@ -1808,8 +1919,8 @@ struct Sim final : ssn_sim {
               continue;
             }
             case IT_DFT: {
-              const size_t lds = (size_t)(it.dft.M > 0 ? it.dft.M : it.dft.N) * 3 * sizeof(float2);
-              if (lds <= 60 * 1024) {
+              const size_t lds = (size_t)(it.dft.M > 0 ? it.dft.M : it.dft.N) * (it.dft.N1 > 0 ? 4 * sizeof(float) : 3 * sizeof(float2));
+              if (lds <= 64 * 1024) {
                 if (ao < 0) ao = (long long)put(&it.dft, sizeof it.dft);
                 entry(ssn::RK_DFT, 1, 1, lds, 0, (size_t)ao);
                 continue;

@@ -494,7 +494,158 @@ __device__ inline float2* dft_stockham(float2* x, float2* y, const float2* tw, i
   return x;
 }
 
+// ---------------------------------------------------------------------------------------------
+// dft4_fft: the same transforms as a FOUR-STEP FFT on the matrix cores (round 3).  L = N1 * N2, input index n = N2 n1 + n2
+// (the natural array IS the N1 x N2 matrix), output index k = k1 + N1 k2:
+//   step 1   A[k1, n2] = sum_n1 W_N1^(k1 n1) x[n1, n2]          one (2 N1 x 2 N1) . (2 N1 x N2) real product  (K = N1 for real input)
+//   step 2   B[k1, n2] = A[k1, n2] W_L^(k1 n2)                   on the accumulators, in registers
+//   step 3   X[k1, k2] = sum_n2 B[k1, n2] W_N2^(n2 k2)          one (N1 x 2 N2) . (2 N2 x 2 N2) real product
+// with complex products written as real ones ([Ar; Ai] = [[Fr, -Fi], [Fi, Fr]] [xr; xi]).  The two small DFT matrices
+// come precomputed in MFMA lane order (v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
+// result col = l & 15, row = 4 (l >> 4) + reg), real and imaginary rows (columns) of the same 16 indices in adjacent
+// tiles, so that ONE wave holds both parts of an element in the same lane and register: the twiddle multiply and the
+// planar stores need no exchange.  A 1015-point transform (29 x 35) is ~0.4 Mflop - ~100 MFMAs per wave of a
+// 256-thread workgroup - against 41 dependent LDS round trips per point in the Stockham passes (generic radix-29 / 7 / 5
+// butterflies): the radix-r butterflies are what a dense r x r DFT matrix IS, and the matrix cores do them as such.
+// Any factorisation works (no radix limit), so a prime length up to 181 is a single dense DFT (N1 = 1).
+// LDS: four planar float arrays of L (16 B per point; the Stockham passes take 24).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+struct Dft4Io { float* xr; float* xi; float* br; float* bi; };
+
+__device__ inline void dft4_fft(const DftArgs& a, const Dft4Io& io, const bool real_in, const bool need_imag, const int n_out,
+                                const int tid, const int nthr) {
+  const int N1 = a.N1, N2 = a.N2, L = N1 * N2;
+  const int lane = tid & 63, wave = tid >> 6, n_waves = nthr >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int P1 = (N1 + 15) >> 4, C1 = (N2 + 15) >> 4;          // step 1: row-tile pairs x column tiles
+  const int N1p = (N1 + 3) & ~3, N2p = (N2 + 3) & ~3;
+  const int KS1_all = 2 * N1p / 4, KS1 = real_in ? N1p / 4 : KS1_all;
+  // ---- step 1 + 2 -------------------------------------------------------------------------------------------------------
+  for (int task = wave; task < P1 * C1; task += n_waves) {
+    const int p = task / C1, ct = task - p * C1;
+    f32x4v ar = {0.0f, 0.0f, 0.0f, 0.0f}, ai = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float* gr = a.g1 + ((size_t)(p * 2 + 0) * KS1_all) * 64 + lane;
+    const float* gi = a.g1 + ((size_t)(p * 2 + 1) * KS1_all) * 64 + lane;
+    const int n2 = ct * 16 + li;
+    for (int ks = 0; ks < KS1; ++ks) {
+      const int k = 4 * ks + lk;                             // K index: [0, N1p) real input rows, [N1p, 2 N1p) imaginary ones
+      const int n1 = k < N1p ? k : k - N1p;
+      const float* src = k < N1p ? io.xr : io.xi;
+      const float b = (n1 < N1 && n2 < N2) ? src[n1 * N2 + n2] : 0.0f;
+      ar = __builtin_amdgcn_mfma_f32_16x16x4f32(gr[(size_t)ks * 64], b, ar, 0, 0, 0);
+      ai = __builtin_amdgcn_mfma_f32_16x16x4f32(gi[(size_t)ks * 64], b, ai, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int k1 = p * 16 + 4 * lk + v;
+      if (k1 < N1 && n2 < N2) {
+        const float2 w = a.tw[(unsigned)(k1 * n2) % (unsigned)L];          // exp(-2 pi i k1 n2 / L)
+        io.br[k1 * N2 + n2] = ar[v] * w.x - ai[v] * w.y;
+        io.bi[k1 * N2 + n2] = ar[v] * w.y + ai[v] * w.x;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- step 3: X[k1 + N1 k2]; only the column tiles that hold an index below n_out --------------------------------------
+  const int R3 = P1, KS3 = 2 * N2p / 4;
+  int Q3 = (N2 + 15) >> 4;
+  while (Q3 > 1 && N1 * 16 * (Q3 - 1) >= n_out) --Q3;        // (k >= N1 k2: tile pair q starts at k2 = 16 q)
+  for (int task = wave; task < R3 * Q3; task += n_waves) {
+    const int rt = task / Q3, q = task - rt * Q3;
+    f32x4v xr = {0.0f, 0.0f, 0.0f, 0.0f}, xi = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float* gr = a.g2 + ((size_t)(q * 2 + 0) * KS3) * 64 + lane;
+    const float* gi = a.g2 + ((size_t)(q * 2 + 1) * KS3) * 64 + lane;
+    const int k1a = rt * 16 + li;                            // A operand row
+    for (int ks = 0; ks < KS3; ++ks) {
+      const int k = 4 * ks + lk;
+      const int n2 = k < N2p ? k : k - N2p;
+      const float* src = k < N2p ? io.br : io.bi;
+      const float av = (k1a < N1 && n2 < N2) ? src[k1a * N2 + n2] : 0.0f;
+      xr = __builtin_amdgcn_mfma_f32_16x16x4f32(av, gr[(size_t)ks * 64], xr, 0, 0, 0);
+      if (need_imag) xi = __builtin_amdgcn_mfma_f32_16x16x4f32(av, gi[(size_t)ks * 64], xi, 0, 0, 0);
+    }
+    const int k2 = q * 16 + li;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int k1 = rt * 16 + 4 * lk + v;
+      const int kk = k1 + N1 * k2;
+      if (k1 < N1 && k2 < N2 && kk < n_out) { io.xr[kk] = xr[v]; if (need_imag) io.xi[kk] = xi[v]; }
+    }
+  }
+  __syncthreads();
+}
+
+// The transforms of dft_body through dft4_fft (planar LDS arrays).
+__device__ __forceinline__ void dft4_body(const DftArgs& a, unsigned char* ssn_dft_dyn) {
+  const int N = a.N, H = N / 2 + 1, tid = threadIdx.x, nthr = blockDim.x;
+  const int L = a.M > 0 ? a.M : N;
+  float* base = reinterpret_cast<float*>(ssn_dft_dyn);
+  const Dft4Io io{base, base + L, base + 2 * L, base + 3 * L};
+  const bool bluestein = a.M > 0;
+  for (int i = tid; i < L; i += nthr) {
+    float re = 0.0f, im = 0.0f;
+    if (i < N) {
+      if (a.kind != 5) re = a.src[i];
+      else {
+        const int w = i < H ? i : N - i;
+        const float* p = a.src + 4 * w;
+        re = p[0] - p[1];
+        im = p[2] + p[3];
+        if (w == 0 || 2 * w == N) im = 0.0f;            // purely real bins (their imaginary slots carry no signal)
+        im = i < H ? -im : im;                          // Z[i] = Y_w or conj(Y_w); the inverse is conj(FFT(conj Z)): load conj Z
+      }
+      if (bluestein) {                                  // a_n = x_n w_n
+        const float2 c = a.chirp[i];
+        const float r2 = re * c.x - im * c.y;
+        im = re * c.y + im * c.x;
+        re = r2;
+      }
+    }
+    io.xr[i] = re;
+    io.xi[i] = im;
+  }
+  __syncthreads();
+  if (!bluestein) {
+    // forward kinds: real input, the half spectrum; inverse: complex (Hermitian) input, only the real part of every point
+    dft4_fft(a, io, a.kind != 5, a.kind != 5, a.kind != 5 ? H : N, tid, nthr);
+  } else {
+    dft4_fft(a, io, false, true, L, tid, nthr);
+    for (int i = tid; i < L; i += nthr) {               // spectrum of the convolution; conj for the transform back (1 / M folded into fb)
+      const float vr = io.xr[i], vi = io.xi[i];
+      const float2 f = a.fb[i];
+      io.xr[i] = vr * f.x - vi * f.y;
+      io.xi[i] = -(vr * f.y + vi * f.x);
+    }
+    __syncthreads();
+    dft4_fft(a, io, false, true, N, tid, nthr);
+    for (int i = tid; i < N; i += nthr) {
+      const float vr = io.xr[i], vi = -io.xi[i];
+      const float2 c = a.chirp[i];
+      io.xr[i] = vr * c.x - vi * c.y;
+      io.xi[i] = vr * c.y + vi * c.x;
+    }
+    __syncthreads();
+  }
+  if (a.kind != 5) {
+    const bool conj = a.kind >= 3, slotB = a.kind == 2 || a.kind == 4;
+    for (int w = tid; w < H; w += nthr) {
+      const float re = io.xr[w], im = conj ? -io.xi[w] : io.xi[w];
+      float* d = a.dst + 4 * w;
+      const float v2 = slotB ? im : re, v3 = slotB ? re : im;
+      if (a.set) { d[0] = re; d[1] = im; d[2] = v2; d[3] = v3; }
+      else { d[0] += re; d[1] += im; d[2] += v2; d[3] += v3; }
+    }
+  } else {
+    const float inv = 1.0f / (float)N;
+    for (int i = tid; i < N; i += nthr) {
+      const float v = io.xr[i] * inv;
+      if (a.set) a.dst[i] = v; else a.dst[i] += v;
+    }
+  }
+}
+
 __device__ __forceinline__ void dft_body(const DftArgs& a, unsigned char* ssn_dft_dyn) {
+  if (a.N1 > 0) { dft4_body(a, ssn_dft_dyn); return; }
   const int N = a.N, H = N / 2 + 1, tid = threadIdx.x, nthr = blockDim.x;
   const int L = a.M > 0 ? a.M : N;              // length of the transforms actually run
   float2* x = reinterpret_cast<float2*>(ssn_dft_dyn);
@@ -564,7 +715,11 @@ template <typename T>
 hipError_t launch_dft(hipStream_t s, const DftBatch& b, int count) {
   int N = 0;
   for (int i = 0; i < count; ++i) N = std::max(N, b.a[i].M > 0 ? b.a[i].M : b.a[i].N);
-  const int threads = std::min(1024, std::max(64, ((N + 3) / 4 + 63) / 64 * 64));      // four output points per thread (dft_stockham)
+  int threads = std::min(1024, std::max(64, ((N + 3) / 4 + 63) / 64 * 64));      // four output points per thread (dft_stockham)
+  if (b.a[0].N1 > 0) {                // four-step: one wave per tile task of the larger step (at most 16 waves)
+    const int tasks = ((b.a[0].N1 + 15) / 16) * ((b.a[0].N2 + 15) / 16);
+    threads = std::min(1024, std::max(256, tasks * 64));
+  }
   static std::atomic<uint64_t> configured{0};
   if (hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(&k_dft<0>), 6400 * 3 * (int)sizeof(float2), configured); e != hipSuccess) return e;
   hipLaunchKernelGGL((k_dft<0>), dim3(count), dim3(threads), (size_t)N * 3 * sizeof(float2), s, b);
@@ -1409,7 +1564,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // time-batched stages are small (384 tiles at 1000 x 1524 on 256 CUs), so a CU holds one or two tiles - with four waves
 // per tile (one 32 x 32 accumulator each, the first version) a SIMD had a single wave and nothing to hide its operand
 // loads behind; four waves per SIMD measured 10 % faster (48 vs 54 us).
-typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int BK>
 __global__ __launch_bounds__(1024) void kb_gemm_mfma_f32(BatchOp<float> o) {
   __shared__ float As[64][BK + 4];          // row stride 36: (36 row + k) mod 64 is distinct for 16 rows x 4 k - conflict-free operand reads

@@ -140,6 +140,11 @@ struct DftArgs {
   int M;                 // 0: N is transformed directly
   const float2* chirp;   // w_n = exp(-i pi n^2 / N), n = 0..N-1
   const float2* fb;      // FFT_M of the wrapped conjugate chirp, divided by M
+  // Four-step transform on the matrix cores (dft4_fft, ssn_kernels.hpp), used instead of the Stockham passes when N1 > 0:
+  // L = N1 * N2 (L = M for Bluestein), two small dense DFTs as f32 MFMA products around a twiddle multiply.
+  int N1, N2;
+  const float* g1;       // step-1 A operand in MFMA lane order: [ceil(N1 / 16) row-tile pairs][re rows | im rows][k steps][64]
+  const float* g2;       // step-3 B operand: [ceil(N2 / 16) column-tile pairs][re cols | im cols][k steps][64]
 };
 
 // Independent operators of one kind that the scheduler placed next to each other share one launch
@@ -237,6 +242,13 @@ constexpr int MAX_ROUND_ENTRIES = 96;
 template <typename T>
 struct RoundArgs {
   int n;
+  int head;                 // blocks [0, head) run the virtual block of their own index (latency-bound bodies first); see stride
+  // Interleaved dispatch (round 3): block b >= head runs virtual block head + ((b - head) * stride) mod (gridDim - head), with
+  // stride coprime to the modulus and ~0.618 of it.  The grid's blocks are dispatched in index order and the entries own
+  // contiguous virtual ranges, so without this a round ran its bodies ONE AFTER THE OTHER (the oscillators' HBM-bound blocks,
+  // then the Voja rows, then 8 000 latency-bound product-ensemble blocks ...: 70 us = the sum of the bodies' stand-alone times);
+  // the stride deals every entry's blocks evenly over the whole launch, so bandwidth-bound and latency-bound bodies share the CUs.
+  unsigned int stride;      // 0 / 1: identity
   int pad;
   const MicroOp<T>* mops;
   const int* chain;

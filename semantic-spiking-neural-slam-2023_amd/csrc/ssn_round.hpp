@@ -267,7 +267,12 @@ __device__ __forceinline__ void round_block(const RoundArgs<T>& ra, int vb, unsi
 template <typename T>
 __global__ __launch_bounds__(256) void k_round(RoundArgs<T> ra) {
   extern __shared__ __align__(16) unsigned char ssn_round_smem[];
-  round_block<T>(ra, (int)blockIdx.x, ssn_round_smem);
+  int vb = (int)blockIdx.x;
+  if (ra.stride > 1u && vb >= ra.head) {
+    const unsigned int m = gridDim.x - (unsigned int)ra.head;
+    vb = ra.head + (int)(((unsigned long long)(unsigned int)(vb - ra.head) * ra.stride) % m);
+  }
+  round_block<T>(ra, vb, ssn_round_smem);
 }
 
 // (A persistent variant - all rounds of a step graph in one resident grid with grid barriers - was built, tested and

@@ -487,7 +487,7 @@ class ShardedSLAM:
             self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
             failed = bool(flag.item() > 0)
         if failed:
-            raise nengo.SimulationError(f"sharded SLAM run refused on rank {self.rank}" if err is not None else
+            raise nengo.SimulationError(f"sharded SLAM run refused on rank {self.rank}: {err}" if err is not None else
                                         "sharded SLAM run refused: another rank failed its pre-flight check") from err
 
     def run_steps(self, n):

@@ -337,15 +337,19 @@ def test_slamview_f64_matches_oracle(Simulator):
 
 
 def test_dft_kernel_matches_the_transform_matrices(Simulator):
-    """k_dft (mixed-radix FFT for the circular-convolution transforms, f32 core) against the dense real-DFT
-    matrices it replaces (reference binding.py:23-74): in ONE run, the probed output of each transform equals
-    matrix @ probed input.  d = 25 (5*5, repeated radix), 55 (11*5), 217 (31*7), 1015 (29*7*5, the benchmark's dimension);
-    both operand layouts, with and without involution; the inverse transform.  d = 97 (prime) and d = 1801 (prime: what
-    ssp_dim = 2047 gives in 3-D, BASELINE config 5) go through Bluestein's convolution."""
+    """k_dft (the FFT of the circular-convolution transforms, f32 core) against the dense real-DFT matrices it replaces
+    (reference binding.py:23-74): in ONE run, the probed output of each transform equals matrix @ probed input.  Both
+    engines: the four-step transform on the matrix cores (default since round 3: two small dense DFTs as f32 MFMA products
+    around a twiddle multiply) and the Stockham passes of rounds 1 - 2 (flag 536870912).  d = 25 (5 x 5), 55 (5 x 11),
+    217 (7 x 31), 1015 (35 x 29, the benchmark's dimension), 97 (prime: ONE dense DFT in the four-step engine, Bluestein in the
+    Stockham one); d = 1801 (prime; what ssp_dim = 2047 gives in 3-D, BASELINE config 5) and d = 2049 (3 x 683; SURVEY's other
+    reading of config 5) go through Bluestein's convolution in both; both operand layouts, with and without involution; the
+    inverse transform."""
     from sspslam_amd.networks import CircularConvolution
     from sspslam_amd.builder import dft_structure
+    STOCKHAM, BIG = 536870912, 268435456
     for d, inv_a, inv_b in ((25, False, True), (55, True, False), (217, False, False), (97, False, True), (1015, True, False),
-                            (1801, True, False)):
+                            (1801, True, False), (2049, False, True)):
         rng = np.random.RandomState(d)
         fa, fb = rng.randn(d) / np.sqrt(d), rng.randn(d) / np.sqrt(d)
         with nengo.Network(seed=1) as m:
@@ -368,19 +372,22 @@ def test_dft_kernel_matches_the_transform_matrices(Simulator):
         kinds = sorted(o.get("dft", 0) for o in model.ops if o["kind"] == "matvec" and o.get("dft"))
         assert kinds == sorted([3 if inv_a else 1, 4 if inv_b else 2, 5]), kinds
         assert dft_structure(cc.transform_out) == 5 and dft_structure(np.eye(8)) == 0
-        if d == 1801:       # a 4096-point chirp-z transform: the planner prefers the 26 MB matrix (one workgroup needs 40 us for it)
+        big = d in (1801, 2049)
+        if big:       # a chirp-z transform of 2048+ points: the planner prefers the dense matrix (spread over the chip) by default
             with Simulator(None, model=model, dtype="f32") as sim:
                 assert sim.counters()["fft_transforms"] == 0
-        with Simulator(None, model=model, dtype="f32", flags=268435456 if d == 1801 else 0) as sim:
-            sim.run_steps(120)
-            a, b, fa_, fb_ = sim.data[p_a], sim.data[p_b], sim.data[p_fa], sim.data[p_fb]
-            prod, out = sim.data[p_prod], sim.data[p_out]
-            c = sim.counters()
-            assert c["fft_transforms"] == 3 and c["fft_bluestein"] == (3 if d in (97, 1801) else 0), c
-        assert np.abs(a).max() > 0.01 and np.abs(prod).max() > 1e-4
-        np.testing.assert_allclose(fa_, a @ cc.transform_a.T, atol=2e-6 * np.sqrt(d))
-        np.testing.assert_allclose(fb_, b @ cc.transform_b.T, atol=2e-6 * np.sqrt(d))
-        np.testing.assert_allclose(out, prod @ cc.transform_out.T, atol=2e-6)
+        for engine in (0, STOCKHAM):
+            with Simulator(None, model=model, dtype="f32", flags=engine | (BIG if big else 0)) as sim:
+                sim.run_steps(120)
+                a, b, fa_, fb_ = sim.data[p_a], sim.data[p_b], sim.data[p_fa], sim.data[p_fb]
+                prod, out = sim.data[p_prod], sim.data[p_out]
+                c = sim.counters()
+                n_blue = 3 if (big or (d == 97 and engine == STOCKHAM)) else 0
+                assert c["fft_transforms"] == 3 and c["fft_bluestein"] == n_blue, (d, engine, c)
+            assert np.abs(a).max() > 0.01 and np.abs(prod).max() > 1e-4
+            np.testing.assert_allclose(fa_, a @ cc.transform_a.T, atol=2e-6 * np.sqrt(d), err_msg=f"d {d} engine {engine}")
+            np.testing.assert_allclose(fb_, b @ cc.transform_b.T, atol=2e-6 * np.sqrt(d), err_msg=f"d {d} engine {engine}")
+            np.testing.assert_allclose(out, prod @ cc.transform_out.T, atol=2e-6, err_msg=f"d {d} engine {engine}")
 
 
 def test_slam_optin_plans_equal_default(Simulator):

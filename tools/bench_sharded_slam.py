@@ -19,6 +19,7 @@ ap.add_argument("--circonv-n-neurons", type=int, default=100)
 ap.add_argument("--steps", type=int, default=256)
 ap.add_argument("--eval-points", type=int, default=4000)
 ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+ap.add_argument("--host-loop", action="store_true", help="round 2's loop: a blocking ssn_run_phase and a blocking exchange per timestep (A/B)")
 a = ap.parse_args()
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
@@ -37,7 +38,7 @@ t0 = time.time()
 r = None
 for turn in range(world if shared else 1):          # ranks sharing a GPU build one after the other (rocSOLVER)
     if not shared or turn == rank:
-        r = ShardedSLAM(sm, rank, world, dtype="f32", device=local, n_eval_points=a.eval_points)
+        r = ShardedSLAM(sm, rank, world, dtype="f32", device=local, n_eval_points=a.eval_points, host_loop=a.host_loop)
     if shared and world > 1:
         dist.barrier()
 build_s = time.time() - t0
@@ -63,8 +64,8 @@ if world > 1:
     wall, ex = float(w[0]), float(w[1])
 if rank == 0:
     n_ex = sum(hi - lo for lo, hi in r.model.exchange)
-    print("sharded SLAM x%d (%s): %.1f us per timestep (%.2f sim-s/wall-s), exchange of %d values alone %.1f us; build %.0f s; "
-          "launches per timestep %d" % (world, a.dist_backend, 1e6 * wall / a.steps, a.steps * 1e-3 / wall, n_ex, 1e6 * ex, build_s,
+    print("sharded SLAM x%d (%s, %s): %.1f us per timestep (%.2f sim-s/wall-s), exchange of %d values alone %.1f us; build %.0f s; "
+          "launches per timestep %d" % (world, a.dist_backend, "stream-ordered run" if r._stream_ordered() else "host loop", 1e6 * wall / a.steps, a.steps * 1e-3 / wall, n_ex, 1e6 * ex, build_s,
                                         r.sim.counters()["launches_per_step"]), flush=True)
 r.close()
 if world > 1:
