@@ -169,8 +169,10 @@ typedef struct ssn_model_desc {
                                               predecessor in the same block),
                                          268435456 = k_dft also for chirp-z (Bluestein) transforms of 2048 points and more
                                               (default: their dense matrix - one workgroup needs 40 us for such a transform).
-                                         536870912 = the Stockham FFT of rounds 1 - 2 (generic radix-r butterflies through LDS) instead of the
-                                              four-step transform on the matrix cores (two small dense DFTs as f32 MFMA products, round 3).
+                                         536870912 = the four-step FFT on the matrix cores (two small dense DFTs as f32 MFMA products around a
+                                              twiddle multiply, round 3; any factorisation, primes up to 192 as one dense DFT) instead of
+                                              the Stockham passes (generic radix-r butterflies through LDS).  Correct for every length of the
+                                              tests, but measured no faster (its operand loads are latency-bound): opt-in.
                                          (Round 1's opt-in experiments 32, 64, 2048, 16384, 32768 - all measured slower - were removed.) */
 } ssn_model_desc;
 
@@ -252,7 +254,8 @@ int ssn_exchange_unpack(ssn_sim* sim, const void* src_dev);
  *   [phase 0 / 2: the exchange ranges (this rank's partial sums) -> exchange_buf]
  * exchange_buf: device buffer of ssn_exchange_size() elements of the simulator's dtype, the same pointer throughout a run (it is
  * captured into the graphs); NULL when the caller does not exchange (a single rank).  A run is
- *   ssn_phase_async(0), [collective on hip_stream], ssn_phase_async(2), [collective], ..., ssn_phase_async(1), ssn_phase_sync. */
+ *   ssn_phase_async(0), [collective on hip_stream], ssn_phase_async(2), [collective], ..., ssn_phase_async(1), ssn_phase_sync.
+ * phase = -1 only builds the graphs for exchange_buf (otherwise built by the first call of a run) and launches nothing. */
 int ssn_phase_async(ssn_sim* sim, int32_t phase, void* exchange_buf, void* hip_stream);
 /* Waits for everything ssn_phase_async enqueued on that stream; checks the device step counter and the probe-overflow flag. */
 int ssn_phase_sync(ssn_sim* sim, void* hip_stream);

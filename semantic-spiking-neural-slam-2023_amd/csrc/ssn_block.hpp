@@ -82,6 +82,21 @@ __device__ inline f32x2 pk_clamp01(f32x2 x) {
   asm("v_pk_mul_f32 %0, %1, 1.0 op_sel_hi:[1,0] clamp" : "=v"(r) : "v"(x));
   return r;
 }
+__device__ inline f32x2 pk_neg_clamp01(f32x2 x) {                    // clamp(-x)
+  f32x2 r;
+  asm("v_pk_mul_f32 %0, %1, -1.0 op_sel_hi:[1,0] clamp" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ inline f32x2 pk_sub_clamp01(f32x2 x, f32x2 y) {          // clamp(x - y), y a uniform constant pair
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(r) : "v"(x), "s"(y));
+  return r;
+}
+__device__ inline f32x2 pk_rsub_clamp01(f32x2 x, f32x2 y) {         // clamp(y - x), y a uniform constant pair
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[1,0] neg_hi:[1,0] clamp" : "=v"(r) : "v"(x), "s"(y));
+  return r;
+}
 __device__ inline f32x2 pk_mul_clamp01(f32x2 x, f32x2 y) {
   f32x2 r;
   asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "s"(y));          // (y: a uniform constant pair)
@@ -118,10 +133,10 @@ __device__ inline f32x2 pk_fma_clamp01_trans_vvs(f32x2 x, f32x2 y, f32x2 z) {
 //                  start of the next step (> dt; a refractory time <= dt is not stored: the next step integrates for the
 //                  full dt whatever its value)
 //   V0 = clamp(s)                 max(s, 0)
-//   m  = s - V0                   min(s, 0)                                       (exact: one of the two is zero)
-//   t  = m + dt                   dt - (R - dt): what is left of this step after the refractory period (<= dt)
-//   delta = clamp(t)              integration time  (nengo: clip(dt - refractory, 0, dt))
-//   mt = t - delta                min(t, 0): < 0 while the neuron stays refractory beyond the next step - the new state word
+//   r  = clamp(-s)                max(-s, 0) = R - dt of a refractory neuron (< 1), else 0
+//   delta = clamp(dt - r)         integration time  (nengo: clip(dt - refractory, 0, dt)); t = dt - r is what is left of this step
+//   nmt = clamp(r - dt)           -min(t, 0): > 0 while the neuron stays refractory beyond the next step - minus the new state
+//                                 word (r - dt = -(dt - r) exactly, so this is round 2's t - clamp(t) with one operation less)
 //   em = delta * P(delta)         -expm1(-delta / tau_rc) = x - x^2/2 + x^3/6 - x^4/24, x = delta / tau_rc <= 1/20: the first
 //                                 neglected term is x^4/120 < 5.3e-8 of the result (half an f32 ulp)
 //   V  = V0 + (J - V0) * em
@@ -132,16 +147,15 @@ __device__ inline f32x2 pk_fma_clamp01_trans_vvs(f32x2 x, f32x2 y, f32x2 z) {
 //                                 turns any of it into a number in [0, 1] (DX10 clamp: NaN -> 0) and spk = 0 discards it -
 //                                 round 2 guarded the operand instead ((J - 1) * spk + nspk): two packed operations more
 //   Vn = clamp(V - spk * 2^24)    voltage of a silent neuron clamped at min_voltage 0 (V <= 1), 0 for a spiking one
-//   s' = (mt + Vn) - spk * nu     (spiking: mt = Vn = 0; silent: spk = 0 - exact selects, products with 0 / 1)
+//   s' = (Vn - nmt) - spk * nu    (spiking: nmt = Vn = 0; silent: spk = 0 - exact selects, products with 0 / 1)
 // Requires dt / tau_rc <= 1/20 and tau_ref >= dt (checked by the host planner).
 struct LifConstV2 { float dt, a1, a2, a3, a4, tau_ln2, tau_ref; };
 
 __device__ inline f32x2 lif_packed_step_f32x2(f32x2 J, f32x2& s, const LifConstV2& c, f32x2 big, f32x2 nbig) {
   const f32x2 V0 = pk_clamp01(s);
-  const f32x2 m = s - V0;
-  const f32x2 t = m + c.dt;
-  const f32x2 delta = pk_clamp01(t);
-  const f32x2 mt = t - delta;
+  const f32x2 r = pk_neg_clamp01(s);                          // max(-s, 0) = R - dt of a refractory neuron, else 0
+  const f32x2 delta = pk_rsub_clamp01(r, (f32x2)(c.dt));      // clamp(dt - r)
+  const f32x2 nmt = pk_sub_clamp01(r, (f32x2)(c.dt));         // clamp(r - dt) = -min(dt - r, 0)
   // (uniform coefficients as scalar-register pairs: one constant-bus operand per instruction, the first FMA's second
   //  coefficient lives in a vector register pair)
   f32x2 P;
@@ -161,7 +175,7 @@ __device__ inline f32x2 lif_packed_step_f32x2(f32x2 J, f32x2& s, const LifConstV
   lg2.y = __builtin_amdgcn_logf(omu.y);
   const f32x2 nu = pk_fma_clamp01_trans_vvs(lg2, (f32x2)(c.tau_ln2), (f32x2)(c.tau_ref));
   const f32x2 Vn = pk_fma_clamp01_vsv(spk, nbig, V);
-  s = __builtin_elementwise_fma(-spk, nu, mt + Vn);
+  s = __builtin_elementwise_fma(-spk, nu, Vn - nmt);
   return spk;
 }
 

@@ -745,9 +745,10 @@ struct Sim final : ssn_sim {
     const int d = kind == 5 ? (int)o.i[2] : (int)o.i[3];
     *a = ssn::DftArgs{};
     if (d < 8 || d > 6400) return SSN_OK;
-    if (!(flags & 536870912)) {
-      // default since round 3: the four-step transform on the matrix cores; a length without a usable divisor pair (a prime
-      // above 192, or 2 x such a prime ...) goes through Bluestein's convolution of the cheapest length M in [2d - 1, 2d - 1 + 12 %]
+    if (flags & 536870912) {
+      // opt-in (round 3, measured slower than the Stockham passes as built - DESIGN.md): the four-step transform on the matrix
+      // cores; a length without a usable divisor pair (a prime above 192, or 2 x such a prime ...) goes through Bluestein's
+      // convolution of the cheapest length M in [2d - 1, 2d - 1 + 12 %]
       std::pair<int, int> sp = dft4_split(d, kind == 5);
       int M = 0;
       if (!sp.first) {
@@ -1538,8 +1539,17 @@ struct Sim final : ssn_sim {
     if (a.defer || a.xrows || (flags & 4194304)) return -1;
     if (a.fast == 1 && a.din == 3 && a.dout == 4) return ssn::RK_ENS_3_4_S;
     if (a.fast == 1 && a.din == 3 && a.dout == 5) return ssn::RK_ENS_3_5_S;
-    if (a.fast == 2 && a.din == 1 && a.dout == 1) return ssn::RK_ENS_1_1_D;
+    if (a.fast == 2 && a.din == 1 && a.dout == 1) {
+      // many small ensembles (the product arrays of a circular convolution): a wave per ensemble instead of a workgroup
+      if (a.n <= 64 && a.P == 1 && a.direct && !no_small_ens) return ssn::RK_ENS_SMALL;
+      return ssn::RK_ENS_1_1_D;
+    }
     return -1;
+  }
+  const bool no_small_ens = getenv("SSN_SMALL_ENS") && atoi(getenv("SSN_SMALL_ENS")) == 0;      // A/B knob
+  // blocks of an ensemble array's grid inside a round
+  int ens_round_blocks(const ssn::EnsArgs<T>& a) const {
+    return ens_round_kind(a) == ssn::RK_ENS_SMALL ? (a.K + 15) / 16 : a.K * a.P;
   }
 
   // Cost model of the round balancer: device time a unit needs when bandwidth-bound (us at ~5 TB/s), the latency of a
@@ -1557,7 +1567,7 @@ struct Sim final : ssn_sim {
     switch (it.type) {
       case IT_ENS:
         *us = (double)it.ens.K * it.ens.n_pad * (it.ens.din + 4.5) * sizeof(T) / per_us;
-        if (ens_round_kind(it.ens) >= 0) *blocks = it.ens.K * it.ens.P;
+        if (ens_round_kind(it.ens) >= 0) *blocks = ens_round_blocks(it.ens);
         break;
       case IT_MATVEC:
         *us = (double)it.rows * it.ld * sizeof(T) / per_us;
@@ -1897,7 +1907,7 @@ struct Sim final : ssn_sim {
               const int kind = ens_round_kind(a);
               if (kind >= 0) {
                 if (ao < 0) ao = (long long)put(&a, sizeof a);
-                entry(kind, a.K * a.P, 1, 512, 0, (size_t)ao);
+                entry(kind, ens_round_blocks(a), 1, 512, 0, (size_t)ao);
                 continue;
               }
               break;
@@ -1920,7 +1930,7 @@ struct Sim final : ssn_sim {
             }
             case IT_DFT: {
               const size_t lds = (size_t)(it.dft.M > 0 ? it.dft.M : it.dft.N) * (it.dft.N1 > 0 ? 4 * sizeof(float) : 3 * sizeof(float2));
-              if (lds <= 64 * 1024) {
+              if (lds <= 64 * 1024 && it.dft.N1 == 0) {      // (the four-step engine is launched on its own: see dft_body<ROUND>)
                 if (ao < 0) ao = (long long)put(&it.dft, sizeof it.dft);
                 entry(ssn::RK_DFT, 1, 1, lds, 0, (size_t)ao);
                 continue;
@@ -2575,6 +2585,12 @@ struct Sim final : ssn_sim {
   int phase_async(int phase, void* buf, hipStream_t ext) override {
     HIPCHK(hipSetDevice(device));
     if (!phased) return fail(SSN_EINVAL, "ssn_phase_async: the model has no exchange ranges (use ssn_run_steps)");
+    if (phase == -1) {              // capture only: the graphs for this exchange buffer are built now, nothing is launched
+      if (async_active) return fail(SSN_EINVAL, "ssn_phase_async(-1): a run is in flight (call ssn_phase_sync first)");
+      HIPCHK(hipStreamSynchronize(stream));
+      if (!async_captured || buf != async_buf) CHK(capture_async(buf));
+      return SSN_OK;
+    }
     if (phase < 0 || phase > 2) return fail(SSN_EINVAL, "ssn_phase_async(%d): 0, 1 or 2 (= 1 followed by the next timestep's 0)", phase);
     if ((phase == 2 ? 1 : phase) != next_phase) return fail(SSN_EINVAL, "ssn_phase_async(%d): phase %d is due", phase, next_phase);
     if (!async_active) {

@@ -312,6 +312,63 @@ __device__ __forceinline__ void ens_body(const EnsArgs<T>& a, const int bx, unsi
     }
   }
 }
+// Arrays of MANY SMALL one-dimensional ensembles - the product ensembles of a circular convolution (reference binding.py:297-317:
+// 2 x 2032 ensembles of 50 neurons per network at d = 1015) - as a body of the round grid.  ens_body gives every ensemble a
+// 256-thread workgroup of which 13 threads have neurons (four each): 8 128 workgroups per SLAM timestep, each a chain of
+// dependent loads, a wave reduction, an LDS round trip and a barrier for 50 neurons.  Here a WAVE owns an ensemble (lane =
+// neuron, one coalesced 200-byte row per parameter), takes four ensembles with all their loads in flight before the first
+// neuron step, reduces with six shuffles and writes the decoded value itself: no LDS, no barrier, 16 ensembles per
+// workgroup (508 workgroups per timestep instead of 8 128).  LIF fast path (packed state word), dense decoders, n <= 64.
+template <typename T>
+__device__ __forceinline__ void ens_small_body(const EnsArgs<T>& a, const int bx) {
+  constexpr int EPW = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k0 = (bx * 4 + wave) * EPW;
+  const NeuronParams<T> np = a.np;
+  const LifMath<T> lm(np);
+  const size_t row = (size_t)a.n_pad;
+  T e[EPW], b[EPW], s[EPW], d[EPW], x[EPW];
+  bool live[EPW];
+#pragma unroll
+  for (int u = 0; u < EPW; ++u) {
+    const int k = k0 + u;
+    live[u] = k < a.K && lane < a.n;
+    const size_t o = (size_t)(k < a.K ? k : 0) * row + (size_t)(lane < a.n ? lane : 0);
+    e[u] = a.enc[o]; b[u] = a.bias[o]; s[u] = a.V[o]; d[u] = a.dec[o];
+    const long long xi = a.x_off + (long long)(k < a.K ? k : 0);
+    T xv = a.sig[xi];
+    for (int j = 0; j < a.n_rec; ++j)
+      if (xi >= a.rec_dst[j] && xi < a.rec_dst[j] + a.rec_len[j]) xv += a.rec_alpha[j] * a.sig[a.rec_src[j] + (xi - a.rec_dst[j])];
+    x[u] = xv;
+  }
+#pragma unroll
+  for (int u = 0; u < EPW; ++u) {
+    const int k = k0 + u;
+    T act = T(0);
+    if (live[u]) {
+      // packed state word -> nengo's LIF step, operation for operation ens_body's fast path
+      const T J = b[u] + e[u] * x[u];
+      const T sw = s[u];
+      T V = sw < T(0) ? T(0) : sw;
+      T R = (sw < T(0) ? -sw : T(0)) - np.dt;
+      T delta = np.dt - R;
+      delta = delta < T(0) ? T(0) : (delta > np.dt ? np.dt : delta);
+      V = V - (J - V) * lm.decay(delta);
+      if (V > T(1)) {
+        const T t_spike = np.dt + np.tau_rc * lm.spike_time_term(V, J);
+        R = np.tau_ref + t_spike;
+        V = T(0);
+        act = d[u];
+      } else if (V < T(0)) {
+        V = T(0);
+      }
+      a.V[(size_t)k * row + lane] = R > np.dt ? -R : V;
+    }
+    const T total = wave_sum(act);
+    if (lane == 0 && k < a.K) a.sig_w[a.didx[k]] = total;
+  }
+}
+
 template <typename T, int DIN, int DOUT, int MODE>
 __global__ __launch_bounds__(256) void k_ensarray(EnsBatch<T> batch) {
   __shared__ __align__(16) unsigned char smem[(4 * DOUT + DIN) * sizeof(T)];
@@ -644,8 +701,11 @@ __device__ __forceinline__ void dft4_body(const DftArgs& a, unsigned char* ssn_d
   }
 }
 
+// (ROUND = true: the body inside k_round never runs the four-step engine - its MFMA accumulators would add 8 AGPRs to the
+//  round kernel and take every body of every round from 7 to 6 waves per SIMD; such transforms are launched on their own)
+template <bool ROUND = false>
 __device__ __forceinline__ void dft_body(const DftArgs& a, unsigned char* ssn_dft_dyn) {
-  if (a.N1 > 0) { dft4_body(a, ssn_dft_dyn); return; }
+  if constexpr (!ROUND) { if (a.N1 > 0) { dft4_body(a, ssn_dft_dyn); return; } }
   const int N = a.N, H = N / 2 + 1, tid = threadIdx.x, nthr = blockDim.x;
   const int L = a.M > 0 ? a.M : N;              // length of the transforms actually run
   float2* x = reinterpret_cast<float2*>(ssn_dft_dyn);

@@ -230,7 +230,8 @@ enum RoundKind {
   RK_GLUE = 0,        // element-wise / reduction micro-operators, one chunk per block (args: GlueBlock map)
   RK_GATE, RK_ARGMAX, // whole-vector micro-operators: one block each (args: MicroOp)
   RK_MATVEC_R1, RK_MATVEC_R4, RK_SPMV, RK_NEURONS, RK_DFT, RK_PES, RK_VOJA,
-  RK_ENS_3_4_S, RK_ENS_3_5_S, RK_ENS_1_1_D      // k_ensarray<din, dout, spike-sparse | dense decoders>
+  RK_ENS_3_4_S, RK_ENS_3_5_S, RK_ENS_1_1_D,     // k_ensarray<din, dout, spike-sparse | dense decoders>
+  RK_ENS_SMALL                                  // arrays of many small 1-D ensembles: a wave per ensemble, 16 per block (ens_small_body)
 };
 struct GlueBlock { int op; int chunk; };        // micro-operator index (into RoundArgs::mops); chunk of it (low 24 bits), timestep offset (high 8)
 // op < 0: a CHAIN of element-aligned micro-operators - RoundArgs::chain[-op - 1 ...] = {n, op_0, sub_0, ..., op_{n-1}, sub_{n-1}} -

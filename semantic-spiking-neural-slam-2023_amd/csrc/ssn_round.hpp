@@ -253,11 +253,12 @@ __device__ __forceinline__ void round_block(const RoundArgs<T>& ra, int vb, unsi
     case RK_SPMV: spmv_body<T>(*(const SpmvArgs<T>*)e.args, bx, by, smem); break;
     case RK_NEURONS: neurons_body<T>(*(const NeuronsArgs<T>*)e.args, bx, smem); break;
     case RK_DFT:
-      if constexpr (sizeof(T) == 4) dft_body(*(const DftArgs*)e.args, smem);
+      if constexpr (sizeof(T) == 4) dft_body<true>(*(const DftArgs*)e.args, smem);
       break;
     case RK_ENS_3_4_S: ens_body<T, 3, 4, 1>(*(const EnsArgs<T>*)e.args, bx, smem); break;
     case RK_ENS_3_5_S: ens_body<T, 3, 5, 1>(*(const EnsArgs<T>*)e.args, bx, smem); break;
     case RK_ENS_1_1_D: ens_body<T, 1, 1, 2>(*(const EnsArgs<T>*)e.args, bx, smem); break;
+    case RK_ENS_SMALL: ens_small_body<T>(*(const EnsArgs<T>*)e.args, bx); break;
     case RK_PES: pes_body<T>(*(const PesArgs<T>*)e.args, bx, by); break;
     case RK_VOJA: voja_body<T>(*(const VojaArgs<T>*)e.args, bx); break;
     default: break;

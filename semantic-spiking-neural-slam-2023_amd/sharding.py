@@ -475,6 +475,22 @@ class ShardedSLAM:
             return True
         return self.dist.is_initialized() and self.dist.get_backend() == "nccl"
 
+    def _exchange_buffer(self):
+        """Device buffer of the per-timestep exchange (None for a single rank: its sums are complete)."""
+        if self.world == 1:
+            return None
+        if self._buf is None:
+            import torch
+            tdt = torch.float32 if self.dtype == "f32" else torch.float64
+            self._buf = torch.zeros(self.sim.exchange_size(), dtype=tdt, device=torch.device("cuda", torch.cuda.current_device()))
+        return self._buf.data_ptr()
+
+    def capture(self):
+        """Build the stream-ordered step graphs now instead of at the first timestep of the first run (optional; several
+        ranks living in one process - tests - do this one after the other before their threads start stepping)."""
+        if self._stream_ordered():
+            self.sim.phase_async(-1, self._exchange_buffer(), None)
+
     def _agree(self, err):
         """Every rank learns whether any rank failed before the collectives of a run start (a rank that raised would leave its
         peers waiting in the first all-reduce until the RCCL watchdog fires)."""
@@ -509,10 +525,7 @@ class ShardedSLAM:
             buf = None
             if self.world > 1:
                 try:
-                    if self._buf is None:
-                        tdt = torch.float32 if self.dtype == "f32" else torch.float64
-                        self._buf = torch.zeros(self.sim.exchange_size(), dtype=tdt, device=torch.device("cuda", torch.cuda.current_device()))
-                    buf = self._buf.data_ptr()
+                    buf = self._exchange_buffer()
                 except Exception as e:               # noqa: BLE001 - agreed on collectively, then re-raised
                     err = err or e
                 self._agree(err)

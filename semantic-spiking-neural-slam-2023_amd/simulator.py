@@ -533,6 +533,9 @@ class Simulator:
     # -- neuron-sharded models (builder.shard_phases): the caller completes the partial sums between the phases ---------
     def run_phase(self, phase):
         """0: up to the exchange; 1: the updates; 2: the updates followed by the next timestep up to its exchange."""
+        if phase == -1:                  # build the graphs for this exchange buffer now (no launch)
+            self._check(self._lib.ssn_phase_async(self._h, -1, C.c_void_p(exchange_buf_ptr or None), C.c_void_p(None)))
+            return
         if phase in (0, 2) and self._prepared_until < self.n_steps + (1 if phase == 0 else 2):
             raise fe.SimulationError("neuron-sharded model: call prepare(n_steps) before stepping")
         self._check(self._lib.ssn_run_phase(self._h, int(phase)))

@@ -339,15 +339,15 @@ def test_slamview_f64_matches_oracle(Simulator):
 def test_dft_kernel_matches_the_transform_matrices(Simulator):
     """k_dft (the FFT of the circular-convolution transforms, f32 core) against the dense real-DFT matrices it replaces
     (reference binding.py:23-74): in ONE run, the probed output of each transform equals matrix @ probed input.  Both
-    engines: the four-step transform on the matrix cores (default since round 3: two small dense DFTs as f32 MFMA products
-    around a twiddle multiply) and the Stockham passes of rounds 1 - 2 (flag 536870912).  d = 25 (5 x 5), 55 (5 x 11),
+    engines: the Stockham passes (default) and the four-step transform on the matrix cores (flag 536870912, round 3: two small
+    dense DFTs as f32 MFMA products around a twiddle multiply).  d = 25 (5 x 5), 55 (5 x 11),
     217 (7 x 31), 1015 (35 x 29, the benchmark's dimension), 97 (prime: ONE dense DFT in the four-step engine, Bluestein in the
     Stockham one); d = 1801 (prime; what ssp_dim = 2047 gives in 3-D, BASELINE config 5) and d = 2049 (3 x 683; SURVEY's other
     reading of config 5) go through Bluestein's convolution in both; both operand layouts, with and without involution; the
     inverse transform."""
     from sspslam_amd.networks import CircularConvolution
     from sspslam_amd.builder import dft_structure
-    STOCKHAM, BIG = 536870912, 268435456
+    FOURSTEP, BIG = 536870912, 268435456
     for d, inv_a, inv_b in ((25, False, True), (55, True, False), (217, False, False), (97, False, True), (1015, True, False),
                             (1801, True, False), (2049, False, True)):
         rng = np.random.RandomState(d)
@@ -376,15 +376,15 @@ def test_dft_kernel_matches_the_transform_matrices(Simulator):
         if big:       # a chirp-z transform of 2048+ points: the planner prefers the dense matrix (spread over the chip) by default
             with Simulator(None, model=model, dtype="f32") as sim:
                 assert sim.counters()["fft_transforms"] == 0
-        for engine in (0, STOCKHAM):
+        for engine in (0, FOURSTEP):
             with Simulator(None, model=model, dtype="f32", flags=engine | (BIG if big else 0)) as sim:
                 sim.run_steps(120)
                 a, b, fa_, fb_ = sim.data[p_a], sim.data[p_b], sim.data[p_fa], sim.data[p_fb]
                 prod, out = sim.data[p_prod], sim.data[p_out]
                 c = sim.counters()
-                n_blue = 3 if (big or (d == 97 and engine == STOCKHAM)) else 0
+                n_blue = 3 if (big or (d == 97 and engine == 0)) else 0
                 assert c["fft_transforms"] == 3 and c["fft_bluestein"] == n_blue, (d, engine, c)
-            assert np.abs(a).max() > 0.01 and np.abs(prod).max() > 1e-4
+            assert np.abs(a).max() > 0.005 and np.abs(prod).max() > 1e-5
             np.testing.assert_allclose(fa_, a @ cc.transform_a.T, atol=2e-6 * np.sqrt(d), err_msg=f"d {d} engine {engine}")
             np.testing.assert_allclose(fb_, b @ cc.transform_b.T, atol=2e-6 * np.sqrt(d), err_msg=f"d {d} engine {engine}")
             np.testing.assert_allclose(out, prod @ cc.transform_out.T, atol=2e-6, err_msg=f"d {d} engine {engine}")
@@ -697,20 +697,23 @@ class _ThreadDist:
         self.barrier.wait()
         return got
 
+    # (stream-level waits, not torch.cuda.synchronize(): a device-wide synchronisation from one rank's thread invalidates a
+    #  stream capture another rank's thread has open - ssn_phase_async captures its graphs at the first call of a run; real
+    #  RCCL collectives never synchronise the device)
     def all_gather_into_tensor(self, out, send):
         import torch
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
         for r, t in enumerate(self._meet(send)):
             out[r].copy_(t)
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
 
     def all_reduce(self, t, op=None):
         import torch
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
         got = self._meet(t.clone())
         st = torch.stack([g.to(t.device) for g in got])
         t.copy_(st.max(dim=0).values if op == "max" else st.sum(dim=0))
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
 
     def all_gather(self, outs, t):
         for o, g in zip(outs, self._meet(t.clone())):
@@ -775,6 +778,9 @@ def test_sharded_slam_device_exchange_with_two_ranks_in_one_process(Simulator):
     sms = [_small_slam(weights_every=None) for _ in range(world)]
     runners = [ShardedSLAM(sms[rank], rank, world, dtype="f64", dist=fake) for rank in range(world)]
     assert all(len(r.model.exchange) > 0 for r in runners)
+    for r in runners:
+        assert r._stream_ordered()
+        r.capture()            # (ranks that share a process build their step graphs one after the other, before the threads run)
     results, errors = {}, []
 
     def work(rank):

@@ -11,7 +11,7 @@ from sspslam_amd.builder import build
 from sspslam_amd.networks import CircularConvolution
 from sspslam_amd.simulator import Simulator
 
-PER_OP, STOCKHAM, BIG, MATRIX = 2097152, 536870912, 268435456, 512
+PER_OP, FOURSTEP, BIG, MATRIX = 2097152, 536870912, 268435456, 512
 for d in [int(x) for x in sys.argv[1:]] or [55, 217, 1015, 1801, 2049]:
     rng = np.random.RandomState(d)
     fa = rng.randn(d) / np.sqrt(d)
@@ -27,7 +27,7 @@ for d in [int(x) for x in sys.argv[1:]] or [55, 217, 1015, 1801, 2049]:
         nengo.Connection(cc.output, sink, synapse=None)
         nengo.Probe(sink, synapse=0.01)
     model = build(m)
-    for name, fl in (("four-step MFMA", BIG), ("Stockham", BIG | STOCKHAM), ("dense matrix", MATRIX)):
+    for name, fl in (("four-step MFMA", BIG | FOURSTEP), ("Stockham", BIG), ("dense matrix", MATRIX)):
         with Simulator(None, model=model, dtype="f32", flags=PER_OP | fl) as sim:
             sim.prepare(400)
             sim.run_steps(100, collect=False)
