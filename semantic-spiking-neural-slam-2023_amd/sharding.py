@@ -429,6 +429,7 @@ class ShardedSLAM:
         self.sim = sim_factory(self.model)
         self.n_steps = 0
         self._buf = None
+        self._stream = None
         if not hasattr(self.sim, "run_phase"):          # oracle-backed stand-in: the stepper calls back between the phases
             self.sim.set_exchange(self._allreduce_host)
 
@@ -531,13 +532,23 @@ class ShardedSLAM:
                 self._agree(err)
             elif err is not None:
                 raise err
-            stream = torch.cuda.current_stream().cuda_stream
-            self.sim.phase_async(0, buf, stream)
-            for i in range(n):
-                if self.world > 1:
-                    self.dist.all_reduce(self._buf)
-                self.sim.phase_async(2 if i + 1 < n else 1, buf, stream)
-            self.sim.phase_sync(stream)
+            # A stream of the runner's own, made torch's current stream for the run: the phase graphs are launched on it and
+            # torch.distributed orders its collectives on the CURRENT stream.  (Not torch's default stream: its handle is 0,
+            # which ssn_phase_async reads as "the simulator's own stream" - the graphs and the all-reduce would then run on
+            # two unordered streams.)
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                stream = self._stream.cuda_stream
+                assert stream, "a created HIP stream has a non-zero handle"
+                self.sim.phase_async(0, buf, stream)
+                for i in range(n):
+                    if self.world > 1:
+                        self.dist.all_reduce(self._buf)
+                    self.sim.phase_async(2 if i + 1 < n else 1, buf, stream)
+                self.sim.phase_sync(stream)
+            torch.cuda.current_stream().wait_stream(self._stream)
         else:
             self._agree(err)
             self.sim.run_phase(0)

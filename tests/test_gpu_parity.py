@@ -700,6 +700,9 @@ class _ThreadDist:
     # (stream-level waits, not torch.cuda.synchronize(): a device-wide synchronisation from one rank's thread invalidates a
     #  stream capture another rank's thread has open - ssn_phase_async captures its graphs at the first call of a run; real
     #  RCCL collectives never synchronise the device)
+    # Like a real collective, ordered on the caller's CURRENT stream only: what the caller enqueued on that stream before is
+    # complete when the ranks meet, and the result is complete when the call returns.  (No torch.cuda.synchronize(): a
+    # device-wide wait would hide a caller that launched its kernels on a stream the collective is not ordered with.)
     def all_gather_into_tensor(self, out, send):
         import torch
         torch.cuda.current_stream().synchronize()
@@ -709,8 +712,9 @@ class _ThreadDist:
 
     def all_reduce(self, t, op=None):
         import torch
+        c = t.clone()
         torch.cuda.current_stream().synchronize()
-        got = self._meet(t.clone())
+        got = self._meet(c)
         st = torch.stack([g.to(t.device) for g in got])
         t.copy_(st.max(dim=0).values if op == "max" else st.sum(dim=0))
         torch.cuda.current_stream().synchronize()
