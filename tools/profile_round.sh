@@ -1,0 +1,22 @@
+#!/bin/bash
+# Profiles the judge reads (run on the GPU box; writes under gpurun_out/$1, copy the summaries into profiles/):
+#   1. rocprofv3 --kernel-trace --stats of the bench command (headline kernel + SLAM leg)
+#   2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over k_ens_block      -> tools/parse_pmc.py
+#   3. the same two passes over every k_round dispatch of SLAM config 3                -> tools/parse_round_pmc.py
+# The profiled program is python3 itself (no env / bash -c hop between rocprofv3 and the program).
+set -o pipefail
+OUT=${1:-gpurun_out/prof}
+R=${GRAFT_REPO_ROOT:-$PWD}
+mkdir -p $R/$OUT
+cd /tmp && export TMPDIR=/tmp
+B="$R/bench.py --steps 3 --warmup 1 --cpu-steps 0 --no-end-to-end --slam-cpu-steps 0"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -o r3 -- python3 $B --slam-steps 256 > $R/$OUT/bench_under_rocprof.json 2> $R/$OUT/stats.err || exit 1
+echo stats done
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_ens_block --output-format csv -d $R/$OUT/pmc_fetch -o r3 -- python3 $B --slam-steps 0 > $R/$OUT/pmc_fetch.log 2>&1 || exit 2
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_ens_block --output-format csv -d $R/$OUT/pmc_write -o r3 -- python3 $B --slam-steps 0 > $R/$OUT/pmc_write.log 2>&1 || exit 3
+echo block pmc done
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_round --output-format csv -d $R/$OUT/slam_fetch -o r3 -- python3 $R/tools/experiments/slam_flags.py 0 > $R/$OUT/slam_fetch.log 2>&1 || exit 4
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_round --output-format csv -d $R/$OUT/slam_write -o r3 -- python3 $R/tools/experiments/slam_flags.py 0 > $R/$OUT/slam_write.log 2>&1 || exit 5
+echo slam pmc done
+cd $R
+find $OUT -name "*.csv" | head -20
