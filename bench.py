@@ -558,7 +558,9 @@ def pathint_main(args):
         if not args.no_end_to_end:
             T = args.steps * args.block * dt
             e2e = {}
-            for label, strip in (("harness_nodes", False), ("plain_closures", True)):
+            for label, strip in (("warm_up", False), ("harness_nodes", False), ("plain_closures", True)):
+                # (the first pass is untimed: it pays the first-use allocations of the read-back path - pinned staging, one
+                #  array per probe - as the W warm-up blocks of the timed region pay the step loop's)
                 sim.reset()
                 saved = [tb["fn"] for tb in model.tables]
                 if strip:      # the reference scripts pass plain `lambda t: table[int((t - dt) / dt)]` closures: one Python call per timestep

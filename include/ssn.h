@@ -137,8 +137,6 @@ typedef struct ssn_model_desc {
                                               (default: finish deferred into the next step's prologue, 1 launch per step),
                                          128 = no whole-block kernel for a recurrent array of independent ensembles
                                               (k_ens_block): step it once per timestep (k_ensarray) instead,
-                                         256 = generic plan: fork the independent branches of a timestep over several
-                                              streams inside the step graph (data-hazard analysis in the planner),
                                          512 = no FFT kernel for DFT-structured matvecs (always multiply by the matrix),
                                          1024 = k_spmv_partial rebuilds the spike list itself (no segmented list from k_neurons),
                                          4096 = one launch per operator (adjacent independent operators of one kind are not batched),
@@ -153,7 +151,7 @@ typedef struct ssn_model_desc {
                                          1048576 = programs stay where the operator order put them (no sinking of a program
                                               into the next one past operators that do not depend on it).
                                          2097152 = no rounds: one launch per big operator and one k_program launch per run of
-                                              small ones (the round-1 plan; flags 256, 4096, 65536, 131072 and 1048576 only act
+                                              small ones (the round-1 plan; flags 4096, 65536, 131072 and 1048576 only act
                                               together with this one).  Default: every operator takes the earliest round its data
                                               hazards allow and a round is ONE heterogeneous grid (k_round),
                                          4194304 = ensemble arrays are launched on their own, not as bodies of the round's grid,
@@ -173,7 +171,7 @@ typedef struct ssn_model_desc {
                                               twiddle multiply, round 3; any factorisation, primes up to 192 as one dense DFT) instead of
                                               the Stockham passes (generic radix-r butterflies through LDS).  Correct for every length of the
                                               tests, but measured no faster (its operand loads are latency-bound): opt-in.
-                                         (Round 1's opt-in experiments 32, 64, 2048, 16384, 32768 - all measured slower - were removed.) */
+                                         (Round 1's opt-in experiments 32, 64, 2048, 16384, 32768 and the multi-stream step graph 256 - all measured slower - were removed.) */
 } ssn_model_desc;
 
 typedef struct ssn_counters {

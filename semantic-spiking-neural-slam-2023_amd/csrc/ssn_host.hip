@@ -190,8 +190,6 @@ struct Sim final : ssn_sim {
   int graph_rounds = 0;
   std::vector<void*> round_bufs;
 
-  std::vector<hipStream_t> side_streams;
-  std::vector<hipEvent_t> dag_events;
   ssn::StepCtx* d_ctx = nullptr;
   std::vector<ssn::TableSlot> tables;
   ssn::TableSlot* d_tables = nullptr;
@@ -254,8 +252,6 @@ struct Sim final : ssn_sim {
     for (auto p : fused_bufs) if (p) hipFree(p);
     for (auto p : round_bufs) if (p) hipFree(p);
     for (auto e : ev_pool) hipEventDestroy(e);
-    for (auto e : dag_events) hipEventDestroy(e);
-    for (auto st : side_streams) hipStreamDestroy(st);
     if (ev_run0) hipEventDestroy(ev_run0);
     if (ev_run1) hipEventDestroy(ev_run1);
     if (sig) hipFree(sig);
@@ -2370,70 +2366,6 @@ struct Sim final : ssn_sim {
     return hipSuccess;
   }
 
-  // One timestep of the generic plan with its independent branches forked over side streams (capture only:
-  // the cross-stream event waits become graph edges).  Head and tail programs run on the main stream and are
-  // the fork / join points.  `ev` indexes the event pool.
-  hipError_t launch_step_dag(bool first, bool last, size_t* ev) {
-    const int n_items = (int)items.size();
-    const int S = (int)side_streams.size();
-    hipStream_t main_stream = stream;
-    hipError_t e = hipSuccess;
-    auto on = [&](hipStream_t st, const Item& it) { stream = st; hipError_t r = launch_item(it, nullptr, nullptr); stream = main_stream; return r; };
-    const bool tr = getenv("SSN_DEBUG_PLAN") && atoi(getenv("SSN_DEBUG_PLAN")) >= 2;
-    auto sid = [&](hipStream_t st) { for (int q = 0; q < S; ++q) if (side_streams[(size_t)q] == st) return q; return -1; };
-    auto eid = [&](hipEvent_t x) { for (size_t q = 0; q < dag_events.size(); ++q) if (dag_events[q] == x) return (int)q; return -1; };
-    if (tr) fprintf(stderr, "OP L -1\n");
-    if (first || !can_fuse) { if ((e = on(main_stream, items[0])) != hipSuccess) return e; }
-    hipEvent_t fork = dag_events[(*ev)++];
-    if ((e = hipEventRecord(fork, main_stream)) != hipSuccess) return e;
-    if (tr) fprintf(stderr, "OP R %d -1\n", eid(fork));
-    std::vector<int> where((size_t)n_items, -1);          // stream of each middle item
-    std::vector<hipEvent_t> done((size_t)n_items, nullptr);
-    std::vector<int> last_on((size_t)S, -1);
-    std::vector<char> forked((size_t)S, 0);
-    // synced[q][r]: the latest item of stream r that stream q already waited for in this step (stream order makes
-    // every earlier item of r implied; the runtime's capture does not tolerate duplicate waits on one event)
-    std::vector<std::vector<int>> synced((size_t)S, std::vector<int>((size_t)S, 0));
-    for (int i = 1; i < n_items - 1; ++i) {
-      // Stream choice.  The runtime's capture follows stream-to-stream wait relations recursively when the capture
-      // ends and does not survive a cycle in them (side stream a waited for b, b for c, c for a - a perfectly
-      // acyclic graph of nodes; observed on ROCm 7.2 as a stack overflow inside hipStreamEndCapture, reproduced
-      // standalone in tools/experiments/graph_replay.hip).  So a side stream only ever waits for LOWER-numbered
-      // side streams: an item goes to a stream >= every stream its predecessors ran on.
-      int lo = 0;                                       // lowest admissible stream
-      for (int d : item_deps[(size_t)i]) if (d >= 1) lo = std::max(lo, where[(size_t)d]);
-      int pick = -1, best = -1;
-      for (int d : item_deps[(size_t)i])               // 1. continue behind a predecessor that is last on its stream
-        if (d >= 1 && where[(size_t)d] >= lo && last_on[(size_t)where[(size_t)d]] == d && d > best) { best = d; pick = where[(size_t)d]; }
-      if (pick < 0) for (int q = lo; q < S; ++q) if (last_on[(size_t)q] < 0) { pick = q; break; }        // 2. an idle stream
-      if (pick < 0) { pick = lo; for (int q = lo + 1; q < S; ++q) if (last_on[(size_t)q] < last_on[(size_t)pick]) pick = q; }   // 3. least recently used
-      hipStream_t st = side_streams[(size_t)pick];
-      if (!forked[(size_t)pick]) { if ((e = hipStreamWaitEvent(st, fork, 0)) != hipSuccess) return e; forked[(size_t)pick] = 1; if (tr) fprintf(stderr, "OP W %d %d\n", pick, eid(fork)); }
-      for (int d : item_deps[(size_t)i]) {
-        if (d < 1 || where[(size_t)d] == pick) continue;
-        int& have = synced[(size_t)pick][(size_t)where[(size_t)d]];
-        if (d <= have) continue;
-        if ((e = hipStreamWaitEvent(st, done[(size_t)d], 0)) != hipSuccess) return e;
-        if (tr) fprintf(stderr, "OP W %d %d\n", pick, eid(done[(size_t)d]));
-        have = d;
-      }
-      if ((e = on(st, items[(size_t)i])) != hipSuccess) return e;
-      done[(size_t)i] = dag_events[(*ev)++];
-      if ((e = hipEventRecord(done[(size_t)i], st)) != hipSuccess) return e;
-      if (tr) fprintf(stderr, "OP L %d\nOP R %d %d\n", sid(st), eid(done[(size_t)i]), sid(st));
-      where[(size_t)i] = pick; last_on[(size_t)pick] = i;
-    }
-    for (int q = 0; q < S; ++q)
-      if (last_on[(size_t)q] >= 0) {
-        if ((e = hipStreamWaitEvent(main_stream, done[(size_t)last_on[(size_t)q]], 0)) != hipSuccess) return e;
-        if (tr) fprintf(stderr, "OP W -1 %d\n", eid(done[(size_t)last_on[(size_t)q]]));
-      }
-    if (tr) fprintf(stderr, "OP L -1\n");
-    if (can_fuse && !last)
-      return ssn::launch_program<T>(main_stream, d_mops, d_progs + tail_begin, 2, sig, d_ctx);
-    return on(main_stream, items[(size_t)(n_items - 1)]);
-  }
-
   hipError_t launch_phase(int phase) {
     if (round_mode) {
       for (const Launch& l : launch_list) {
@@ -2466,38 +2398,6 @@ struct Sim final : ssn_sim {
       return SSN_OK;
     }
     if (steps_per_graph <= 1 || fused_block) return SSN_OK;
-    const bool dag = (flags & 256) && !round_mode && !fused_core && items.size() >= 4 && item_deps.size() == items.size();
-    if (getenv("SSN_DEBUG_PLAN")) {
-      size_t edges = 0;
-      for (auto& d : item_deps) edges += d.size();
-      fprintf(stderr, "[ssn] capture: %zu items, %zu dependency edges, dag %d (flags %d, fused_core %d)\n", items.size(), edges, (int)dag, flags, (int)fused_core);
-      for (size_t i = 0; i < item_deps.size(); ++i) {
-        fprintf(stderr, "[ssn]   item %2zu type %d deps:", i, items[i].type);
-        for (int d : item_deps[i]) fprintf(stderr, " %d", d);
-        fprintf(stderr, "\n");
-      }
-    }
-    if (dag) {
-      side_streams.resize(8);
-      for (auto& st : side_streams) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-      dag_events.resize((size_t)steps_per_graph * (items.size() + 1));
-      for (auto& ev : dag_events) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-      hipError_t e = hipSuccess;
-      size_t ev = 0;
-      const bool dbg = getenv("SSN_DEBUG_PLAN") != nullptr;
-      for (int s = 0; s < steps_per_graph && e == hipSuccess; ++s) {
-        e = launch_step_dag(s == 0, s + 1 == steps_per_graph, &ev);
-        if (dbg) fprintf(stderr, "[ssn] captured step %d: %s (%zu events)\n", s, hipGetErrorString(e), ev);
-      }
-      hipError_t e2 = hipStreamEndCapture(stream, &graph);
-      if (dbg) fprintf(stderr, "[ssn] end capture: %s\n", hipGetErrorString(e2));
-      HIPCHK(e);
-      HIPCHK(e2);
-      HIPCHK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
-      if (dbg) fprintf(stderr, "[ssn] graph instantiated\n");
-      return SSN_OK;
-    }
     HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
     hipError_t e = launch_steps(steps_per_graph, true);
     hipError_t e2 = hipStreamEndCapture(stream, &graph);

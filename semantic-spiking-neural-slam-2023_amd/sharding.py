@@ -216,7 +216,7 @@ class ShardedPathIntegration:
         dev = torch.device("cuda", torch.cuda.current_device())
         width = 3 * (self.hi - self.lo)
         send = torch.zeros((n, 3 * self.per), dtype=tdt, device=dev)
-        torch.cuda.current_stream().synchronize()      # the simulator copies on its own stream
+        torch.cuda.current_stream().synchronize()      # the simulator copies on its own stream: the zero fill must have landed
         if width:
             have = self.sim.probe_count(self.osc_probe)
             if have < n:

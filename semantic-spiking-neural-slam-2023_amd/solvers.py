@@ -33,12 +33,20 @@ def _rates_np(J, neuron):
 
 class _blas_threads:
     """OpenBLAS with one thread per core is pathologically slow on the small Cholesky factorisations
-    of a build (measured 133 ms vs 6 ms for 500x500 with 8 threads vs 1-4): cap it."""
+    of a build (measured 133 ms vs 6 ms for 500x500 with 8 threads vs 1-4): cap it.
+
+    Re-entrant and cheap inside an outer ``with _blas_threads():`` - the builder wraps a whole build in one, so the 8 128
+    product-ensemble solves of a SLAMNetwork do not each pay threadpoolctl's scan of the loaded libraries (0.75 ms x 2 per
+    solve: 19 of the 84 s of a config-3 build under cProfile, round 3)."""
+    _depth = 0
 
     def __init__(self, n=4):
         self.n, self.ctx = n, None
 
     def __enter__(self):
+        _blas_threads._depth += 1
+        if _blas_threads._depth > 1:
+            return
         try:
             from threadpoolctl import threadpool_info, threadpool_limits
             # only ever LOWER the count: a pool started with OMP_NUM_THREADS / OPENBLAS_NUM_THREADS = 1 or 2 (torchrun sets 1
@@ -52,6 +60,7 @@ class _blas_threads:
             self.ctx = None
 
     def __exit__(self, *a):
+        _blas_threads._depth -= 1
         if self.ctx is not None:
             self.ctx.__exit__(*a)
 

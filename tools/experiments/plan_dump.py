@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["SSN_DEBUG_PLAN"] = "1"
 from sspslam_amd import harness as H
 from sspslam_amd.builder import build

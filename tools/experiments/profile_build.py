@@ -1,6 +1,6 @@
 """Where does the build of SLAM config 3 (62 s on the GPU box) go?  cProfile of harness.make_config3_model + builder.build."""
 import cProfile, pstats, sys, os, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sspslam_amd import harness as H
 from sspslam_amd.builder import build
 t0 = time.time()

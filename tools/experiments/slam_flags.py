@@ -2,7 +2,7 @@
 usage: python tools/experiments/slam_flags.py [flags[,ENV=value...] ...]      (default: 0 256)
   e.g.  0  0,SSN_ROUND_INTERLEAVE=0  536870912      (default plan | contiguous block order | Stockham FFT)"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sspslam_amd import harness as H
 from sspslam_amd.builder import build
 from sspslam_amd.simulator import Simulator

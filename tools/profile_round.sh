@@ -11,6 +11,7 @@ mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 B="$R/bench.py --steps 3 --warmup 1 --cpu-steps 0 --no-end-to-end --slam-cpu-steps 0"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -o r3 -- python3 $B --slam-steps 256 > $R/$OUT/bench_under_rocprof.json 2> $R/$OUT/stats.err || exit 1
+find $R/$OUT/stats -name "*kernel_trace*" -delete; find $R/$OUT/stats -name "*agent_info*" -delete
 echo stats done
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_ens_block --output-format csv -d $R/$OUT/pmc_fetch -o r3 -- python3 $B --slam-steps 0 > $R/$OUT/pmc_fetch.log 2>&1 || exit 2
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_ens_block --output-format csv -d $R/$OUT/pmc_write -o r3 -- python3 $B --slam-steps 0 > $R/$OUT/pmc_write.log 2>&1 || exit 3
@@ -19,4 +20,12 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_round --ou
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_round --output-format csv -d $R/$OUT/slam_write -o r3 -- python3 $R/tools/experiments/slam_flags.py 0 > $R/$OUT/slam_write.log 2>&1 || exit 5
 echo slam pmc done
 cd $R
-find $OUT -name "*.csv" | head -20
+# summaries (the raw counter files stay on the box: gpurun merges at most 64 MiB back)
+KS=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
+cp $KS $OUT/kernel_stats.csv
+python3 tools/parse_pmc.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $KS $OUT/pmc_traffic.json 5080000000 k_ens_block > $OUT/pmc_traffic.txt
+# (time per timestep of the UNPROFILED run: bench.py's slam leg; the profiled passes are slower)
+python3 tools/parse_round_pmc.py $(find $OUT/slam_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/slam_write -name "*counter_collection.csv" | head -1) 640 ${2:-114} > $OUT/slam_traffic.txt
+cat $OUT/pmc_traffic.txt $OUT/slam_traffic.txt
+rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/slam_fetch $OUT/slam_write
+du -sh $OUT
