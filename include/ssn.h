@@ -142,16 +142,10 @@ typedef struct ssn_model_desc {
                                          4096 = one launch per operator (adjacent independent operators of one kind are not batched),
                                          8192 = ensemble arrays always leave partial sums for a finish operator (no direct write
                                               when one workgroup covers an ensemble),
-                                         65536 = a workgroup barrier at every level change inside a program (no barrier elision for
-                                              element-aligned dependencies between element-wise operators),
-                                         131072 = the head program of a timestep is kept whole (its long first level is otherwise run
-                                              grid-wide by k_vecops, giving up the tail / head fusion),
                                          262144 = one launch per element-wise operator of the time-batched stages (no batching),
                                          524288 = clean-up similarities always from the pass over the table (no factored grid),
-                                         1048576 = programs stay where the operator order put them (no sinking of a program
-                                              into the next one past operators that do not depend on it).
                                          2097152 = no rounds: one launch per big operator and one k_program launch per run of
-                                              small ones (the round-1 plan; flags 4096, 65536, 131072 and 1048576 only act
+                                              small ones (the round-1 plan; flag 4096 only acts
                                               together with this one).  Default: every operator takes the earliest round its data
                                               hazards allow and a round is ONE heterogeneous grid (k_round),
                                          4194304 = ensemble arrays are launched on their own, not as bodies of the round's grid,
@@ -171,7 +165,8 @@ typedef struct ssn_model_desc {
                                               twiddle multiply, round 3; any factorisation, primes up to 192 as one dense DFT) instead of
                                               the Stockham passes (generic radix-r butterflies through LDS).  Correct for every length of the
                                               tests, but measured no faster (its operand loads are latency-bound): opt-in.
-                                         (Round 1's opt-in experiments 32, 64, 2048, 16384, 32768 and the multi-stream step graph 256 - all measured slower - were removed.) */
+                                         (Round 1's opt-in experiments 32, 64, 2048, 16384, 32768 the multi-stream step graph 256 and the program-planner switches 65536, 131072, 1048576 of
+                                          the round-1 plan - all measured slower - were removed.) */
 } ssn_model_desc;
 
 typedef struct ssn_counters {

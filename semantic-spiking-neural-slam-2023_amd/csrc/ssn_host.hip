@@ -1045,7 +1045,6 @@ struct Sim final : ssn_sim {
       }
     };
     auto level_change_needs_barrier = [&](const MOp& op) -> bool {
-      if (flags & 65536) return true;
       std::vector<EwAcc> mine;
       if (!ew_access(op, mine)) return true;
       for (size_t q = cur.size(); q-- > 0;) {             // operators since the last barrier
@@ -1403,7 +1402,7 @@ struct Sim final : ssn_sim {
     // argmax + row gather, whose result is first used after the path integrator's ensembles; the chunk reductions
     // of sparse products whose sums are first used behind the next neuron populations) joins that next program -
     // same operators, same order among dependent ones, one launch (~8 us inside the step graph) fewer each.
-    if (!fused && !(flags & 1048576) && !phased) {
+    if (!fused && !phased) {
       for (bool changed = true; changed;) {
         changed = false;
         analyse_dependencies(programs, item_prog);
@@ -1432,7 +1431,7 @@ struct Sim final : ssn_sim {
     // timestep, so the tail / head fusion is given up: worth it from ~16 k elements on (SLAM config 3: 42 -> ~23 us).
     std::vector<MOp>& vec_ops = vecops_host;
     vec_ops.clear();
-    if (!fused && !(flags & 131072) && !phased && !items.empty() && items.front().type == IT_PROGRAM && !programs.empty()) {
+    if (!fused && !phased && !items.empty() && items.front().type == IT_PROGRAM && !programs.empty()) {
       std::vector<MOp>& head = programs[(size_t)item_prog[0]];
       size_t lv = 0;
       long long elems = 0;
