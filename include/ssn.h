@@ -165,6 +165,10 @@ typedef struct ssn_model_desc {
                                               twiddle multiply, round 3; any factorisation, primes up to 192 as one dense DFT) instead of
                                               the Stockham passes (generic radix-r butterflies through LDS).  Correct for every length of the
                                               tests, but measured no faster (its operand loads are latency-bound): opt-in.
+                                         1073741824 = split ensembles in the whole-block kernel (f32, at most 4 decoded rows): an array with fewer
+                                              ensembles than the GPU has CUs (a 4- or 8-GPU shard of config 2) is stepped by 2 or 4
+                                              member workgroups per ensemble that exchange their partial sums every timestep; needs every
+                                              workgroup of the launch resident at once, i.e. the GPU for this process alone.
                                          (Round 1's opt-in experiments 32, 64, 2048, 16384, 32768 the multi-stream step graph 256 and the program-planner switches 65536, 131072, 1048576 of
                                           the round-1 plan - all measured slower - were removed.) */
 } ssn_model_desc;
@@ -185,6 +189,8 @@ typedef struct ssn_counters {
   int32_t block_threads;            /* threads actually launched per workgroup                    */
   int32_t fft_transforms;           /* DFT-structured matvecs of a timestep that run as k_dft (FFT) instead of the matrix */
   int32_t fft_bluestein;            /* ... of which through Bluestein's convolution (a prime factor > 32)           */
+  int32_t block_members;            /* member workgroups per ensemble of the whole-block kernel (flag 1073741824; 1 = not split, 0 = no block kernel) */
+  int32_t reserved;
 } ssn_counters;
 
 /* Per-kernel device time of the generic (one launch per operator) plan, collected by ssn_run_steps(profile = 2):

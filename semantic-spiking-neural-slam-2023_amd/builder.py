@@ -789,7 +789,18 @@ class Builder:
 
         for p in self.model.probes:
             if "src" in p:
-                mark(p["src"])
+                unused = getattr(p["probe"], "unused", None)
+                if unused is None:
+                    mark(p["src"])
+                else:
+                    # a probe that declares elements nobody will look at (the shard probe of the sharded path integrator: the
+                    # frequency rows of the oscillator outputs meet all-zero columns of to_SSP) does not keep them alive:
+                    # they are sampled as the zeros they are initialised with
+                    r = p["src"]
+                    keep = ~np.asarray(unused, dtype=bool).reshape(-1)
+                    if keep.size != r.len:
+                        raise fe.BuildError(f"probe.unused has {keep.size} entries for a probe of width {r.len}")
+                    live[r.arena][r.off:r.off + r.len] |= keep
         for table in (self.ens_in, self.ens_J, self.rule_in):
             for r in table.values():
                 mark(r)

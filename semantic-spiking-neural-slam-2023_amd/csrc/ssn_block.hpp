@@ -224,8 +224,8 @@ inline hipError_t read_block_stamps(unsigned long long* out, int reset) {
 //     (identical in all waves: deterministic).  The totals stay "lane-distributed" (row r of a register = decoded row
 //     r): the Lowpass update of the recurrent filter states is ONE v_fma on that register with per-lane constants, and
 //     only the (at most DIN) states the next input needs are broadcast with v_readlane.
-template <typename T, int DIN, int DOUT, int NPT, int TPB, int LDSW>      // LDSW: 0 all parameters in registers | DIN: the encoder rows in LDS
-__global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
+template <typename T, int DIN, int DOUT, int NPT, int TPB, int LDSW, int SPLIT = 0>      // LDSW: 0 all parameters in registers | DIN: the encoder rows in LDS
+__global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT: an ensemble over a.P member workgroups (own instantiation: the plain kernel's loop stays as it is)
   constexpr bool ENC_LDS = LDSW == DIN;
   // (Encoders AND bias in LDS - rows as long as the padded neuron count, 160 000 of the CU's 163 840 bytes at n = 10 000 -
   //  were built and measured in round 2: (768, 14) 3.68 ms and (1024, 10) 3.64 ms per 1000 timesteps of config 2 against
@@ -239,14 +239,20 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   static_assert(NPT % PK == 0, "f32 variants handle neuron pairs");
   using G = typename std::conditional<F32, f32x2, T>::type;   // one group of neurons
   constexpr int DP = DOUT <= 4 ? 4 : 8;
-  const int k = blockIdx.x;
+  // split ensembles: P consecutive workgroups are the members of ensemble k (f32, DOUT <= 4 only - the planner sees to it)
+  static_assert(!SPLIT || (sizeof(T) == 4 && DOUT <= 4), "split ensembles: f32, at most four decoded rows");
+  const int P = SPLIT ? a.P : 1;
+  const int k = P > 1 ? (int)blockIdx.x / P : (int)blockIdx.x;
+  const int member = P > 1 ? (int)blockIdx.x - k * P : 0;
+  const int noff = member * a.n_member;                        // first neuron of this member's slice
+  const int n_loc = P > 1 ? max(0, min(a.n_member, a.n_pad - noff)) : a.n_pad;
   const int tid = threadIdx.x;
   const int nthr = NG == 1 ? (int)blockDim.x : TPB;       // variants with more than one group always run full workgroups
   const int lane = tid & 63, wave = tid >> 6;
   const size_t row = (size_t)a.n_pad;
-  const T* __restrict__ enc = a.enc + (size_t)k * DIN * row;
-  const T* __restrict__ bias = a.bias + (size_t)k * row;
-  T* __restrict__ Sp = a.S + (size_t)k * row;
+  const T* __restrict__ enc = a.enc + (size_t)k * DIN * row + noff;
+  const T* __restrict__ bias = a.bias + (size_t)k * row + noff;
+  T* __restrict__ Sp = a.S + (size_t)k * row + noff;
   const NeuronParams<T> np = a.np;
   const LifMath<T> lm(np);
   const float itau = 1.0f / (float)np.tau_rc;
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int i0 = (g * nthr + tid) * PK;
-    const bool in = i0 < a.n_pad;
+    const bool in = i0 < n_loc;
     const int ii = in ? i0 : 0;
     const T msk = in ? T(1) : T(0);
     auto ld = [&](const T* p) -> G { if constexpr (F32) return *reinterpret_cast<const f32x2*>(p) * msk; else return *p * msk; };
@@ -290,13 +296,13 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
     b[g] = ld(bias + ii);
     s[g] = ld(Sp + ii);
     if (a.dec_neuron_major) {
-      const T* dp = a.dec + ((size_t)k * row + ii) * DP;
+      const T* dp = a.dec + ((size_t)k * row + noff + ii) * DP;
 #pragma unroll
       for (int r = 0; r < DOUT; ++r) {
         if constexpr (F32) dc[g][r] = (f32x2){dp[r], dp[DP + r]} * msk; else dc[g][r] = dp[r] * msk;
       }
     } else {
-      const T* dp = a.dec + (size_t)k * DOUT * row + ii;
+      const T* dp = a.dec + (size_t)k * DOUT * row + noff + ii;
 #pragma unroll
       for (int r = 0; r < DOUT; ++r) dc[g][r] = ld(dp + r * row);
     }
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   for (int j0 = 0; j0 < a.B; j0 += CH) {
     const int cn = min(CH, a.B - j0);
     __syncthreads();                         // previous chunk: every wave is past its last xs read / os write
-    if (j0 > 0) {                            // hand the previous chunk's decoded rows to the post stage
+    if (j0 > 0 && member == 0) {             // hand the previous chunk's decoded rows to the post stage
       for (int i = tid; i < CH * DOUT; i += nthr) {
         const int jj = i / DOUT, r = i - jj * DOUT;
         if (s_out[r]) a.bsig[(size_t)(a.row0 + j0 - CH + jj) * a.n_sig + s_dst[r]] = os[jj][r];
@@ -393,6 +399,13 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
 
     for (int jj = 0; jj < cn; ++jj) {
       SSN_BSTAMP(bt0);
+      if constexpr (SPLIT != 0) {
+        if (P > 1 && wave == 0 && (lane & 15) == 0) {        // split ensemble: own words of the NEXT exchange buffer back to the sentinel
+          unsigned int* const rst = a.xslots + (size_t)k * 64 + (size_t)((j0 + jj + 1) % 3) * ((size_t)a.K * 64) + member * 4 + (lane >> 4);
+          const unsigned int sent = BLOCK_XCHG_SENTINEL;
+          asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(rst), "v"(sent) : "memory");
+        }
+      }
       T xin[XP];
       if constexpr (sizeof(T) == 4) *(float4*)xin = *(const float4*)xs[jj];
       else { *(double2*)xin = *(const double2*)xs[jj]; *(double2*)(xin + 2) = *(const double2*)(xs[jj] + 2); }
@@ -527,12 +540,40 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
         __syncthreads();
         SSN_BSTAMP(bt4);
         v0 = row_sum_dpp(red[par][lane]);                          // row r of every wave: total of decoded row r
+        if constexpr (SPLIT != 0) {
+          if (P > 1) {
+            // Split ensemble: the members publish their four sums and read their partners' (tools/xcd_exchange.hip measured
+            // this protocol: +0.5 - 0.6 us per timestep wherever the members sit).  Three rotating buffers of sentinel
+            // words: step t publishes into buffer t % 3 and resets the member's own words of buffer (t + 1) % 3, which
+            // its partners read for the last time at step t - 2 (a partner that has published step t - 1 has consumed
+            // everybody's step t - 2); the reset is acknowledged (s_waitcnt vmcnt(0)) before this step's publication.
+            // Row r of every wave sums the members in lane order: identical totals, bit for bit, in every member.
+            const int tq = j0 + jj;
+            unsigned int* const xb = a.xslots + (size_t)k * 64;                      // [16 members][4 words] of one buffer
+            const size_t bstride = (size_t)a.K * 64;
+            if (wave == 0 && (lane & 15) == 0) {
+              unsigned int* const pub = xb + (size_t)(tq % 3) * bstride + member * 4 + (lane >> 4);
+              const unsigned int val = f_bits(v0);
+              // (the reset of buffer (t + 1) % 3 was issued at the top of the timestep: its acknowledgement has arrived long ago)
+              asm volatile("s_waitcnt vmcnt(0)\n\tglobal_store_dword %0, %1, off sc0 sc1" :: "v"(pub), "v"(val) : "memory");
+            }
+            const unsigned int* const src = xb + (size_t)(tq % 3) * bstride + (lane & 15) * 4 + (lane >> 4);
+            const bool mine = (lane & 15) < P;
+            unsigned int got = 0, spins = 0;
+            while (true) {
+              if (mine) asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(got) : "v"(src) : "memory");
+              if (!__any(mine && got == BLOCK_XCHG_SENTINEL)) break;
+              if (++spins > (1u << 20)) { if (lane == 0) *a.xerr = 1; break; }        // (a partner that never comes: no hang)
+            }
+            v0 = row_sum_dpp(mine ? bits_f(got) : 0.0f);
+          }
+        }
         F0 = __builtin_fmaf(la0, F0, lb0 * v0);                    // rows without a filter: la = lb = 0
         if constexpr (DOUT > 4) {
           v1 = row_sum_dpp(red[par][64 + lane]);
           F1 = __builtin_fmaf(la1, F1, lb1 * v1);
         }
-        if (wave == 0) {
+        if (wave == 0 && member == 0) {
           if ((lane & 15) == 0 && (lane >> 4) < DOUT) os[jj][lane >> 4] = v0;
           if (DOUT > 4 && lane == 0) os[jj][4] = v1;
         }
@@ -579,7 +620,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
   }
 #endif
   __syncthreads();
-  {                                          // last chunk's decoded rows
+  if (member == 0) {                         // last chunk's decoded rows
     const int j0 = (a.B - 1) / CH * CH, cn = a.B - j0;
     for (int i = tid; i < cn * DOUT; i += nthr) {
       const int jj = i / DOUT, r = i - jj * DOUT;
@@ -593,9 +634,9 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int i0 = (g * nthr + tid2) * PK;
-    if (i0 < a.n_pad) *reinterpret_cast<G*>(Sp + i0) = s[g];       // (padding elements of the row are never read back)
+    if (i0 < n_loc) *reinterpret_cast<G*>(Sp + i0) = s[g];         // (padding elements of the row are never read back)
   }
-  if (a.B > 0) {
+  if (a.B > 0 && member == 0) {
     if constexpr (F32) {
       if (wave == 0 && (lane & 15) == 0 && (lane >> 4) < DOUT) {
         const int r = lane >> 4;
@@ -621,17 +662,25 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {
 
 constexpr int BLOCK_LDS_BYTES = 160 * 1024, BLOCK_STATIC_LDS = 2560;     // CU capacity; bound on the kernel's static arrays
 
-template <typename T, int DIN, int DOUT, int NPT, int TPB, int LDSW>
-static hipError_t launch_block_variant(hipStream_t s, const BlockArgs<T>& a) {
+template <typename T, int DIN, int DOUT, int NPT, int TPB, int LDSW, int SPLIT>
+static hipError_t launch_block_variant_s(hipStream_t s, const BlockArgs<T>& a) {
   const int lds = LDSW * a.threads * NPT * (int)sizeof(T);
   static std::atomic<uint64_t> configured{0};
   if (LDSW > 0) {
-    hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(&k_ens_block<T, DIN, DOUT, NPT, TPB, LDSW>),
+    hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(&k_ens_block<T, DIN, DOUT, NPT, TPB, LDSW, SPLIT>),
                                             BLOCK_LDS_BYTES - BLOCK_STATIC_LDS, configured);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((k_ens_block<T, DIN, DOUT, NPT, TPB, LDSW>), dim3((unsigned)a.K), dim3((unsigned)a.threads), lds, s, a);
+  hipLaunchKernelGGL((k_ens_block<T, DIN, DOUT, NPT, TPB, LDSW, SPLIT>), dim3((unsigned)(a.K * (SPLIT ? a.P : 1))), dim3((unsigned)a.threads), lds, s, a);
   return hipGetLastError();
+}
+template <typename T, int DIN, int DOUT, int NPT, int TPB, int LDSW>
+static hipError_t launch_block_variant(hipStream_t s, const BlockArgs<T>& a) {
+  if (a.P > 1) {
+    if constexpr (sizeof(T) == 4 && DOUT <= 4) return launch_block_variant_s<T, DIN, DOUT, NPT, TPB, LDSW, 1>(s, a);
+    else return hipErrorInvalidValue;
+  }
+  return launch_block_variant_s<T, DIN, DOUT, NPT, TPB, LDSW, 0>(s, a);
 }
 
 // (workgroup size, neurons per thread, parameter rows in LDS) variants, in the order the planner tries them.  A wave's

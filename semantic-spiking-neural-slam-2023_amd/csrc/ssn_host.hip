@@ -921,8 +921,26 @@ struct Sim final : ssn_sim {
     //  every timestep was built and measured in round 1 - 3.3 us per timestep at P = 2 and 3.6 at P = 4 against 2.95 for
     //  one workgroup on 127- / 64-VCO shards: a cross-CU round trip costs ~1.6 us, more than halving the neuron work
     //  saves - and removed in round 2: DESIGN.md section 5.)
+    // Split ensembles (flag 1073741824; f32, dout <= 4): when the array has fewer ensembles than the GPU has CUs - a 4- or
+    // 8-GPU shard of config 2, a small model - P = 2 or 4 member workgroups step one ensemble and exchange their partial sums
+    // every timestep (k_ens_block; the exchange costs 0.5 - 0.6 us per timestep, tools/xcd_exchange.hip).  All K * P
+    // workgroups must be resident together, so P is only raised while K * P fits the CUs - and the caller only asks for
+    // it when this process has the GPU to itself.
+    int split_P = 1, n_member = 0;
+    if ((flags & 1073741824) && sizeof(T) == 4 && dout <= 4) {
+      hipDeviceProp_t prop;
+      int n_cu = 256;
+      if (hipGetDeviceProperties(&prop, device) == hipSuccess) n_cu = prop.multiProcessorCount;
+      if (const char* env = getenv("SSN_BLOCK_SPLIT_CUS")) n_cu = atoi(env);            // (tests: pretend the GPU is smaller / larger)
+      const int64_t n_ens = eo.i[2];
+      for (int cand : {4, 2}) {
+        if (K * cand <= n_cu && n_ens / cand >= 1024) { split_P = cand; break; }
+      }
+      if (const char* env = getenv("SSN_BLOCK_SPLIT")) { const int q = atoi(env); if (q == 1 || q == 2 || q == 4 || q == 8) split_P = q; }
+      if (split_P > 1) n_member = (int)(((n_ens + split_P - 1) / split_P + 3) / 4 * 4);
+    }
     if (defer && !(flags & 128) && ens_fast(eo) && (sizeof(T) == 8 || (dt <= 0.05 * eo.f[0] && eo.f[1] >= dt)) &&
-        ssn::ens_block_supported<T>((int)din, (int)dout, (int)eo.i[2], &blk_threads, &blk_tpb, &blk_npt, &blk_lds)) {
+        ssn::ens_block_supported<T>((int)din, (int)dout, split_P > 1 ? n_member : (int)eo.i[2], &blk_threads, &blk_tpb, &blk_npt, &blk_lds)) {
       const int64_t nr = K * dout;
       int* d_lp = nullptr; T* d_a = nullptr; T* d_b = nullptr; unsigned char* d_ro = nullptr; int* d_xrow = nullptr; T* d_xalpha = nullptr;
       if ((*rc = dmalloc(&d_lp, nr * 4)) != SSN_OK) return true;
@@ -950,6 +968,15 @@ struct Sim final : ssn_sim {
       blk.B = 0; blk.row0 = 1; blk.threads = blk_threads; blk.tpb = blk_tpb; blk.npt = blk_npt; blk.enc_lds = blk_lds;
       blk.dec_neuron_major = ea.fast == 1 ? 1 : 0;
       blk.np = ea.np;
+      blk.P = split_P; blk.n_member = n_member; blk.xslots = nullptr; blk.xerr = nullptr;
+      if (split_P > 1) {
+        unsigned int* d_x = nullptr; int* d_e = nullptr;
+        if ((*rc = dmalloc(&d_x, (int64_t)3 * K * 64 * 4)) != SSN_OK) return true;
+        if ((*rc = dmalloc(&d_e, 16)) != SSN_OK) return true;
+        fused_bufs.insert(fused_bufs.end(), {(void*)d_x, (void*)d_e});
+        hipMemset(d_e, 0, 16);
+        blk.xslots = d_x; blk.xerr = d_e;
+      }
       dom_units = (int64_t)ea.K * ea.n * block;
       dom_bytes = (double)dom_units * (ea.din + ea.dout + 5) * sizeof(T);
       fused_core = fused_block = true;
@@ -2552,6 +2579,8 @@ struct Sim final : ssn_sim {
       if (fused_block) {
         const bool timed = profile && B == block && ev_used + 2 <= ev_pool.size();
         blk.B = (int)B;
+        if (blk.P > 1)      // every exchange word back to the sentinel: the kernel boundary is the members' only common barrier
+          HIPCHK(hipMemsetD32Async((hipDeviceptr_t)blk.xslots, (int)ssn::BLOCK_XCHG_SENTINEL, (size_t)3 * blk.K * 64, stream));
         if (timed) HIPCHK(hipEventRecord(ev_pool[ev_used], stream));
         HIPCHK(ssn::launch_ens_block<T>(stream, blk));
         if (timed) { HIPCHK(hipEventRecord(ev_pool[ev_used + 1], stream)); ev_used += 2; }
@@ -2679,6 +2708,12 @@ struct Sim final : ssn_sim {
     HIPCHK(hipMemcpy(&ctx, d_ctx, sizeof ctx, hipMemcpyDeviceToHost));
     if (ctx.step != steps_done) return fail(SSN_EHIP, "device step counter %lld != host %lld", (long long)ctx.step, (long long)steps_done);
     if (ctx.probe_overflow) return fail(SSN_EINVAL, "probe storage overflow: call ssn_reserve_probes before ssn_run_steps");
+    if (fused_block && blk.P > 1) {
+      int xe = 0;
+      HIPCHK(hipMemcpy(&xe, blk.xerr, sizeof xe, hipMemcpyDeviceToHost));
+      if (xe) return fail(SSN_EHIP, "split ensembles: a member workgroup waited too long for a partner's sums (are all %d workgroups "
+                                    "resident together? flag 1073741824 needs the GPU for this process alone)", blk.K * blk.P);
+    }
     return SSN_OK;
   }
 
@@ -2813,6 +2848,8 @@ struct Sim final : ssn_sim {
     out->block_npt = fused_block ? blk.npt : 0;
     out->block_enc_lds = fused_block ? blk.enc_lds : 0;
     out->block_threads = fused_block ? blk.threads : 0;
+    out->block_members = fused_block ? std::max(1, blk.P) : 0;
+    out->reserved = 0;
     out->fft_transforms = 0; out->fft_bluestein = 0;
     for (auto& it : items) if (it.type == IT_DFT) { out->fft_transforms += 1; out->fft_bluestein += it.dft.M > 0 ? 1 : 0; }
     return SSN_OK;

@@ -123,7 +123,14 @@ struct BlockArgs {
   int dec_neuron_major;
   int enc_lds;         // kernel variant keeps the encoders in LDS instead of registers
   NeuronParams<T> np;
+  // Split ensembles (round 3; f32, dout <= 4): P member workgroups per ensemble, member m steps neurons [m * n_member, ...)
+  // and the members exchange their four partial sums every timestep (k_ens_block, ssn_block.hpp).  P = 1: one workgroup.
+  int P;
+  int n_member;        // neurons per member (a multiple of 4)
+  unsigned int* xslots;   // [3 buffers][K][16 members][4 words], all words = the sentinel at launch (host memset)
+  int* xerr;           // set to 1 by a member that waited too long for a partner (the launch then produced garbage)
 };
+constexpr unsigned int BLOCK_XCHG_SENTINEL = 0x7fc0deadu;      // a NaN payload no sum produces
 
 // k_dft: the real-DFT maps of a circular-convolution network (reference binding.py:23-74) as a mixed-radix FFT.
 struct DftArgs {

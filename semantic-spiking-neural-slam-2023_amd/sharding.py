@@ -94,6 +94,11 @@ class ShardedPathIntegration:
                 if width else None
         if self.osc_probe is not None:
             pm.model.probes.remove(self.osc_probe)
+            # oscillator outputs that meet all-zero columns of the read-out (the frequency dimension of every VCO,
+            # get_from_Fourier, reference pathintegration.py:824-844) need not be decoded by the shard either: the unsharded
+            # model drops those rows through the builder's liveness pass, the shard's probe would otherwise keep them alive
+            # (a fifth decoded row per VCO: ~6 % of the shard's step time, and no split ensembles)
+            self.osc_probe.unused = np.all(np.asarray(pi.to_SSP)[:, 3 * self.lo:3 * self.hi] == 0.0, axis=0)
         probes = [self.osc_probe] if self.osc_probe is not None else []
         self.model = build(pm.model, dt=dt, n_eval_points=n_eval_points, vco_shard=(rank, world),
                            probes=probes, prune=True)

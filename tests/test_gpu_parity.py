@@ -1258,7 +1258,7 @@ def test_sharded_pathint_streaming_plan_and_choose_plan(Simulator):
     r = ShardedPathIntegration(small_pathint(**kw), 0, 1, dtype="f64", block=128, n_eval_points=1500, flags=128)
     r.prepare(256)
     r.run_steps(256)
-    assert r.sim.counters()["launches_per_step"] == 1 and r.sim.counters()["block_tpb"] == 0
+    assert r.sim.counters()["launches_per_step"] == 1 and r.sim.counters()["block_tpb"] == 0 and r.sim.counters()["block_members"] == 0
     np.testing.assert_allclose(r.probe_data(), want, atol=1e-9, rtol=0)
     r.close()
     # choose_plan on a shard where both plans exist (n = 600: block kernel vs streaming); the chosen one steps on
@@ -1372,3 +1372,54 @@ def test_sharded_slam_stream_ordered_run_equals_the_host_loop(Simulator):
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     np.testing.assert_allclose(outs[0][0], ref.probe_data(0), atol=1e-9, rtol=0)
+
+
+def test_split_vco_members_match_oracle(Simulator):
+    """Split ensembles of the whole-block kernel (flag 1073741824): an array with fewer VCOs than the GPU has
+    CUs - a 4- or 8-GPU shard of BASELINE config 2 - is stepped by 2 or 4 member workgroups per VCO that exchange their four
+    partial sums every timestep (sentinel words in three rotating buffers).  Against the oracle (1e-3 cosine) and against the
+    unsplit kernel (the sums are re-associated over the members: rounding only), members of unequal size (n not a multiple of
+    4 P), several launches in a run (the exchange words are reset at every kernel boundary), the planner's own choice of P,
+    and the cases it must leave alone (f64; a fifth decoded row; more VCOs than CUs)."""
+    SPLIT = 1073741824
+    os.environ.pop("SSN_BLOCK_SPLIT", None)
+    os.environ.pop("SSN_BLOCK_SPLIT_CUS", None)
+    try:
+        for n, force, expect in ((5203, "2", 2), (5203, "4", 4), (9000, None, 4), (2600, None, 2)):
+            pm = small_pathint(ssp_dim=19, n=n, T=10.0, limit=0.2)          # (ssp_dim 19 -> d = 7: 4 VCOs)
+            model = build(pm.model, n_eval_points=600)
+            ref = OracleSimulator(model)
+            ref.run_steps(300)
+            want = ref.probe_data(0)
+            with Simulator(None, model=model, dtype="f32", block_steps=100) as sim:
+                sim.run_steps(300)
+                plain = sim.data[pm.probe]
+                assert sim.counters()["block_members"] == 1
+            if force:
+                os.environ["SSN_BLOCK_SPLIT"] = force
+            with Simulator(None, model=model, dtype="f32", flags=SPLIT, block_steps=100) as sim:
+                os.environ.pop("SSN_BLOCK_SPLIT", None)
+                sim.run_steps(130)                   # 100 + 30, then 100 + 70: four launches, two of them short
+                sim.run_steps(170)
+                got = sim.data[pm.probe]
+                c = sim.counters()
+            assert c["block_members"] == expect and c["launches_per_step"] == 0, c
+            assert H.cosine_error(got[20:], want[20:]).max() < 1e-3
+            assert np.abs(got - plain).max() < 2e-4 * np.abs(plain).max()
+        # left alone: f64; a probe that keeps the fifth decoded row; more VCOs than (pretended) CUs
+        pm = small_pathint(ssp_dim=19, n=5203, T=10.0, limit=0.2)
+        model = build(pm.model, n_eval_points=600)
+        with Simulator(None, model=model, dtype="f64", flags=SPLIT, block_steps=100) as sim:
+            assert sim.counters()["block_members"] in (0, 1)
+        os.environ["SSN_BLOCK_SPLIT_CUS"] = "7"       # 4 VCOs x 2 members > 7 "CUs"
+        with Simulator(None, model=model, dtype="f32", flags=SPLIT, block_steps=100) as sim:
+            assert sim.counters()["block_members"] == 1
+        os.environ.pop("SSN_BLOCK_SPLIT_CUS", None)
+        pm5 = small_pathint(ssp_dim=19, n=5203, T=10.0, limit=0.2)
+        with pm5.model:
+            nengo.Probe(pm5.pathintegrator.oscillators.output, synapse=None)
+        with Simulator(None, model=build(pm5.model, n_eval_points=600), dtype="f32", flags=SPLIT, block_steps=100) as sim:
+            assert sim.counters()["block_members"] == 1
+    finally:
+        os.environ.pop("SSN_BLOCK_SPLIT", None)
+        os.environ.pop("SSN_BLOCK_SPLIT_CUS", None)
