@@ -29,7 +29,7 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])          # (8 ranks over 28 VCOs: shards of 4, the last rank has none)
 def test_sharded_equals_unsharded(world):
     import subprocess
     from sspslam_amd.builder import build
