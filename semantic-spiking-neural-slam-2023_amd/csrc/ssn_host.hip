@@ -192,6 +192,11 @@ struct Sim final : ssn_sim {
 
   ssn::StepCtx* d_ctx = nullptr;
   std::vector<ssn::TableSlot> tables;
+  // host copy of every table's row index per step, and where each table's rows land in the signal vector: a time-batched
+  // product whose whole input is a table that is zero for the whole block (the init-SSP input of the path integrator after
+  // its first 50 ms, reference run_pathint.py:136) is not multiplied out - its result rows are zero-filled instead
+  std::vector<std::vector<int32_t>> table_idx_host;
+  std::vector<std::pair<long long, long long>> table_dst;      // (signal offset, width) per table id; width 0: unknown
   ssn::TableSlot* d_tables = nullptr;
   std::vector<void*> table_rows;
   std::vector<int*> table_idx;
@@ -1141,7 +1146,10 @@ struct Sim final : ssn_sim {
         switch (o.kind) {
           case SSN_OP_FILL: b.kind = ssn::M_FILL; b.dst = o.i[0]; b.len = o.i[1]; b.a = (T)o.f[0]; wlo = o.i[0]; wlen = o.i[1]; break;
           case SSN_OP_TABLE: b.kind = ssn::M_TABLE; b.dst = o.i[0]; b.len = o.i[1]; b.p0 = d_tables + o.i[2];
-            tables[o.i[2]].width = o.i[1]; wlo = o.i[0]; wlen = o.i[1]; break;
+            tables[o.i[2]].width = o.i[1]; wlo = o.i[0]; wlen = o.i[1];
+            if (table_dst.size() < tables.size()) table_dst.resize(tables.size(), {0, 0});
+            table_dst[(size_t)o.i[2]] = {o.i[0], o.i[1]};
+            break;
           case SSN_OP_AXPY: b.kind = o.i[3] ? ssn::M_AXPY_SET : ssn::M_AXPY_INC; b.dst = o.i[0]; b.src = o.i[1]; b.len = o.i[2];
             b.a = (T)o.f[0]; wlo = o.i[0]; wlen = o.i[2]; break;
           case SSN_OP_LOWPASS: b.kind = ssn::M_LOWPASS; b.dst = o.i[0]; b.src = o.i[1]; b.len = o.i[2];
@@ -2271,6 +2279,30 @@ struct Sim final : ssn_sim {
       if (rd(a) && wr(b) && ov(a.src, a.len, b.dst, b.len)) return true;
       return false;
     };
+    // Signal elements known to be ZERO in every row of this block: a table without an entry for any timestep of the block
+    // (the init-SSP input of the path integrator after its first 50 ms, reference run_pathint.py:136), and what fills /
+    // copies / products make of zeros.  A product whose whole input is zero is not multiplied out (PathIntegration config 2:
+    // the 1000 x 1015 x 1524 to_Fourier GEMM of every block but the first - 47 of a block's 3480 us).
+    std::vector<char> zero((size_t)n_sig, 0);
+    const bool track = !getenv("SSN_NO_ZERO_SKIP");
+    auto all_zero = [&](long long lo, long long n) { for (long long q = lo; q < lo + n; ++q) if (!zero[(size_t)q]) return false; return n > 0; };
+    auto set_zero = [&](long long lo, long long n, bool v) { for (long long q = lo; q < lo + n; ++q) zero[(size_t)q] = v ? 1 : 0; };
+    auto note = [&](const ssn::BatchOp<T>& o) {              // effect of an operator that IS executed on the zero map
+      if (!track) return;
+      switch (o.kind) {
+        case ssn::M_TABLE: {
+          bool z = false;
+          for (size_t id = 0; id < table_dst.size() && id < table_idx_host.size(); ++id)
+            if (table_dst[id].second > 0 && table_dst[id].first == o.dst && table_dst[id].second == o.len) z = table_is_zero((int)id, B, step0);
+          set_zero(o.dst, o.len, z); break;
+        }
+        case ssn::M_FILL: set_zero(o.dst, o.len, o.a == T(0)); break;
+        case ssn::M_AXPY_SET: set_zero(o.dst, o.len, !o.src_prev && all_zero(o.src, o.len)); break;
+        case ssn::M_AXPY_INC: if (o.src_prev || !all_zero(o.src, o.len)) set_zero(o.dst, o.len, false); break;
+        case ssn::M_PROBE: break;
+        default: set_zero(o.dst, o.len, false); break;          // products, filters: not known
+      }
+    };
     for (size_t i = 0; i < ops.size();) {
       ops[i].B = B; ops[i].step0 = step0;
       if (elementwise(ops[i]) && !(flags & 262144)) {
@@ -2289,15 +2321,37 @@ struct Sim final : ssn_sim {
         if (l.count > 1) {
           hipError_t e = ssn::launch_batch_elementwise<T>(stream, l);
           if (e != hipSuccess) return e;
+          for (int q = 0; q < l.count; ++q) note(l.op[q]);      // (members of one launch are independent of each other: any order)
           i = j;
           continue;
         }
       }
+      if (track && (ops[i].kind == ssn::M_MATVEC_SET || ops[i].kind == ssn::M_MATVEC_INC) && !ops[i].src_prev && all_zero(ops[i].src, ops[i].cols)) {
+        if (ops[i].kind == ssn::M_MATVEC_SET) {        // W @ 0: the result rows of the block are zero (an increment adds nothing)
+          hipError_t e = hipMemset2DAsync(bsig + n_sig + ops[i].dst, (size_t)n_sig * sizeof(T), 0, (size_t)ops[i].len * sizeof(T), (size_t)B, stream);
+          if (e != hipSuccess) return e;
+          set_zero(ops[i].dst, ops[i].len, true);
+        }
+        ++i;
+        continue;
+      }
       hipError_t e = ssn::launch_batch_op<T>(stream, ops[i]);
       if (e != hipSuccess) return e;
+      note(ops[i]);
       ++i;
     }
     return hipSuccess;
+  }
+
+  // Has the table no entry (index -1, or outside its range) for every timestep of this block?  Its rows are zeros then.
+  bool table_is_zero(int id, int B, int64_t step0) const {
+    const ssn::TableSlot& t = tables[(size_t)id];
+    const std::vector<int32_t>& ix = table_idx_host[(size_t)id];
+    for (int64_t st = step0; st < step0 + B; ++st) {
+      const int64_t rel = st - t.first_step;
+      if (rel >= 0 && rel < (int64_t)ix.size() && ix[(size_t)rel] >= 0) return false;
+    }
+    return true;
   }
 
   // ---- launching --------------------------------------------------------------------------
@@ -2760,6 +2814,8 @@ struct Sim final : ssn_sim {
     if (rows_dev) HIPCHK(hipMemcpy(table_rows[id], rows_dev, (size_t)(n_rows * width) * sizeof(T), hipMemcpyDeviceToDevice));
     else if (n_rows) CHK(upload(rows, (T*)table_rows[id], n_rows, width, width));
     if (n_idx) HIPCHK(hipMemcpy(table_idx[id], idx, (size_t)n_idx * 4, hipMemcpyHostToDevice));
+    if (table_idx_host.size() < tables.size()) table_idx_host.resize(tables.size());
+    table_idx_host[(size_t)id].assign(idx, idx + n_idx);
     tables[id] = ssn::TableSlot{table_rows[id], table_idx[id], n_rows, width, n_idx, first_step};
     HIPCHK(hipMemcpy(d_tables + id, &tables[id], sizeof(ssn::TableSlot), hipMemcpyHostToDevice));
     return SSN_OK;
