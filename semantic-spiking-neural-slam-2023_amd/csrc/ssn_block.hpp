@@ -122,62 +122,97 @@ __device__ inline f32x2 pk_fma_clamp01_trans_vvs(f32x2 x, f32x2 y, f32x2 z) {
   return r;
 }
 
+__device__ inline f32x2 pk_add_clamp01_m1(f32x2 x) {                // clamp(x - 1)
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, -1.0 op_sel_hi:[1,0] clamp" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ inline f32x2 pk_fma_clamp01_vs_negv(f32x2 x, f32x2 y, f32x2 z) {     // clamp(x * y - z), y a uniform constant pair
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1] clamp" : "=v"(r) : "v"(x), "s"(y), "v"(z));
+  return r;
+}
+
 // Branch-free f32 LIF step, TWO neurons per call in the two halves of 64-bit register pairs, built ONLY from packed
 // multiply / add / FMA (v_pk_*_f32: 2 flops per lane per issue slot) plus one v_rcp_f32 and one v_log_f32 per neuron:
 // no compare, no select, no integer min / max.  On gfx950 every non-FMA vector instruction (v_cndmask, v_cmp, v_max_i32,
 // v_med3 ...) costs a full issue slot of its own per NEURON where a packed one serves two (v_cndmask: five of them - measured,
 // tools/valu_issue_rate.hip, profiles/round3_valu_issue_rate.txt), so the selects of nengo's LIF step (SURVEY
-// Appendix A.4) are rewritten as exact arithmetic on {0, 1} indicators made with the clamp modifier:
+// Appendix A.4) are rewritten as exact arithmetic on {0, 1} indicators made with the clamp modifier.
 //
-//   state word s:  s >= 0  voltage of a non-refractory neuron (<= 1);  s < 0  -(R - dt), R = refractory time left at the
-//                  start of the next step (> dt; a refractory time <= dt is not stored: the next step integrates for the
-//                  full dt whatever its value)
-//   V0 = clamp(s)                 max(s, 0)
-//   r  = clamp(-s)                max(-s, 0) = R - dt of a refractory neuron (< 1), else 0
-//   delta = clamp(dt - r)         integration time  (nengo: clip(dt - refractory, 0, dt)); t = dt - r is what is left of this step
-//   nmt = clamp(r - dt)           -min(t, 0): > 0 while the neuron stays refractory beyond the next step - minus the new state
-//                                 word (r - dt = -(dt - r) exactly, so this is round 2's t - clamp(t) with one operation less)
-//   em = delta * P(delta)         -expm1(-delta / tau_rc) = x - x^2/2 + x^3/6 - x^4/24, x = delta / tau_rc <= 1/20: the first
-//                                 neglected term is x^4/120 < 5.3e-8 of the result (half an f32 ulp)
-//   V  = V0 + (J - V0) * em
-//   spk = clamp((V - 1) * 2^24)   1 if V > 1 (V - 1 is exact and >= 2^-23 then), else 0
-//   nu = clamp(tau_ref + tau_rc * ln(1 - (V - 1) / (J - 1)))      MINUS the new state word of a spiking neuron (tau_ref +
-//                                 t_spike - dt, in [tau_ref - dt, tau_ref] - inside [0, 1] because tau_ref >= dt).  A silent
-//                                 neuron feeds rcp / log whatever its J - 1 and V - 1 are (0, negative: inf, NaN); the clamp
-//                                 turns any of it into a number in [0, 1] (DX10 clamp: NaN -> 0) and spk = 0 discards it -
-//                                 round 2 guarded the operand instead ((J - 1) * spk + nspk): two packed operations more
-//   Vn = clamp(V - spk * 2^24)    voltage of a silent neuron clamped at min_voltage 0 (V <= 1), 0 for a spiking one
-//   s' = (Vn - nmt) - spk * nu    (spiking: nmt = Vn = 0; silent: spk = 0 - exact selects, products with 0 / 1)
+// Inside the time loop the state word is w = 1 - V for a neuron that integrates (0 <= w <= 1: the distance to the threshold)
+// and w = 1 + K (R - dt) for a refractory one (R = refractory time left at the start of the next step, > dt; K a power of two
+// with K tau_ref <= 1: times in units of 1 / K so that they fit the clamp's [0, 1] without losing bits next to the 1).  The
+// input current arrives as J - 1 (the bias registers hold bias - 1).  With everything measured from the threshold, V - 1 and
+// J - 1 - the operands of the spike test and of the spike time - are what the update produces anyway: 16 packed operations
+// per neuron pair against 19 with V and J (round 3's second cut; the words in HBM keep round 2's form, see the prologue).
+//
+//   W0 = clamp(w)                 1 - V0  (V0 = 0 while refractory)
+//   rt = clamp(w - 1)             K (R - dt) of a refractory neuron (< 1), else 0
+//   dl = clamp(K dt - rt)         K x integration time  (nengo: clip(dt - refractory, 0, dt))
+//   nmt = clamp(rt - K dt)        > 0 while the neuron stays refractory beyond the next step: its new word is 1 + nmt
+//   em = dl * P(dl)               -expm1(-delta / tau_rc), P of degree 2: the interpolant of (1 - exp(-x)) / x through x = h,
+//                                 h / 2, 0.067 h with h = dt / tau_rc <= 1/20 - EXACT for a full step (delta = dt, all steps
+//                                 but the one in which a refractory period ends), within 2.3e-7 of the result for a partial
+//                                 one (a 4-term Taylor polynomial, one operation more, was within 5.3e-8 everywhere)
+//   U  = (Jm1 + W0) * em - W0     V - 1 = V0 + (J - V0) em - 1
+//   spk = clamp(U * 2^100)        1 if V > 1, else 0 (a positive U is at least 2^-53: it is the rounded difference of a
+//                                 product >= 2^-6 and a W0 next to it)
+//   nu = clamp(K tau_ref + K tau_rc ln(1 - U / Jm1))      K (tau_ref + t_spike - dt) of a spiking neuron, inside [0, 1] because
+//                                 dt <= tau_ref.  A silent neuron feeds rcp / log whatever its operands are (0, negative: inf,
+//                                 NaN); the clamp turns any of it into a number in [0, 1] (DX10 clamp: NaN -> 0), spk = 0 discards it
+//   Wn = clamp(spk * 2^100 - U)   1 - Vn: voltage of a silent neuron clamped at min_voltage 0, Vn = 0 for a spiking one
+//   w' = (Wn + nmt) + spk * nu    (spiking: Wn = 1, nmt = 0; silent: spk = 0 - exact selects, products with 0 / 1)
 // Requires dt / tau_rc <= 1/20 and tau_ref >= dt (checked by the host planner).
-struct LifConstV2 { float dt, a1, a2, a3, a4, tau_ln2, tau_ref; };
+struct LifConstV3 { float kdt, c1, c2, c3, ktau_ln2, ktau_ref, K; };
 
-__device__ inline f32x2 lif_packed_step_f32x2(f32x2 J, f32x2& s, const LifConstV2& c, f32x2 big, f32x2 nbig) {
-  const f32x2 V0 = pk_clamp01(s);
-  const f32x2 r = pk_neg_clamp01(s);                          // max(-s, 0) = R - dt of a refractory neuron, else 0
-  const f32x2 delta = pk_rsub_clamp01(r, (f32x2)(c.dt));      // clamp(dt - r)
-  const f32x2 nmt = pk_sub_clamp01(r, (f32x2)(c.dt));         // clamp(r - dt) = -min(dt - r, 0)
+// K and the coefficients of P in units of 1 / K (uniform; evaluated once per launch, in double)
+__device__ inline LifConstV3 lif_const_v3(double dt, double tau_rc, double tau_ref) {
+  double K = 1.0;
+  while (2.0 * K * tau_ref <= 1.0 && K < 1048576.0) K *= 2.0;
+  while (K * tau_ref > 1.0) K *= 0.5;
+  const double h = dt / tau_rc;
+  const double x0 = h, x1 = 0.5 * h, x2 = 0.0669872981077807 * h;
+  auto f = [](double x) { return -expm1(-x) / x; };
+  const double f0 = f(x0), f1 = f(x1), f2 = f(x2);
+  // Newton form of the interpolant, expanded to monomials
+  const double d01 = (f1 - f0) / (x1 - x0), d12 = (f2 - f1) / (x2 - x1), d012 = (d12 - d01) / (x2 - x0);
+  const double q2 = d012, q1 = d01 - d012 * (x0 + x1), q0 = f0 - d01 * x0 + d012 * x0 * x1;
+  const double u = 1.0 / (K * tau_rc);                           // x = dl * u
+  LifConstV3 c;
+  c.kdt = (float)(K * dt); c.c1 = (float)(q0 * u); c.c2 = (float)(q1 * u * u); c.c3 = (float)(q2 * u * u * u);
+  c.ktau_ln2 = (float)(K * tau_rc * 0.6931471805599453); c.ktau_ref = (float)(K * tau_ref); c.K = (float)K;
+  return c;
+}
+
+__device__ inline f32x2 lif_packed_step_f32x2(f32x2 Jm1, f32x2& w, const LifConstV3& c, f32x2 big) {
+  const f32x2 W0 = pk_clamp01(w);
+  const f32x2 rt = pk_add_clamp01_m1(w);
+  const f32x2 dl = pk_rsub_clamp01(rt, (f32x2)(c.kdt));       // clamp(K dt - rt)
+  const f32x2 nmt = pk_sub_clamp01(rt, (f32x2)(c.kdt));       // clamp(rt - K dt)
   // (uniform coefficients as scalar-register pairs: one constant-bus operand per instruction, the first FMA's second
   //  coefficient lives in a vector register pair)
   f32x2 P;
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(delta), "v"((f32x2)(c.a4)), "s"((f32x2)(c.a3)));
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(delta), "v"(P), "s"((f32x2)(c.a2)));
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(delta), "v"(P), "s"((f32x2)(c.a1)));
-  const f32x2 em = delta * P;
-  const f32x2 V = __builtin_elementwise_fma(J - V0, em, V0);
-  const f32x2 vm1 = V - 1.0f, jm1 = J - 1.0f;
-  const f32x2 spk = pk_mul_clamp01(vm1, big);
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(dl), "v"((f32x2)(c.c3)), "s"((f32x2)(c.c2)));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(dl), "v"(P), "s"((f32x2)(c.c1)));
+  const f32x2 em = dl * P;
+  const f32x2 U = __builtin_elementwise_fma(Jm1 + W0, em, -W0);
+  const f32x2 spk = pk_mul_clamp01(U, big);
   f32x2 rc;
-  rc.x = __builtin_amdgcn_rcpf(jm1.x);
-  rc.y = __builtin_amdgcn_rcpf(jm1.y);
-  const f32x2 omu = __builtin_elementwise_fma(-vm1, rc, (f32x2)(1.0f));     // 1 - (V - 1) / (J - 1)
+  rc.x = __builtin_amdgcn_rcpf(Jm1.x);
+  rc.y = __builtin_amdgcn_rcpf(Jm1.y);
+  const f32x2 omu = __builtin_elementwise_fma(-U, rc, (f32x2)(1.0f));       // 1 - (V - 1) / (J - 1)
   f32x2 lg2;
   lg2.x = __builtin_amdgcn_logf(omu.x);
   lg2.y = __builtin_amdgcn_logf(omu.y);
-  const f32x2 nu = pk_fma_clamp01_trans_vvs(lg2, (f32x2)(c.tau_ln2), (f32x2)(c.tau_ref));
-  const f32x2 Vn = pk_fma_clamp01_vsv(spk, nbig, V);
-  s = __builtin_elementwise_fma(-spk, nu, Vn - nmt);
+  const f32x2 nu = pk_fma_clamp01_trans_vvs(lg2, (f32x2)(c.ktau_ln2), (f32x2)(c.ktau_ref));
+  const f32x2 Wn = pk_fma_clamp01_vs_negv(spk, big, U);
+  w = __builtin_elementwise_fma(spk, nu, Wn + nmt);
   return spk;
 }
+// HBM state word (s >= 0: voltage; s < 0: -(R - dt)) <-> loop word
+__device__ inline float lif_word_in(float s, float K) { return __builtin_fmaf(-s, s < 0.0f ? K : 1.0f, 1.0f); }
+__device__ inline float lif_word_out(float w, float K) { return (1.0f - w) * (w > 1.0f ? 1.0f / K : 1.0f); }
 
 __device__ inline float bits_f(unsigned int x) { return __builtin_bit_cast(float, x); }
 __device__ inline unsigned int f_bits(float x) { return __builtin_bit_cast(unsigned int, x); }
@@ -255,13 +290,13 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
   T* __restrict__ Sp = a.S + (size_t)k * row + noff;
   const NeuronParams<T> np = a.np;
   const LifMath<T> lm(np);
-  const float itau = 1.0f / (float)np.tau_rc;
-  // (float arithmetic runs on the vector unit: readfirstlane moves the uniform results to scalar registers, where the
-  //  packed instructions of the time loop can take them as their one constant-bus operand)
+  // (uniform values: readfirstlane moves them to scalar registers, where the packed instructions of the time loop can take
+  //  them as their one constant-bus operand)
   auto uni = [](float v) { return bits_f(__builtin_amdgcn_readfirstlane(f_bits(v))); };
-  const LifConstV2 lc{uni((float)np.dt), uni(itau), uni(-0.5f * itau * itau), uni(itau * itau * itau / 6.0f),
-                      uni(-itau * itau * itau * itau / 24.0f), uni((float)np.tau_rc * 0.6931471805599453f), uni((float)np.tau_ref)};
-  const f32x2 big = {16777216.0f, 16777216.0f}, nbig = {-16777216.0f, -16777216.0f};
+  LifConstV3 lc = lif_const_v3((double)np.dt, (double)np.tau_rc, (double)np.tau_ref);
+  lc.kdt = uni(lc.kdt); lc.c1 = uni(lc.c1); lc.c2 = uni(lc.c2); lc.c3 = uni(lc.c3); lc.ktau_ln2 = uni(lc.ktau_ln2); lc.ktau_ref = uni(lc.ktau_ref);
+  lc.K = uni(lc.K);
+  const f32x2 big = {0x1p100f, 0x1p100f};
 
   // ---- parameters and state of this thread's neurons -> registers ---------------------------------------------
   G e[ENC_LDS ? 1 : NG][DIN], b[NG], s[NG], dc[NG][DOUT];
@@ -295,6 +330,10 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
     }
     b[g] = ld(bias + ii);
     s[g] = ld(Sp + ii);
+    if constexpr (F32) {                                   // the time loop's forms: J - 1, distance to the threshold (lif_packed_step_f32x2)
+      b[g] = b[g] - 1.0f;
+      s[g] = (f32x2){lif_word_in(s[g].x, lc.K), lif_word_in(s[g].y, lc.K)};
+    }
     if (a.dec_neuron_major) {
       const T* dp = a.dec + ((size_t)k * row + noff + ii) * DP;
 #pragma unroll
@@ -471,7 +510,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
           const int g = g0 + u;
           if (g >= NG) continue;
           if constexpr (F32) {
-            spk[u] = lif_packed_step_f32x2(J[u], s[g], lc, big, nbig);
+            spk[u] = lif_packed_step_f32x2(J[u], s[g], lc, big);
           } else {
             // packed state word -> nengo's LIF step, operation for operation k_ensarray's fast path
             const T sw = s[g];
@@ -634,6 +673,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int i0 = (g * nthr + tid2) * PK;
+    if constexpr (F32) s[g] = (f32x2){lif_word_out(s[g].x, lc.K), lif_word_out(s[g].y, lc.K)};
     if (i0 < n_loc) *reinterpret_cast<G*>(Sp + i0) = s[g];         // (padding elements of the row are never read back)
   }
   if (a.B > 0 && member == 0) {

@@ -1407,6 +1407,8 @@ struct Sim final : ssn_sim {
       push_micro(op, -2, first_probe);
       first_probe = false;
     }
+    optimise_batch(pre_ops);
+    optimise_batch(post_ops);
     if (!fused) {
       MOp end{};
       end.kind = ssn::M_STEP_END;
@@ -2265,20 +2267,102 @@ struct Sim final : ssn_sim {
     return SSN_OK;
   }
 
+  // Element-wise operators of a time-batched stage: what they write / read (column ranges; rows are handled alike).
+  static bool batch_elementwise(const ssn::BatchOp<T>& o) {
+    return o.kind == ssn::M_FILL || o.kind == ssn::M_AXPY_INC || o.kind == ssn::M_AXPY_SET || o.kind == ssn::M_TABLE || o.kind == ssn::M_PROBE;
+  }
+  static bool batch_writes(const ssn::BatchOp<T>& o) { return o.kind != ssn::M_PROBE; }
+  static bool batch_reads(const ssn::BatchOp<T>& o) {
+    return o.kind == ssn::M_AXPY_INC || o.kind == ssn::M_AXPY_SET || o.kind == ssn::M_PROBE || o.kind == ssn::M_LOWPASS ||
+           o.kind == ssn::M_MATVEC_SET || o.kind == ssn::M_MATVEC_INC;
+  }
+  static long long batch_read_len(const ssn::BatchOp<T>& o) { return (o.kind == ssn::M_MATVEC_SET || o.kind == ssn::M_MATVEC_INC) ? o.cols : o.len; }
+  // Hazard between two operators of a stage, `a` the earlier one.  0: none; 1: only on elements that both touch at the SAME
+  // index of the same row (equal range origins, no previous-row read of what the other writes) - two element-wise operators
+  // may then share a launch, the same thread runs them in order (kb_elementwise_multi); 2: anything else.
+  static int batch_hazard(const ssn::BatchOp<T>& a, const ssn::BatchOp<T>& b) {
+    auto ov = [](long long x, long long xl, long long y, long long yl) { return x < y + yl && y < x + xl; };
+    int kind = 0;
+    auto pair = [&](long long x, long long xl, long long y, long long yl, bool prev) {
+      if (!ov(x, xl, y, yl)) return;
+      kind = std::max(kind, (x == y && !prev) ? 1 : 2);
+    };
+    if (batch_writes(a) && batch_writes(b)) pair(a.dst, a.len, b.dst, b.len, false);
+    if (batch_writes(a) && batch_reads(b)) pair(a.dst, a.len, b.src, batch_read_len(b), b.src_prev != 0);
+    if (batch_reads(a) && batch_writes(b)) pair(a.src, batch_read_len(a), b.dst, b.len, a.src_prev != 0);
+    if (kind == 1 && !(batch_elementwise(a) && batch_elementwise(b))) kind = 2;
+    return kind;
+  }
+
+  // Order of a time-batched stage: the builder hands its operators over in one valid order (stages.py `border`), in which
+  // independent operators of different kinds alternate (a scan, the sum that reads it, the next scan ...) and every one is
+  // a launch.  Here: resets and sums are cut at the range endpoints of the other operators (the reset of all accumulators
+  // of a network then lines up with each consumer), every operator takes the earliest dependency level its hazards allow,
+  // operators are sorted by level and kind, and neighbouring scans with equal coefficients over adjacent ranges are joined
+  // again.  run_batch then packs consecutive element-wise operators - also dependent ones, see batch_hazard - into launches.
+  void optimise_batch(std::vector<ssn::BatchOp<T>>& ops) {
+    if (ops.size() < 2 || getenv("SSN_NO_BATCH_REORDER")) return;
+    typedef ssn::BatchOp<T> Op;
+    std::vector<long long> cuts;
+    for (const Op& o : ops) {
+      if (batch_writes(o)) { cuts.push_back(o.dst); cuts.push_back(o.dst + o.len); }
+      if (batch_reads(o)) { cuts.push_back(o.src); cuts.push_back(o.src + batch_read_len(o)); }
+    }
+    std::sort(cuts.begin(), cuts.end());
+    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    std::vector<Op> cut;
+    for (const Op& o : ops) {
+      const bool axpy = o.kind == ssn::M_AXPY_INC || o.kind == ssn::M_AXPY_SET;
+      if (!(axpy || o.kind == ssn::M_FILL) || o.len <= 1) { cut.push_back(o); continue; }
+      std::vector<long long> offs{0, o.len};
+      for (long long base : {o.dst, axpy ? o.src : o.dst}) {
+        auto lo = std::upper_bound(cuts.begin(), cuts.end(), base), hi = std::lower_bound(cuts.begin(), cuts.end(), base + o.len);
+        for (auto it = lo; it < hi; ++it) offs.push_back(*it - base);
+      }
+      std::sort(offs.begin(), offs.end());
+      offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+      if (offs.size() > 32) { cut.push_back(o); continue; }
+      for (size_t q = 0; q + 1 < offs.size(); ++q) {
+        Op pc = o;
+        pc.dst = o.dst + offs[q]; pc.len = offs[q + 1] - offs[q];
+        if (axpy) pc.src = o.src + offs[q];
+        cut.push_back(pc);
+      }
+    }
+    const size_t n = cut.size();
+    std::vector<int> level(n, 0);
+    for (size_t j = 0; j < n; ++j)
+      for (size_t i = 0; i < j; ++i)
+        if (batch_hazard(cut[i], cut[j])) level[j] = std::max(level[j], level[i] + 1);
+    auto cls = [](const Op& o) { return batch_elementwise(o) ? 0 : o.kind == ssn::M_LOWPASS ? 1 : 2; };
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+      if (level[x] != level[y]) return level[x] < level[y];
+      if (cls(cut[x]) != cls(cut[y])) return cls(cut[x]) < cls(cut[y]);
+      return cut[x].kind == ssn::M_LOWPASS && cut[y].kind == ssn::M_LOWPASS && cut[x].dst < cut[y].dst;
+    });
+    std::vector<Op> out;
+    int last_level = -1;
+    for (size_t k : order) {
+      const Op& o = cut[k];
+      if (!out.empty() && level[k] == last_level && o.kind == ssn::M_LOWPASS && out.back().kind == ssn::M_LOWPASS && out.back().a == o.a && out.back().b == o.b &&
+          out.back().src_prev == o.src_prev && out.back().dst + out.back().len == o.dst && out.back().src + out.back().len == o.src) {
+        out.back().len += o.len;
+        continue;
+      }
+      out.push_back(o);
+      last_level = level[k];
+    }
+    if (getenv("SSN_DEBUG_PLAN")) {
+      fprintf(stderr, "[ssn] time-batched stage: %zu operators -> %zu\n", ops.size(), out.size());
+      for (const Op& o : out) fprintf(stderr, "[ssn]   batch op kind %d dst %lld src %lld len %lld cols %d prev %d\n", o.kind, (long long)o.dst, (long long)o.src, (long long)o.len, o.cols, o.src_prev);
+    }
+    ops.swap(out);
+  }
+
   hipError_t run_batch(std::vector<ssn::BatchOp<T>>& ops, int B, int64_t step0) {
-    auto elementwise = [](const ssn::BatchOp<T>& o) {
-      return o.kind == ssn::M_FILL || o.kind == ssn::M_AXPY_INC || o.kind == ssn::M_AXPY_SET || o.kind == ssn::M_TABLE || o.kind == ssn::M_PROBE;
-    };
-    // signal ranges (rows are handled identically by every operator, so column ranges decide): written / read
-    auto conflict = [&](const ssn::BatchOp<T>& a, const ssn::BatchOp<T>& b) {
-      auto ov = [](long long x, long long xl, long long y, long long yl) { return x < y + yl && y < x + xl; };
-      auto wr = [](const ssn::BatchOp<T>& o) { return o.kind != ssn::M_PROBE; };
-      auto rd = [](const ssn::BatchOp<T>& o) { return o.kind == ssn::M_AXPY_INC || o.kind == ssn::M_AXPY_SET || o.kind == ssn::M_PROBE; };
-      if (wr(a) && wr(b) && ov(a.dst, a.len, b.dst, b.len)) return true;
-      if (wr(a) && rd(b) && ov(a.dst, a.len, b.src, b.len)) return true;
-      if (rd(a) && wr(b) && ov(a.src, a.len, b.dst, b.len)) return true;
-      return false;
-    };
+    auto elementwise = [](const ssn::BatchOp<T>& o) { return batch_elementwise(o); };
     // Signal elements known to be ZERO in every row of this block: a table without an entry for any timestep of the block
     // (the init-SSP input of the path integrator after its first 50 ms, reference run_pathint.py:136), and what fills /
     // copies / products make of zeros.  A product whose whole input is zero is not multiplied out (PathIntegration config 2:
@@ -2306,7 +2390,7 @@ struct Sim final : ssn_sim {
     for (size_t i = 0; i < ops.size();) {
       ops[i].B = B; ops[i].step0 = step0;
       if (elementwise(ops[i]) && !(flags & 262144)) {
-        // consecutive element-wise operators without a data hazard between them share one launch
+        // consecutive element-wise operators share one launch unless a hazard between them crosses threads (batch_hazard)
         ssn::BatchOpList<T> l{};
         l.op[0] = ops[i];
         l.count = 1;
@@ -2314,14 +2398,14 @@ struct Sim final : ssn_sim {
         for (; j < ops.size() && l.count < ssn::MAX_BATCH_OPS && elementwise(ops[j]); ++j) {
           ops[j].B = B; ops[j].step0 = step0;
           bool clash = false;
-          for (int q = 0; q < l.count; ++q) clash = clash || conflict(l.op[q], ops[j]);
+          for (int q = 0; q < l.count; ++q) clash = clash || batch_hazard(l.op[q], ops[j]) == 2;
           if (clash) break;
           l.op[l.count++] = ops[j];
         }
         if (l.count > 1) {
           hipError_t e = ssn::launch_batch_elementwise<T>(stream, l);
           if (e != hipSuccess) return e;
-          for (int q = 0; q < l.count; ++q) note(l.op[q]);      // (members of one launch are independent of each other: any order)
+          for (int q = 0; q < l.count; ++q) note(l.op[q]);      // (list order = program order of every thread)
           i = j;
           continue;
         }

@@ -1458,53 +1458,63 @@ hipError_t launch_voja(hipStream_t s, T* E, const T* spk, const T* key, const T*
 // block_start + r).  A per-step GEMV becomes one GEMM (the matrix is read once per block), a Lowpass
 // becomes a scan along time.
 // ---------------------------------------------------------------------------------------------
+// element i of row t (the signals after step block_start + t) of one element-wise operator
+template <typename T>
+__device__ inline void kb_elementwise_at(const BatchOp<T>& o, long long t, long long i) {
+  T* drow = o.bsig + (size_t)(t + 1) * o.n_sig;
+  const T* srow = o.bsig + (size_t)(t + 1 - o.src_prev) * o.n_sig;
+  switch (o.kind) {
+    case M_FILL: drow[o.dst + i] = o.a; break;
+    case M_AXPY_INC: drow[o.dst + i] += o.a * srow[o.src + i]; break;
+    case M_AXPY_SET: drow[o.dst + i] = o.a * srow[o.src + i]; break;
+    case M_TABLE: {
+      const TableSlot* tb = (const TableSlot*)o.p0;
+      const long long rel = o.step0 + t - tb->first_step;
+      int row = -1;
+      if (rel >= 0 && rel < tb->n_idx) row = tb->idx[rel];
+      drow[o.dst + i] = (row >= 0 && row < tb->n_rows) ? ((const T*)tb->rows)[(size_t)row * tb->width + i] : T(0);
+      break;
+    }
+    case M_PROBE: {
+      const ProbeSlot* ps = (const ProbeSlot*)o.p0;
+      const long long s1 = o.step0 + t + 1;
+      if (s1 % ps->every == 0) {
+        const long long slot = s1 / ps->every - 1 - ps->base_slot;
+        if (slot >= 0 && slot < ps->capacity) ((T*)ps->data)[(size_t)slot * o.len + i] = drow[o.src + i];
+      }
+      break;
+    }
+    default: break;
+  }
+}
 template <typename T>
 __device__ inline void kb_elementwise_body(const BatchOp<T>& o) {
   const long long total = (long long)o.B * o.len;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const long long t = e / o.len, i = e - t * o.len;
-    T* drow = o.bsig + (size_t)(t + 1) * o.n_sig;
-    const T* srow = o.bsig + (size_t)(t + 1 - o.src_prev) * o.n_sig;
-    switch (o.kind) {
-      case M_FILL: drow[o.dst + i] = o.a; break;
-      case M_AXPY_INC: drow[o.dst + i] += o.a * srow[o.src + i]; break;
-      case M_AXPY_SET: drow[o.dst + i] = o.a * srow[o.src + i]; break;
-      case M_TABLE: {
-        const TableSlot* tb = (const TableSlot*)o.p0;
-        const long long rel = o.step0 + t - tb->first_step;
-        int row = -1;
-        if (rel >= 0 && rel < tb->n_idx) row = tb->idx[rel];
-        drow[o.dst + i] = (row >= 0 && row < tb->n_rows) ? ((const T*)tb->rows)[(size_t)row * tb->width + i] : T(0);
-        break;
-      }
-      case M_PROBE: {
-        const ProbeSlot* ps = (const ProbeSlot*)o.p0;
-        const long long s1 = o.step0 + t + 1;
-        if (s1 % ps->every == 0) {
-          const long long slot = s1 / ps->every - 1 - ps->base_slot;
-          if (slot >= 0 && slot < ps->capacity) ((T*)ps->data)[(size_t)slot * o.len + i] = drow[o.src + i];
-        }
-        break;
-      }
-      default: break;
-    }
+    const long long t = e / o.len;
+    kb_elementwise_at<T>(o, t, e - t * o.len);
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void kb_elementwise(BatchOp<T> o) { kb_elementwise_body<T>(o); }
-// several independent element-wise operators of a time-batched stage in one launch (a launch costs ~5 us)
+// Several element-wise operators of a time-batched stage in one launch (a launch costs ~5 us + the gap behind it).  Thread
+// (t, i) runs element i of row t of EVERY operator of the list, in list order: operators may depend on each other where
+// both touch a signal element at the same index i of the same row (ssn_host.hip run_batch checks: equal range origins, no
+// previous-row read in between) - a reset, the sums into it and the hand-off of the result are one launch.
 template <typename T>
 __global__ __launch_bounds__(256) void kb_elementwise_multi(BatchOpList<T> l) {
-  for (int q = 0; q < l.count; ++q) kb_elementwise_body<T>(l.op[q]);
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (long long t = blockIdx.y; t < l.op[0].B; t += gridDim.y)
+    for (int q = 0; q < l.count; ++q)
+      if (i < l.op[q].len) kb_elementwise_at<T>(l.op[q], t, i);
 }
 template <typename T>
 hipError_t launch_batch_elementwise(hipStream_t s, const BatchOpList<T>& l) {
-  long long total = 0;
-  for (int q = 0; q < l.count; ++q) total = std::max(total, (long long)l.op[q].B * l.op[q].len);
-  if (total <= 0) return hipSuccess;
-  const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL((kb_elementwise_multi<T>), dim3(grid), dim3(256), 0, s, l);
+  long long len = 0;
+  for (int q = 0; q < l.count; ++q) len = std::max(len, (long long)l.op[q].len);
+  if (len <= 0 || l.count <= 0 || l.op[0].B <= 0) return hipSuccess;
+  hipLaunchKernelGGL((kb_elementwise_multi<T>), dim3((unsigned)((len + 255) / 256), (unsigned)std::min(l.op[0].B, 16384)), dim3(256), 0, s, l);
   return hipGetLastError();
 }
 

@@ -269,7 +269,7 @@ template <typename T> hipError_t launch_round(hipStream_t, const RoundArgs<T>&, 
 constexpr int GLUE_CHUNK = 1024;
 constexpr int GLUE_ROWS = 256;
 
-constexpr int MAX_BATCH_OPS = 6;
+constexpr int MAX_BATCH_OPS = 24;
 template <typename T> struct BatchOpList { BatchOp<T> op[MAX_BATCH_OPS]; int count; };
 template <typename T> hipError_t launch_batch_elementwise(hipStream_t, const BatchOpList<T>&);   // independent element-wise ops, one launch
 
