@@ -122,11 +122,6 @@ __device__ inline f32x2 pk_fma_clamp01_trans_vvs(f32x2 x, f32x2 y, f32x2 z) {
   return r;
 }
 
-__device__ inline f32x2 pk_add_clamp01_m1(f32x2 x) {                // clamp(x - 1)
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, -1.0 op_sel_hi:[1,0] clamp" : "=v"(r) : "v"(x));
-  return r;
-}
 __device__ inline f32x2 pk_fma_clamp01_vs_negv(f32x2 x, f32x2 y, f32x2 z) {     // clamp(x * y - z), y a uniform constant pair
   f32x2 r;
   asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1] clamp" : "=v"(r) : "v"(x), "s"(y), "v"(z));
@@ -144,13 +139,13 @@ __device__ inline f32x2 pk_fma_clamp01_vs_negv(f32x2 x, f32x2 y, f32x2 z) {     
 // and w = 1 + K (R - dt) for a refractory one (R = refractory time left at the start of the next step, > dt; K a power of two
 // with K tau_ref <= 1: times in units of 1 / K so that they fit the clamp's [0, 1] without losing bits next to the 1).  The
 // input current arrives as J - 1 (the bias registers hold bias - 1).  With everything measured from the threshold, V - 1 and
-// J - 1 - the operands of the spike test and of the spike time - are what the update produces anyway: 16 packed operations
+// J - 1 - the operands of the spike test and of the spike time - are what the update produces anyway: 15 packed operations
 // per neuron pair against 19 with V and J (round 3's second cut; the words in HBM keep round 2's form, see the prologue).
 //
 //   W0 = clamp(w)                 1 - V0  (V0 = 0 while refractory)
-//   rt = clamp(w - 1)             K (R - dt) of a refractory neuron (< 1), else 0
-//   dl = clamp(K dt - rt)         K x integration time  (nengo: clip(dt - refractory, 0, dt))
-//   nmt = clamp(rt - K dt)        > 0 while the neuron stays refractory beyond the next step: its new word is 1 + nmt
+//   dl = clamp(c - a w)           integration time / dt  (nengo: clip(dt - refractory, 0, dt)): a = 1 / (K dt), c = a + 1 rounded
+//                                 up, so that every integrating neuron (w <= 1) gets exactly 1 and a refractory one 1 - (R - dt) / dt
+//   nmt = clamp(w - (1 + K dt))   > 0 while the neuron stays refractory beyond the next step: its new word is 1 + nmt
 //   em = dl * P(dl)               -expm1(-delta / tau_rc), P of degree 2: the interpolant of (1 - exp(-x)) / x through x = h,
 //                                 h / 2, 0.067 h with h = dt / tau_rc <= 1/20 - EXACT for a full step (delta = dt, all steps
 //                                 but the one in which a refractory period ends), within 2.3e-7 of the result for a partial
@@ -164,9 +159,9 @@ __device__ inline f32x2 pk_fma_clamp01_vs_negv(f32x2 x, f32x2 y, f32x2 z) {     
 //   Wn = clamp(spk * 2^100 - U)   1 - Vn: voltage of a silent neuron clamped at min_voltage 0, Vn = 0 for a spiking one
 //   w' = (Wn + nmt) + spk * nu    (spiking: Wn = 1, nmt = 0; silent: spk = 0 - exact selects, products with 0 / 1)
 // Requires dt / tau_rc <= 1/20 and tau_ref >= dt (checked by the host planner).
-struct LifConstV3 { float kdt, c1, c2, c3, ktau_ln2, ktau_ref, K; };
+struct LifConstV3 { float na, ca, m1, c1, c2, c3, ktau_ln2, ktau_ref, K; };
 
-// K and the coefficients of P in units of 1 / K (uniform; evaluated once per launch, in double)
+// K, the constants of dl / nmt and the coefficients of P for dl in units of dt (uniform; evaluated once per launch, in double)
 __device__ inline LifConstV3 lif_const_v3(double dt, double tau_rc, double tau_ref) {
   double K = 1.0;
   while (2.0 * K * tau_ref <= 1.0 && K < 1048576.0) K *= 2.0;
@@ -178,18 +173,20 @@ __device__ inline LifConstV3 lif_const_v3(double dt, double tau_rc, double tau_r
   // Newton form of the interpolant, expanded to monomials
   const double d01 = (f1 - f0) / (x1 - x0), d12 = (f2 - f1) / (x2 - x1), d012 = (d12 - d01) / (x2 - x0);
   const double q2 = d012, q1 = d01 - d012 * (x0 + x1), q0 = f0 - d01 * x0 + d012 * x0 * x1;
-  const double u = 1.0 / (K * tau_rc);                           // x = dl * u
   LifConstV3 c;
-  c.kdt = (float)(K * dt); c.c1 = (float)(q0 * u); c.c2 = (float)(q1 * u * u); c.c3 = (float)(q2 * u * u * u);
+  const float a = (float)(1.0 / (K * dt));
+  float ca = a + 1.0f;
+  if ((double)ca < (double)a + 1.0) ca = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, ca) + 1u);      // next float up: c - a >= 1 in exact arithmetic, a full step is 1, never 1 - ulp
+  c.na = -a; c.ca = ca; c.m1 = (float)(1.0 + K * dt);
+  c.c1 = (float)(q0 * h); c.c2 = (float)(q1 * h * h); c.c3 = (float)(q2 * h * h * h);       // x = dl * h
   c.ktau_ln2 = (float)(K * tau_rc * 0.6931471805599453); c.ktau_ref = (float)(K * tau_ref); c.K = (float)K;
   return c;
 }
 
 __device__ inline f32x2 lif_packed_step_f32x2(f32x2 Jm1, f32x2& w, const LifConstV3& c, f32x2 big) {
   const f32x2 W0 = pk_clamp01(w);
-  const f32x2 rt = pk_add_clamp01_m1(w);
-  const f32x2 dl = pk_rsub_clamp01(rt, (f32x2)(c.kdt));       // clamp(K dt - rt)
-  const f32x2 nmt = pk_sub_clamp01(rt, (f32x2)(c.kdt));       // clamp(rt - K dt)
+  const f32x2 dl = pk_fma_clamp01_vsv(w, (f32x2)(c.na), (f32x2)(c.ca));      // clamp(c - a w)
+  const f32x2 nmt = pk_sub_clamp01(w, (f32x2)(c.m1));                        // clamp(w - 1 - K dt)
   // (uniform coefficients as scalar-register pairs: one constant-bus operand per instruction, the first FMA's second
   //  coefficient lives in a vector register pair)
   f32x2 P;
@@ -294,7 +291,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
   //  them as their one constant-bus operand)
   auto uni = [](float v) { return bits_f(__builtin_amdgcn_readfirstlane(f_bits(v))); };
   LifConstV3 lc = lif_const_v3((double)np.dt, (double)np.tau_rc, (double)np.tau_ref);
-  lc.kdt = uni(lc.kdt); lc.c1 = uni(lc.c1); lc.c2 = uni(lc.c2); lc.c3 = uni(lc.c3); lc.ktau_ln2 = uni(lc.ktau_ln2); lc.ktau_ref = uni(lc.ktau_ref);
+  lc.na = uni(lc.na); lc.ca = uni(lc.ca); lc.m1 = uni(lc.m1); lc.c1 = uni(lc.c1); lc.c2 = uni(lc.c2); lc.c3 = uni(lc.c3); lc.ktau_ln2 = uni(lc.ktau_ln2); lc.ktau_ref = uni(lc.ktau_ref);
   lc.K = uni(lc.K);
   const f32x2 big = {0x1p100f, 0x1p100f};
 
