@@ -1502,19 +1502,49 @@ __global__ __launch_bounds__(256) void kb_elementwise(BatchOp<T> o) { kb_element
 // (t, i) runs element i of row t of EVERY operator of the list, in list order: operators may depend on each other where
 // both touch a signal element at the same index i of the same row (ssn_host.hip run_batch checks: equal range origins, no
 // previous-row read in between) - a reset, the sums into it and the hand-off of the result are one launch.
+constexpr int KB_MULTI_ROWS = 8;      // rows per workgroup of kb_elementwise_multi (independent iterations: eight accesses in flight per thread)
 template <typename T>
 __global__ __launch_bounds__(256) void kb_elementwise_multi(BatchOpList<T> l) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  for (long long t = blockIdx.y; t < l.op[0].B; t += gridDim.y)
-    for (int q = 0; q < l.count; ++q)
-      if (i < l.op[q].len) kb_elementwise_at<T>(l.op[q], t, i);
+  const int B = l.op[0].B;
+  for (long long t0 = (long long)blockIdx.y * KB_MULTI_ROWS; t0 < B; t0 += (long long)gridDim.y * KB_MULTI_ROWS)
+    for (int q = 0; q < l.count; ++q) {
+      if (i >= l.op[q].len) continue;
+      const BatchOp<T> o = l.op[q];
+      if (t0 + KB_MULTI_ROWS <= B && (o.kind == M_FILL || o.kind == M_AXPY_INC || o.kind == M_AXPY_SET)) {
+        // full chunk of a reset / sum: all loads first (the compiler cannot move a load across a store to the same buffer)
+        T* d = o.bsig + (size_t)(t0 + 1) * o.n_sig + o.dst + i;
+        const T* u = o.bsig + (size_t)(t0 + 1 - o.src_prev) * o.n_sig + o.src + i;
+        T x[KB_MULTI_ROWS], y[KB_MULTI_ROWS];
+        if (o.kind != M_FILL) {
+#pragma unroll
+          for (int r = 0; r < KB_MULTI_ROWS; ++r) x[r] = u[(size_t)r * o.n_sig];
+        }
+        if (o.kind == M_AXPY_INC) {
+#pragma unroll
+          for (int r = 0; r < KB_MULTI_ROWS; ++r) y[r] = d[(size_t)r * o.n_sig];
+        }
+#pragma unroll
+        for (int r = 0; r < KB_MULTI_ROWS; ++r) {
+          T v = o.a;
+          if (o.kind == M_AXPY_SET) v = o.a * x[r];
+          if (o.kind == M_AXPY_INC) { const T p = o.a * x[r]; v = y[r] + p; }
+          d[(size_t)r * o.n_sig] = v;
+        }
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < KB_MULTI_ROWS; ++r)
+        if (t0 + r < B) kb_elementwise_at<T>(o, t0 + r, i);
+    }
 }
 template <typename T>
 hipError_t launch_batch_elementwise(hipStream_t s, const BatchOpList<T>& l) {
   long long len = 0;
   for (int q = 0; q < l.count; ++q) len = std::max(len, (long long)l.op[q].len);
   if (len <= 0 || l.count <= 0 || l.op[0].B <= 0) return hipSuccess;
-  hipLaunchKernelGGL((kb_elementwise_multi<T>), dim3((unsigned)((len + 255) / 256), (unsigned)std::min(l.op[0].B, 16384)), dim3(256), 0, s, l);
+  const int gy = std::min((l.op[0].B + KB_MULTI_ROWS - 1) / KB_MULTI_ROWS, 16384);
+  hipLaunchKernelGGL((kb_elementwise_multi<T>), dim3((unsigned)((len + 255) / 256), (unsigned)gy), dim3(256), 0, s, l);
   return hipGetLastError();
 }
 
