@@ -644,19 +644,34 @@ struct Sim final : ssn_sim {
   // (LDS: 24 B per point of the longest transform, 32-bit index products) - the matrix is used then.
   static std::vector<int> smooth_radices(int L) {
     std::vector<int> primes;
-    int rest = L;
-    for (int p = 2; p <= 32 && rest > 1; ++p)
+    int rest = L, twos = 0;
+    while (rest % 2 == 0) { ++twos; rest /= 2; }
+    for (int p = 3; p <= 32 && rest > 1; ++p)
       while (rest % p == 0) { primes.push_back(p); rest /= p; }
     if (rest != 1) return {};
     std::sort(primes.begin(), primes.end());
     std::vector<int> rad;
-    for (size_t i = 0; i < primes.size();) {           // greedy merge of ascending primes while the product stays <= 16
+    // factors of two: radix 8 / 4 / 2 passes run as in-register FFT butterflies (dft_pass_small) - eights, with a remainder
+    // of 2^1 as one radix-2 pass and of 2^4 as two fours
+    while (twos >= 3 && twos != 4) { rad.push_back(8); twos -= 3; }
+    while (twos >= 2) { rad.push_back(4); twos -= 2; }
+    if (twos) rad.push_back(2);
+    for (size_t i = 0; i < primes.size();) {           // greedy merge of ascending odd primes while the product stays <= 16
       int r = primes[i++];
       while (i < primes.size() && r * primes[i] <= 16) r *= primes[i++];
       rad.push_back(r);
     }
     std::sort(rad.rbegin(), rad.rend());
     return rad;
+  }
+  // relative cost of the Stockham passes of a length: a generic radix-r pass does r complex multiply-adds per point out of
+  // LDS, an in-register one (2, 4, 8) reads and writes each point once
+  static double stockham_cost(int L) {
+    const std::vector<int> rad = smooth_radices(L);
+    if (rad.empty() || rad.size() > 12) return -1.0;
+    double c = 0.0;
+    for (int r : rad) c += (r == 8 || r == 4 || r == 2) ? 1.0 : 0.25 * r + 0.5;
+    return c * L;
   }
 
   int dft_table(int key, const std::vector<float2>& h, float2** out) {
@@ -776,28 +791,35 @@ struct Sim final : ssn_sim {
     std::vector<int> rad = smooth_radices(d);
     int L = d, M = 0;
     if (rad.empty()) {
-      for (M = 2 * d - 1; M <= 6400 && smooth_radices(M).empty(); ++M) {}
-      if (M > 6400) return SSN_OK;
-      // prefer 2^a 3^b 5^c lengths (few, small radices): the next such length within 12 % is taken instead
-      for (int c = M; c <= 6400 && c <= M + M / 8; ++c) {
-        int r = c;
-        for (int p : {2, 3, 5}) while (r % p == 0) r /= p;
-        if (r == 1) { M = c; break; }
+      // the cheapest smooth length in [2d - 1, 2 (2d - 1)] (a power of two where one fits: four radix-8 passes at 4096)
+      double best = -1.0;
+      for (int c = 2 * d - 1; c <= 6400 && c <= 2 * (2 * d - 1); ++c) {
+        const double cost = stockham_cost(c);
+        if (cost > 0.0 && (best < 0.0 || cost < best)) { best = cost; M = c; }
       }
+      if (best < 0.0) return SSN_OK;
       rad = smooth_radices(M);
       L = M;
     }
     if (rad.empty() || rad.size() > 12) return SSN_OK;
     float2* tw = nullptr;
     CHK(dft_table(L, twiddles(L), &tw));
-    if (M > 0) CHK(bluestein_tables(d, M, a));
+    bool small_only = M > 0 && !getenv("SSN_DFT_NO_INPLACE");          // every pass an in-register one: both transforms in place
+    for (int r : rad) small_only = small_only && (r == 8 || r == 4 || r == 2);
+    if (M > 0) CHK(bluestein_tables(d, M, a, small_only ? &rad : nullptr));
     a->src = (const float*)(sig + o.i[1]); a->dst = (float*)(sig + o.i[0]); a->tw = tw; a->N = d; a->kind = kind;
     a->set = (int)o.i[5]; a->nr = (int)rad.size();
     for (size_t i = 0; i < rad.size(); ++i) a->radix[i] = rad[i];
     return SSN_OK;
   }
 
-  int bluestein_tables(int d, int M, ssn::DftArgs* a) {
+  // position of frequency k after the in-place decimation-in-frequency passes with radices rad[0], rad[1], ...
+  static int dif_position(int k, int M, const std::vector<int>& rad) {
+    int pos = 0, len = M;
+    for (int r : rad) { len /= r; pos += (k % r) * len; k /= r; }
+    return pos;
+  }
+  int bluestein_tables(int d, int M, ssn::DftArgs* a, const std::vector<int>* inplace_radices = nullptr) {
     {
       // chirp w_n = exp(-i pi n^2 / d) with the phase reduced exactly (n^2 mod 2d), and the spectrum of its wrapped conjugate
       std::vector<float2> w((size_t)d);
@@ -825,8 +847,13 @@ struct Sim final : ssn_sim {
       }
       float2* dw = nullptr; float2* dfb = nullptr;
       CHK(dft_table(-d, w, &dw));
-      CHK(dft_table(-(1 << 20) - d - (M << 3), fb, &dfb));     // (the spectrum depends on M too: the two engines pick different lengths)
-      a->M = M; a->chirp = dw; a->fb = dfb;
+      if (inplace_radices) {                             // the in-place engine multiplies in digit-reversed order
+        std::vector<float2> fp((size_t)M);
+        for (int k = 0; k < M; ++k) fp[(size_t)dif_position(k, M, *inplace_radices)] = fb[(size_t)k];
+        fb.swap(fp);
+      }
+      CHK(dft_table(-(1 << 20) - d - (M << 3) - (inplace_radices ? 4 : 0), fb, &dfb));     // (the spectrum depends on M and on the engine)
+      a->M = M; a->chirp = dw; a->fb = dfb; a->inplace = inplace_radices ? 1 : 0;
     }
     return SSN_OK;
   }
@@ -1197,8 +1224,10 @@ struct Sim final : ssn_sim {
         case SSN_OP_MATVEC: {
           const Buf& w = bufs[o.i[4]];
           ssn::DftArgs da{};
-          // (a chirp-z transform of M >= 2048 points is three long FFTs on ONE workgroup - 40 us at d = 1801 - against
-          //  ~7 us for its 26 MB matrix spread over the chip: the matrix is used there unless flag 268435456 asks for the FFT)
+          // (a chirp-z transform of M >= 2048 points is two long FFTs on ONE workgroup: 16.5 us per launch at d = 1801 with the
+          //  in-register radix-8 passes of round 3 (38.5 us with generic radix-16 butterflies) against ~7 us for its 26 MB matrix
+          //  spread over the chip - measured on config 5: 266 us per timestep with the matrices, 288 - 295 with the FFT as a body
+          //  of the round grid; the matrix is used for such a length unless flag 268435456 asks for the FFT)
           if (o.i[6] && sizeof(T) == 4 && !(flags & 512) && plan_dft(o, &da) == SSN_OK && da.N &&
               (da.M < 2048 || (flags & 268435456))) {
             // the matrix is a real-DFT map of a circular-convolution network: mixed-radix FFT instead of a GEMV
@@ -1961,7 +1990,12 @@ struct Sim final : ssn_sim {
               continue;
             }
             case IT_DFT: {
-              const size_t lds = (size_t)(it.dft.M > 0 ? it.dft.M : it.dft.N) * (it.dft.N1 > 0 ? 4 * sizeof(float) : 3 * sizeof(float2));
+              size_t lds = (size_t)(it.dft.M > 0 ? it.dft.M : it.dft.N) * (it.dft.N1 > 0 ? 4 * sizeof(float) : 3 * sizeof(float2));
+              if (it.dft.inplace) {                         // in place: M + M / 8 points + M / (smallest radix) twiddles
+                int rmin = 8;
+                for (int q = 0; q < it.dft.nr; ++q) rmin = std::min(rmin, it.dft.radix[q]);
+                lds = (size_t)(it.dft.M + it.dft.M / 8 + it.dft.M / rmin) * sizeof(float2);
+              }
               if (lds <= 64 * 1024 && it.dft.N1 == 0) {      // (the four-step engine is launched on its own: see dft_body<ROUND>)
                 if (ao < 0) ao = (long long)put(&it.dft, sizeof it.dft);
                 entry(ssn::RK_DFT, 1, 1, lds, 0, (size_t)ao);

@@ -502,16 +502,114 @@ hipError_t launch_ensarray(hipStream_t s, const EnsArgs<T>& a) {
 // chirp-z form: X_k = w_k sum_n (x_n w_n) conj(w_{k-n}), w_n = exp(-i pi n^2 / N) - a circular convolution of smooth
 // length M >= 2N - 1, i.e. two Stockham transforms of length M around a pointwise product with a precomputed spectrum.
 // ---------------------------------------------------------------------------------------------
+// In-register butterflies of the Stockham passes with radix 2, 4 and 8 (round 3): one thread reads the r inputs of an output
+// group ONCE, runs the r-point FFT on registers (r log2 r real operations instead of the generic pass's r^2 complex
+// multiply-adds, each of which re-read its operand and a twiddle from LDS) and applies the group's r - 1 twiddles on the way
+// out.  A 4096-point transform - the Bluestein length of d = 1801 - is four radix-8 passes: 0.26 MB of LDS traffic and ~40 k
+// multiply-adds instead of 3 MB and 197 k with (16, 16, 16) generic butterflies.
+__device__ inline float2 cmulf(float2 a, float2 b) { return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x)); }
+__device__ inline float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ inline float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ inline float2 cmul_mi(float2 a) { return make_float2(a.y, -a.x); }                 // a * (-i)
+__device__ inline void fft4_fwd(float2& c0, float2& c1, float2& c2, float2& c3) {             // outputs in natural order
+  const float2 e0 = caddf(c0, c2), e1 = csubf(c0, c2), o0 = caddf(c1, c3), o1 = cmul_mi(csubf(c1, c3));
+  c0 = caddf(e0, o0); c2 = csubf(e0, o0); c1 = caddf(e1, o1); c3 = csubf(e1, o1);
+}
+// r-point forward FFT on registers, r = 2, 4, 8; outputs in natural order
+template <int R>
+__device__ inline void fft_small(float2* v) {
+  if constexpr (R == 2) {
+    const float2 a = caddf(v[0], v[1]), b = csubf(v[0], v[1]);
+    v[0] = a; v[1] = b;
+  } else if constexpr (R == 4) {
+    fft4_fwd(v[0], v[1], v[2], v[3]);
+  } else {
+    // radix 8: even outputs = FFT4 of the sums, odd outputs = FFT4 of the differences times W8^k
+    float2 a0 = caddf(v[0], v[4]), a1 = caddf(v[1], v[5]), a2 = caddf(v[2], v[6]), a3 = caddf(v[3], v[7]);
+    float2 b0 = csubf(v[0], v[4]), b1 = csubf(v[1], v[5]), b2 = csubf(v[2], v[6]), b3 = csubf(v[3], v[7]);
+    const float h = 0.70710678118654752f;
+    b1 = make_float2(h * (b1.x + b1.y), h * (b1.y - b1.x));            // * (1 - i) / sqrt 2
+    b2 = cmul_mi(b2);                                                  // * -i
+    b3 = make_float2(h * (b3.y - b3.x), -h * (b3.x + b3.y));           // * (-1 - i) / sqrt 2
+    fft4_fwd(a0, a1, a2, a3);
+    fft4_fwd(b0, b1, b2, b3);
+    v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3; v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
+  }
+}
+template <int R>
+__device__ inline void dft_pass_small(const float2* x, float2* y, const float2* tw, int L, unsigned us, unsigned fn, int tid, int nthr) {
+  const int groups = L / R;                       // output groups (q, p): inputs x[u + k L / R], outputs y[q + s (R p + j)]
+  for (int u = tid; u < groups; u += nthr) {
+    const unsigned q = (unsigned)u % us, p = (unsigned)u / us;
+    float2 v[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) v[k] = x[u + k * groups];
+    fft_small<R>(v);
+    float2* out = y + q + us * (R * p);
+    const unsigned t1 = p * fn;                   // twiddle of output j: W_L^(p j fn), p j fn < L
+    out[0] = v[0];
+#pragma unroll
+    for (int j = 1; j < R; ++j) out[us * j] = cmulf(v[j], tw[t1 * j]);
+  }
+}
+
+// One in-place pass over M points in LDS, span n (the sub-transforms' current length), radix R: the group (block, i) owns the
+// points z[block n + i + k n / R].  DIF: butterfly, then output j times W_n^(i j); DIT (the mirror): input k times W_n^(i k),
+// then the butterfly.  W_n^i = T[i M / n], T = the first M / 8 entries of the twiddle table, in LDS; the group's other powers
+// by multiplication (six complex products instead of six more table reads).  Points are stored at pad(a) = a + a / 8: in the
+// passes with short spans a wave's 64 groups would otherwise hit the same LDS banks eight at a time.
+__device__ inline unsigned dft_pad(unsigned a) { return a + (a >> 3); }
+template <int R, bool DIT>
+__device__ inline void dft_pass_inplace(float2* z, const float2* T, int M, int n, int tid, int nthr) {
+  const unsigned sub = (unsigned)n / R, f = (unsigned)(M / n);
+  for (int u = tid; u < M / R; u += nthr) {
+    const unsigned blk = (unsigned)u / sub, i = (unsigned)u - blk * sub;
+    const unsigned g = blk * (unsigned)n + i;
+    float2 v[R], w[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) v[k] = z[dft_pad(g + k * sub)];
+    w[1] = T[i * f];
+    if constexpr (R >= 4) { w[2] = cmulf(w[1], w[1]); w[3] = cmulf(w[2], w[1]); }
+    if constexpr (R == 8) { w[4] = cmulf(w[2], w[2]); w[5] = cmulf(w[4], w[1]); w[6] = cmulf(w[3], w[3]); w[7] = cmulf(w[4], w[3]); }
+    if constexpr (DIT) {
+#pragma unroll
+      for (int k = 1; k < R; ++k) v[k] = cmulf(v[k], w[k]);
+    }
+    fft_small<R>(v);
+    if constexpr (!DIT) {
+#pragma unroll
+      for (int k = 1; k < R; ++k) v[k] = cmulf(v[k], w[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) z[dft_pad(g + k * sub)] = v[k];
+  }
+}
+template <bool DIT>
+__device__ inline void dft_pass_inplace_r(int r, float2* z, const float2* T, int M, int n, int tid, int nthr) {
+  if (r == 8) dft_pass_inplace<8, DIT>(z, T, M, n, tid, nthr);
+  else if (r == 4) dft_pass_inplace<4, DIT>(z, T, M, n, tid, nthr);
+  else dft_pass_inplace<2, DIT>(z, T, M, n, tid, nthr);
+}
+
 // One mixed-radix Stockham pass structure over L points held in LDS (x -> result returned; y is scratch)
 __device__ inline float2* dft_stockham(float2* x, float2* y, const float2* tw, int L, const int* radix, int nr, int tid, int nthr) {
-  // Four output points per thread at a time: a radix-r butterfly is r dependent LDS round trips (value + twiddle), and
-  // one wave per SIMD has nothing else to hide them behind - four independent chains do (a 256-thread workgroup then
-  // runs a 1015-point transform as fast as 1024 threads with one point each).
+  // Generic radix: four output points per thread at a time: a radix-r butterfly is r dependent LDS round trips (value +
+  // twiddle), and one wave per SIMD has nothing else to hide them behind - four independent chains do (a 256-thread workgroup
+  // then runs a 1015-point transform as fast as 1024 threads with one point each).
   constexpr int U = 4;
   int n = L, s = 1;
   for (int st = 0; st < nr; ++st) {
     const unsigned r = (unsigned)radix[st], m = (unsigned)n / r, fn = (unsigned)(L / n), fr = (unsigned)L / r;
     const unsigned us = (unsigned)s, stride = us * m;
+    if (r == 8 || r == 4 || r == 2) {
+      if (r == 8) dft_pass_small<8>(x, y, tw, L, us, fn, tid, nthr);
+      else if (r == 4) dft_pass_small<4>(x, y, tw, L, us, fn, tid, nthr);
+      else dft_pass_small<2>(x, y, tw, L, us, fn, tid, nthr);
+      __syncthreads();
+      float2* t2 = x; x = y; y = t2;
+      n = (int)m; s *= (int)r;
+      continue;
+    }
     for (int o0 = tid; o0 < L; o0 += nthr * U) {
       // (all products below stay under 2^32: p j fn < L * 32, L <= 6400, see plan_dft)
       int idx[U], stp[U];
@@ -703,9 +801,74 @@ __device__ __forceinline__ void dft4_body(const DftArgs& a, unsigned char* ssn_d
 
 // (ROUND = true: the body inside k_round never runs the four-step engine - its MFMA accumulators would add 8 AGPRs to the
 //  round kernel and take every body of every round from 7 to 6 waves per SIMD; such transforms are launched on their own)
+// Bluestein's convolution with both transforms in place (DftArgs::inplace): one LDS array of M points.
+__device__ __forceinline__ void dft_bluestein_inplace(const DftArgs& a, unsigned char* ssn_dft_dyn) {
+  const int N = a.N, H = N / 2 + 1, M = a.M, tid = threadIdx.x, nthr = blockDim.x;
+  float2* z = reinterpret_cast<float2*>(ssn_dft_dyn);           // M + M / 8 points (padded), then the first M / (smallest radix) twiddles W_M^i
+  float2* T = z + M + M / 8;
+  int rmin = 8;
+  for (int st = 0; st < a.nr; ++st) rmin = min(rmin, a.radix[st]);
+  for (int i = tid; i < M / rmin; i += nthr) T[i] = a.tw[i];       // a pass of radix r reads W_M^e with e < M / r
+  for (int i = tid; i < M; i += nthr) {
+    float2 v = make_float2(0.0f, 0.0f);
+    if (i < N) {
+      if (a.kind != 5) v = make_float2(a.src[i], 0.0f);
+      else {
+        const int w = i < H ? i : N - i;
+        const float* p = a.src + 4 * w;
+        float re = p[0] - p[1], im = p[2] + p[3];
+        if (w == 0 || 2 * w == N) im = 0.0f;            // purely real bins (their imaginary slots carry no signal)
+        v = make_float2(re, i < H ? -im : im);          // conj Z (the inverse transform is conj . FFT . conj)
+      }
+      v = cmulf(v, a.chirp[i]);                         // a_n = x_n w_n
+    }
+    z[dft_pad(i)] = v;
+  }
+  __syncthreads();
+  int n = M;
+  for (int st = 0; st < a.nr; ++st) {                   // decimation in frequency: natural order in, digit-reversed out
+    dft_pass_inplace_r<false>(a.radix[st], z, T, M, n, tid, nthr);
+    __syncthreads();
+    n /= a.radix[st];
+  }
+  for (int i = tid; i < M; i += nthr) {                 // spectrum of the convolution (fb in the same digit-reversed order, 1 / M folded in); conj for the way back
+    const float2 v = cmulf(z[dft_pad(i)], a.fb[i]);
+    z[dft_pad(i)] = make_float2(v.x, -v.y);
+  }
+  __syncthreads();
+  n = 1;
+  for (int st = a.nr - 1; st >= 0; --st) {              // the mirrored decimation-in-time passes: digit-reversed in, natural out
+    n *= a.radix[st];
+    dft_pass_inplace_r<true>(a.radix[st], z, T, M, n, tid, nthr);
+    __syncthreads();
+  }
+  // X_k = w_k conj(c_k)
+  if (a.kind != 5) {
+    const bool conj = a.kind >= 3, slotB = a.kind == 2 || a.kind == 4;
+    for (int w = tid; w < H; w += nthr) {
+      const float2 zz = z[dft_pad(w)];
+      const float2 x = cmulf(make_float2(zz.x, -zz.y), a.chirp[w]);
+      const float re = x.x, im = conj ? -x.y : x.y;
+      float* d = a.dst + 4 * w;
+      const float v2 = slotB ? im : re, v3 = slotB ? re : im;
+      if (a.set) { d[0] = re; d[1] = im; d[2] = v2; d[3] = v3; }
+      else { d[0] += re; d[1] += im; d[2] += v2; d[3] += v3; }
+    }
+  } else {
+    const float inv = 1.0f / (float)N;
+    for (int i = tid; i < N; i += nthr) {
+      const float2 zz = z[dft_pad(i)];
+      const float2 x = cmulf(make_float2(zz.x, -zz.y), a.chirp[i]);
+      const float v = x.x * inv;
+      if (a.set) a.dst[i] = v; else a.dst[i] += v;
+    }
+  }
+}
+
 template <bool ROUND = false>
 __device__ __forceinline__ void dft_body(const DftArgs& a, unsigned char* ssn_dft_dyn) {
   if constexpr (!ROUND) { if (a.N1 > 0) { dft4_body(a, ssn_dft_dyn); return; } }
+  if (a.M > 0 && a.inplace) { dft_bluestein_inplace(a, ssn_dft_dyn); return; }
   const int N = a.N, H = N / 2 + 1, tid = threadIdx.x, nthr = blockDim.x;
   const int L = a.M > 0 ? a.M : N;              // length of the transforms actually run
   float2* x = reinterpret_cast<float2*>(ssn_dft_dyn);
@@ -776,6 +939,7 @@ hipError_t launch_dft(hipStream_t s, const DftBatch& b, int count) {
   int N = 0;
   for (int i = 0; i < count; ++i) N = std::max(N, b.a[i].M > 0 ? b.a[i].M : b.a[i].N);
   int threads = std::min(1024, std::max(64, ((N + 3) / 4 + 63) / 64 * 64));      // four output points per thread (dft_stockham)
+  if (b.a[0].inplace) threads = std::min(1024, std::max(64, (N / 8 + 63) / 64 * 64));                // one radix-8 group per thread and pass
   if (b.a[0].N1 > 0) {                // four-step: one wave per tile task of the larger step (at most 16 waves)
     const int tasks = ((b.a[0].N1 + 15) / 16) * ((b.a[0].N2 + 15) / 16);
     threads = std::min(1024, std::max(256, tasks * 64));

@@ -147,6 +147,11 @@ struct DftArgs {
   int M;                 // 0: N is transformed directly
   const float2* chirp;   // w_n = exp(-i pi n^2 / N), n = 0..N-1
   const float2* fb;      // FFT_M of the wrapped conjugate chirp, divided by M
+  // inplace = 1 (M a product of radices 2, 4, 8 only): the two transforms of the convolution run IN PLACE on one LDS array of
+  // M points - decimation in frequency forward (natural order in, digit-reversed out), `fb` stored in that digit-reversed
+  // order, the mirrored decimation-in-time passes back (digit-reversed in, natural out): no reordering pass, 8 B of LDS per
+  // point instead of 24, twiddles read from `tw` in global memory (dft_bluestein_inplace, ssn_kernels.hpp)
+  int inplace;
   // Four-step transform on the matrix cores (dft4_fft, ssn_kernels.hpp), used instead of the Stockham passes when N1 > 0:
   // L = N1 * N2 (L = M for Bluestein), two small dense DFTs as f32 MFMA products around a twiddle multiply.
   int N1, N2;
