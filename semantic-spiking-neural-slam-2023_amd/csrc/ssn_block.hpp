@@ -19,7 +19,7 @@
 //   filter_state[r] = a[r]*filter_state[r] + b[r]*total[r]; total[r] is staged for the post stage's row.
 // At the end the state words go back to HBM and the decoded values / filter states of the last step go to the
 // signal vector (what k_ens_finish does after every step of the per-step plan).
-// f32 state words hold -(R - dt) for a refractory neuron (see lif_packed_step_f32x2), f64 ones -R (k_ensarray's fast path).
+// f32 state words hold -(R - dt) for a refractory neuron (see lif_input_part), f64 ones -R (k_ensarray's fast path).
 #pragma once
 #include <type_traits>
 #include "ssn_launch.hpp"
@@ -82,29 +82,14 @@ __device__ inline f32x2 pk_clamp01(f32x2 x) {
   asm("v_pk_mul_f32 %0, %1, 1.0 op_sel_hi:[1,0] clamp" : "=v"(r) : "v"(x));
   return r;
 }
-__device__ inline f32x2 pk_neg_clamp01(f32x2 x) {                    // clamp(-x)
-  f32x2 r;
-  asm("v_pk_mul_f32 %0, %1, -1.0 op_sel_hi:[1,0] clamp" : "=v"(r) : "v"(x));
-  return r;
-}
 __device__ inline f32x2 pk_sub_clamp01(f32x2 x, f32x2 y) {          // clamp(x - y), y a uniform constant pair
   f32x2 r;
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(r) : "v"(x), "s"(y));
   return r;
 }
-__device__ inline f32x2 pk_rsub_clamp01(f32x2 x, f32x2 y) {         // clamp(y - x), y a uniform constant pair
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[1,0] neg_hi:[1,0] clamp" : "=v"(r) : "v"(x), "s"(y));
-  return r;
-}
 __device__ inline f32x2 pk_mul_clamp01(f32x2 x, f32x2 y) {
   f32x2 r;
   asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "s"(y));          // (y: a uniform constant pair)
-  return r;
-}
-__device__ inline f32x2 pk_mul_clamp01_vv(f32x2 x, f32x2 y) {
-  f32x2 r;
-  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "v"(y));
   return r;
 }
 __device__ inline f32x2 pk_fma_clamp01_vsv(f32x2 x, f32x2 y, f32x2 z) {          // clamp(x * y + z), y a uniform constant pair
@@ -183,16 +168,22 @@ __device__ inline LifConstV3 lif_const_v3(double dt, double tau_rc, double tau_r
   return c;
 }
 
-__device__ inline f32x2 lif_packed_step_f32x2(f32x2 Jm1, f32x2& w, const LifConstV3& c, f32x2 big) {
-  const f32x2 W0 = pk_clamp01(w);
+// The step in two halves: lif_state_part needs only the state word, lif_input_part is what needs J.  (Measured and dropped in
+// round 3: running the state half for all of a thread's neurons in the tail of the previous timestep, behind the workgroup
+// barrier or - the older wave of each SIMD - in front of it, 40 more registers: 2.90 - 2.92 ms per 1000 steps either way against
+// 2.91 - 2.92 with the halves back to back, same box; alternating s_setprio between the two waves of a SIMD: 3.21 ms.)
+__device__ inline void lif_state_part(f32x2 w, const LifConstV3& c, f32x2& W0, f32x2& em) {
+  W0 = pk_clamp01(w);
   const f32x2 dl = pk_fma_clamp01_vsv(w, (f32x2)(c.na), (f32x2)(c.ca));      // clamp(c - a w)
-  const f32x2 nmt = pk_sub_clamp01(w, (f32x2)(c.m1));                        // clamp(w - 1 - K dt)
   // (uniform coefficients as scalar-register pairs: one constant-bus operand per instruction, the first FMA's second
   //  coefficient lives in a vector register pair)
   f32x2 P;
   asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(dl), "v"((f32x2)(c.c3)), "s"((f32x2)(c.c2)));
   asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(dl), "v"(P), "s"((f32x2)(c.c1)));
-  const f32x2 em = dl * P;
+  em = dl * P;
+}
+__device__ inline f32x2 lif_input_part(f32x2 Jm1, f32x2& w, f32x2 W0, f32x2 em, const LifConstV3& c, f32x2 big) {
+  const f32x2 nmt = pk_sub_clamp01(w, (f32x2)(c.m1));                        // clamp(w - 1 - K dt)
   const f32x2 U = __builtin_elementwise_fma(Jm1 + W0, em, -W0);
   const f32x2 spk = pk_mul_clamp01(U, big);
   f32x2 rc;
@@ -327,7 +318,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
     }
     b[g] = ld(bias + ii);
     s[g] = ld(Sp + ii);
-    if constexpr (F32) {                                   // the time loop's forms: J - 1, distance to the threshold (lif_packed_step_f32x2)
+    if constexpr (F32) {                                   // the time loop's forms: J - 1, distance to the threshold (lif_state_part / lif_input_part)
       b[g] = b[g] - 1.0f;
       s[g] = (f32x2){lif_word_in(s[g].x, lc.K), lif_word_in(s[g].y, lc.K)};
     }
@@ -507,7 +498,9 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
           const int g = g0 + u;
           if (g >= NG) continue;
           if constexpr (F32) {
-            spk[u] = lif_packed_step_f32x2(J[u], s[g], lc, big);
+            f32x2 W0, em;
+            lif_state_part(s[g], lc, W0, em);
+            spk[u] = lif_input_part(J[u], s[g], W0, em, lc, big);
           } else {
             // packed state word -> nengo's LIF step, operation for operation k_ensarray's fast path
             const T sw = s[g];

@@ -2100,6 +2100,30 @@ struct Sim final : ssn_sim {
           cur = prev;
         }
       }
+      if (getenv("SSN_DEBUG_DEPS")) {
+        // what every instance of the steady-state rounds waits for in the round before it (diagnostic for in-launch dependencies)
+        auto name = [&](const Inst& in) {
+          const Unit& u = units[(size_t)in.unit];
+          char buf[160];
+          if (u.mop >= 0) snprintf(buf, sizeof buf, "micro k%d len %lld dst %lld", mops[(size_t)u.mop].kind, (long long)mops[(size_t)u.mop].len, (long long)mops[(size_t)u.mop].dst);
+          else snprintf(buf, sizeof buf, "item %d type %d rows %d cols %d n %d", u.item, items[(size_t)u.item].type, items[(size_t)u.item].rows, items[(size_t)u.item].cols, items[(size_t)u.item].n);
+          return std::string(buf);
+        };
+        const int r_lo = atoi(getenv("SSN_DEBUG_DEPS")), r_hi = r_lo + 4;
+        for (size_t i = 0; i < all.size(); ++i) {
+          if (all[i].round < r_lo || all[i].round >= r_hi) continue;
+          fprintf(stderr, "[ssn] deps: round %d step %d %s\n", all[i].round, all[i].sub, name(all[i]).c_str());
+          for (size_t v = 0; v < all.size(); ++v) {
+            if (v == i || all[v].round != all[i].round - 1) continue;
+            const std::vector<Rng>& x = acc_nc[(size_t)all[i].unit];
+            const std::vector<Rng>& y = acc_nc[(size_t)all[v].unit];
+            bool raw = false, war = false, waw = false;
+            for (const Rng& p : x) for (const Rng& q : y)
+              if (p.space == q.space && p.lo < q.hi && q.lo < p.hi) { if (!p.w && q.w) raw = true; if (p.w && !q.w) war = true; if (p.w && q.w) waw = true; }
+            if ((raw || war || waw) && (v < i)) fprintf(stderr, "[ssn] deps:     <- step %d %s%s%s%s\n", all[v].sub, name(all[v]).c_str(), raw ? " RAW" : "", war ? " WAR" : "", waw ? " WAW" : "");
+          }
+        }
+      }
       if (!(flags & 16777216)) balance_rounds(all, nr, per, [&](int a, int b) { return hazard(acc_nc[(size_t)a], acc_nc[(size_t)b]); },
                                               [&](int u, double* us, double* lat, int* blocks) { unit_cost(units[(size_t)u].mop, units[(size_t)u].item, us, lat, blocks); });
       emit(all, nr, graph_list, chains_all);
