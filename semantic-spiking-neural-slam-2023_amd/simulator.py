@@ -300,6 +300,7 @@ class Simulator:
                                                    idx.ctypes.data, idx.size, first_step))
 
     PIPELINE_CHUNK = 2048
+    PIPELINE_CHUNK_CHEAP = 8192      # chunk length once the input nodes have proved cheap to tabulate (vectorised .table twins)
 
     def _tabulate_chunk(self, first, n):
         """(first, n, [(rows, idx) per table]) for the n timesteps after 0-based step ``first``."""
@@ -333,7 +334,14 @@ class Simulator:
                 self._check(self._lib.ssn_reserve_probes(self._h, steps))
                 self._fetched = {}
                 self._reserved_until = self.n_steps + steps
+                import time as _time
+                t_tab = _time.perf_counter()
                 pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_CHUNK, steps))
+                t_tab = (_time.perf_counter() - t_tab) / max(1, pipelined[1])
+                # Every chunk boundary costs ~0.7 ms of idle device (the run returns, tables are replaced, helper threads
+                # start): when evaluating the nodes takes well under the device's ~3 us per timestep the later chunks are
+                # four times as long; slow node closures keep the short chunks, whose tabulation hides behind the device run
+                self._chunk_len = self.PIPELINE_CHUNK_CHEAP if t_tab < 0.5e-6 else self.PIPELINE_CHUNK
                 if collect:
                     # the samples of chunk k are fetched (float64, straight into one array per probe) on a helper thread
                     # while the device steps chunk k + 1: the library downloads on its own stream
@@ -362,6 +370,7 @@ class Simulator:
         self._prepared_until = max(self._prepared_until, self.n_steps)
 
     _collector = None
+    _chunk_len = PIPELINE_CHUNK
 
     def _step_loop(self, steps, profile, pipelined, buf_probes):
         done = 0
@@ -388,7 +397,7 @@ class Simulator:
                 if done + chunk < steps:
                     import threading
                     box = {}
-                    n_next = min(self.PIPELINE_CHUNK, steps - done - chunk)
+                    n_next = min(self._chunk_len, steps - done - chunk)
                     def tab(box=box, nxt=nxt, n_next=n_next):
                         try:
                             box.update(r=self._tabulate_chunk(nxt, n_next))
@@ -414,7 +423,7 @@ class Simulator:
                     raise fe.SimulationError("evaluating the input nodes for the next chunk failed") from box.get("e")
                 pipelined = box["r"]
                 if self.n_steps != pipelined[0]:          # a weight-probe boundary cut the chunk short: re-tabulate from here
-                    pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_CHUNK, steps - done))
+                    pipelined = self._tabulate_chunk(self.n_steps, min(self._chunk_len, steps - done))
         if collector is not None:
             collector.join()
         self._collector = None
