@@ -84,6 +84,9 @@ def parse():
                          "per timestep (an ensemble over several workgroups), or whichever is faster at this shard size (timed on "
                          "one block before the timed region, the slowest rank's time decides)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="one rank, but through the N > 1 code: a process group of world size 1 on --dist-backend, the sharded runner, "
+                         "its collectives (what a one-GPU box can exercise of the RCCL path)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path with several ranks sharing one GPU (RCCL needs one GPU per rank)")
     return ap.parse_args()
@@ -231,14 +234,18 @@ def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    sharded = world > 1 or args.rehearse_dist
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if sharded:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -330,15 +337,17 @@ def slam_main(args):
     block = args.block or 250
     n_total = (args.steps + args.warmup) * block
 
+    sharded = world > 1 or args.rehearse_dist
+
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
     out = {"metric": METRIC, "unit": "sim-sec/wall-sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "value_is": "device-resident stepping rate: inputs tabulated and uploaded before the timed region, probe samples left in HBM"}
-    if world == 1:
+    if not sharded:
         from oracle import OracleSimulator
         leg = slam_leg(args, H, build, Simulator, OracleSimulator, dt, timed_steps=args.steps * block, warm_steps=args.warmup * block,
                        device=local_rank)
@@ -413,13 +422,15 @@ def pathint_main(args):
     K = (space.ssp_dim + 1) // 2
     N = K * args.pi_n_neurons
 
+    sharded = world > 1 or args.rehearse_dist
+
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
     t0 = time.time()
-    if world == 1:
+    if not sharded:
         model = build(pm.model, dt=dt, n_eval_points=args.eval_points)
         sim = Simulator(None, model=model, dtype=args.dtype, device=local_rank, block_steps=args.sim_block)
         runner = None
@@ -466,7 +477,7 @@ def pathint_main(args):
         runner.flush()                       # rank 0: the read-out of the last block is part of the job
     barrier()
     wall = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         w = torch.tensor([wall], device="cuda" if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
@@ -482,15 +493,15 @@ def pathint_main(args):
         "config": {"workload": f"PathIntegration 2-D ssp_dim={space.ssp_dim} pi_n_neurons={args.pi_n_neurons}/VCO "
                                f"({K} VCOs, {N} LIF neurons), configs[1]",
                    "timesteps_per_step": args.block, "dt": dt, "eval_points_per_vco": args.eval_points,
-                   "parallelism": "1 GPU" if world == 1 else f"VCO-sharded x{world}, all-gather per {args.block} steps ({args.dist_backend})",
+                   "parallelism": "1 GPU" if not sharded else f"VCO-sharded x{world}, all-gather per {args.block} steps ({args.dist_backend})",
                    "build_seconds": round(build_s, 1)},
     }
 
-    if world > 1:
+    if sharded:
         out["config"]["shard_plan"] = {"chosen": "streaming launch per timestep (flag 128)" if runner._flags == 128 else "planner default (k_ens_block where a VCO fits a workgroup)",
                                        "vcos_per_rank": runner.hi - runner.lo,
                                        "seconds_per_block": {str(k): round(v, 6) for k, v in (plan_seconds or {}).items()}}
-    if rank == 0 and world == 1:
+    if rank == 0 and not sharded:
         # ---- roofline: HIP events around every launch of the dominant kernel in the timed region ------
         c = sim.counters()
         n_timed = c["dominant_launches"] - c_warm["dominant_launches"]
@@ -612,7 +623,7 @@ def pathint_main(args):
                 out["slam"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -167,7 +167,7 @@ class ShardedPathIntegration:
             t0 = time.perf_counter()
             sim.run_steps(steps, collect=False)
             wall = time.perf_counter() - t0
-            if self.world > 1 and self.dist.is_initialized():
+            if self._grouped():
                 import torch
                 t = torch.tensor([wall], dtype=torch.float64)
                 if self.dist.get_backend() == "nccl":
@@ -205,13 +205,20 @@ class ShardedPathIntegration:
         self.readout.prepare(n)
         self.readout.run_steps(n)
 
+    def _grouped(self):
+        """True when this runner's collectives are real: a process group of the runner's world size (also of size one -
+        `bench.py --rehearse-dist` takes one rank through the RCCL calls on a one-GPU box)."""
+        if not self.dist.is_initialized():
+            return False
+        return self.world > 1 or self.dist.get_world_size() == 1
+
     def _device_exchange(self):
         """True when the block exchange can stay in HBM: RCCL backend and the HIP simulator (not the test double)."""
         if not hasattr(self.sim, "read_probe_device") or self.gather_device is not None or self.device_exchange is False:
             return False
         if self.device_exchange:
             return True
-        return self.world > 1 and self.dist.is_initialized() and self.dist.get_backend() == "nccl"
+        return self._grouped() and self.dist.get_backend() == "nccl"
 
     def _stage_send(self, n):
         """Local half of the device exchange (no collective): this rank's last n oscillator samples, padded to the
@@ -254,7 +261,7 @@ class ShardedPathIntegration:
             send = self._stage_send(n)
         except Exception as e:                         # noqa: BLE001 - agreed on collectively below, then re-raised
             err = e
-        collective = self.world > 1 and self.dist.is_initialized()
+        collective = self._grouped()
         failed = err is not None
         if collective:
             flag = torch.tensor([1.0 if failed else 0.0], device=torch.device("cuda", torch.cuda.current_device()))
@@ -455,7 +462,7 @@ class ShardedSLAM:
     def _exchange(self):
         if self.world == 1:
             return                                   # a single rank's sums are complete
-        dev = self.world > 1 and self.dist.is_initialized() and self.dist.get_backend() == "nccl" and hasattr(self.sim, "exchange_pack")
+        dev = self._grouped() and self.dist.get_backend() == "nccl" and hasattr(self.sim, "exchange_pack")
         if not dev:
             self.sim.exchange_host(self._allreduce_host)
             return
@@ -471,6 +478,12 @@ class ShardedSLAM:
     # -- running ----------------------------------------------------------------------------------------------------
     def prepare(self, n_steps):
         self.sim.prepare(n_steps)
+
+    def _grouped(self):
+        """True when this runner's collectives are real (a process group of the runner's world size - also of size one)."""
+        if not self.dist.is_initialized():
+            return False
+        return self.world > 1 or self.dist.get_world_size() == 1
 
     def _stream_ordered(self):
         """True when a run can be enqueued without the host in the loop: the HIP simulator, and either a single rank or the
@@ -501,7 +514,7 @@ class ShardedSLAM:
         """Every rank learns whether any rank failed before the collectives of a run start (a rank that raised would leave its
         peers waiting in the first all-reduce until the RCCL watchdog fires)."""
         failed = err is not None
-        if self.world > 1 and self.dist.is_initialized():
+        if self._grouped():
             import torch
             flag = torch.tensor([1.0 if failed else 0.0])
             if self.dist.get_backend() == "nccl":

@@ -156,3 +156,27 @@ def test_bench_slam_workload_one_rank_and_two():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and "neuron-sharded x2" in d["config"]["parallelism"] and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_rehearse_dist_takes_one_rank_through_the_rccl_path():
+    """`--rehearse-dist`: a process group of ONE rank on the nccl backend (RCCL), the sharded runners and their collectives -
+    what a one-GPU box can exercise of the code the driver's N > 1 runs take (init, device-resident all-gather, choose_plan's
+    all-reduce, the stream-ordered SLAM all-reduce)."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-dist", "--dist-backend", "nccl", "--ssp-dim", "55",
+            "--pi-n-neurons", "500", "--steps", "2", "--warmup", "1", "--block", "256", "--cpu-steps", "0", "--slam-steps", "0",
+            "--eval-points", "500"]
+    p = subprocess.run(base, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "VCO-sharded x1" in d["config"]["parallelism"] and "nccl" in d["config"]["parallelism"]
+    assert set(d["config"]["shard_plan"]["seconds_per_block"]) == {"0", "128"} and d["value"] > 0
+    p = subprocess.run(base + ["--workload", "slam", "--mem-n-neurons", "300", "--circonv-n-neurons", "20", "--block", "64"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "neuron-sharded x1" in d["config"]["parallelism"] and "one stream" in d["config"]["parallelism"] and d["value"] > 0
