@@ -228,6 +228,12 @@ def slam_roofline(us_per_timestep, n_neurons):
                     "spiking / active neurons; achieved = measured bytes / time of a timestep in this run"}
 
 
+def emit(args, out):
+    """The bench line: stdout (the descriptor saved by init_dist where a rank's stdout was redirected)."""
+    f = getattr(args, "_json_out", None) or sys.stdout
+    print(json.dumps(out), file=f, flush=True)
+
+
 def init_dist(args):
     import torch
     import torch.distributed as dist
@@ -236,6 +242,11 @@ def init_dist(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     sharded = world > 1 or args.rehearse_dist
     if sharded:
+        # RCCL prints a version banner on stdout when its first communicator comes up: a rank's stdout is pointed at stderr for the
+        # whole run and the ONE JSON line goes to the saved descriptor (emit)
+        sys.stdout.flush()
+        args._json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
@@ -359,7 +370,7 @@ def slam_main(args):
         for key in ("cpu_baseline", "parity", "gpu_over_cpu"):
             if key in leg:
                 out[key] = leg[key]
-        print(json.dumps(out))
+        emit(args, out)
         return
     t0 = time.time()
     sm = H.make_config3_model(seed=args.seed, T=max(20.0, (n_total + 10) * dt), dt=dt, pi_n_neurons=args.pi_n_neurons,
@@ -396,7 +407,7 @@ def slam_main(args):
                us_per_timestep=round(1e6 * wall / (args.steps * block), 2), launches_per_timestep=r.sim.counters()["launches_per_step"])
     r.close()
     if rank == 0:
-        print(json.dumps(out))
+        emit(args, out)
     dist.destroy_process_group()
 
 
@@ -622,7 +633,7 @@ def pathint_main(args):
             except Exception as e:                     # the headline line must not depend on the secondary leg
                 out["slam"] = {"error": repr(e)}
     if rank == 0:
-        print(json.dumps(out))
+        emit(args, out)
     if sharded:
         dist.destroy_process_group()
 

@@ -168,6 +168,7 @@ def test_bench_rehearse_dist_takes_one_rank_through_the_rccl_path():
             "--eval-points", "500"]
     p = subprocess.run(base, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
+    assert len([ln for ln in p.stdout.splitlines() if ln.strip()]) == 1, p.stdout      # (RCCL's version banner goes to stderr)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
