@@ -1634,7 +1634,7 @@ struct Sim final : ssn_sim {
         *us = (double)it.rows * it.ld * sizeof(T) / per_us;
         if ((size_t)it.cols * sizeof(T) <= 48 * 1024) *blocks = it.rows <= 4096 ? (it.rows + 3) / 4 : (it.rows + 15) / 16;
         break;
-      case IT_PES: *us = 2.0 * it.rows * it.ld * sizeof(T) / per_us; *blocks = ((it.cols + 1023) / 1024) * it.rows; break;
+      case IT_PES: *us = 2.0 * it.rows * it.ld * sizeof(T) / per_us; *blocks = ((it.cols + 1023) / 1024) * ((it.rows + ssn::PES_ROWS - 1) / ssn::PES_ROWS); break;
       case IT_VOJA: *us = 0.2 * it.rows * it.ld * sizeof(T) / per_us; break;
       case IT_SPMV: *us = 0.1 * (double)it.cols * it.ld * sizeof(T) / per_us; break;
       case IT_NEURONS: *us = (double)it.n * 5.0 * sizeof(T) / per_us; break;
@@ -2006,7 +2006,7 @@ struct Sim final : ssn_sim {
             case IT_PES: {
               ssn::PesArgs<T> a{it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar};
               if (ao < 0) ao = (long long)put(&a, sizeof a);
-              entry(ssn::RK_PES, (it.cols + 1023) / 1024, it.rows, 64, 0, (size_t)ao);
+              entry(ssn::RK_PES, (it.cols + 1023) / 1024, (it.rows + ssn::PES_ROWS - 1) / ssn::PES_ROWS, 64, 0, (size_t)ao);
               continue;
             }
             case IT_VOJA: {

@@ -1558,19 +1558,27 @@ hipError_t launch_neurons(hipStream_t s, const NeuronsBatch<T>& b, int count) {
 
 // ---------------------------------------------------------------------------------------------
 // k_pes: W[r][c] += kappa * err[r] * act[c]   (fused delta + increment).
-// One workgroup per (row, 1024-column tile): act is read once per tile, W streamed once.
+// One workgroup per (PES_ROWS rows, 1024-column tile).  With neuron-major weights (the learned decoders of the associative
+// memory: a row per neuron, `err` = the filtered activities) ~1 % of the rows have a nonzero factor: a workgroup reads the
+// factors of its eight rows at once and updates the rows that have one - 1 270 workgroups, all resident at once, instead of
+// a sweep of 10 150 that each load one factor and leave (round 3; SLAM config 3).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void pes_body(const PesArgs<T>& a, const int bx, const int by) {
-  const int r = by;
-  const T e = a.kappa * a.err[r];
-  if (e == T(0)) return;
-  T* wr = a.Wm + (size_t)r * a.ld;
+  const int r0 = by * PES_ROWS;
+  T e[PES_ROWS];
+#pragma unroll
+  for (int q = 0; q < PES_ROWS; ++q) e[q] = r0 + q < a.rows ? a.kappa * a.err[r0 + q] : T(0);
   const int c0 = bx * 1024;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = c0 + j * 256 + threadIdx.x;
-    if (c < a.cols) wr[c] += e * a.act[c];
+  for (int q = 0; q < PES_ROWS; ++q) {
+    if (e[q] == T(0)) continue;
+    T* wr = a.Wm + (size_t)(r0 + q) * a.ld;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + j * 256 + threadIdx.x;
+      if (c < a.cols) wr[c] += e[q] * a.act[c];
+    }
   }
 }
 template <typename T>
@@ -1581,7 +1589,7 @@ __global__ __launch_bounds__(256) void k_pes(T* __restrict__ Wm, const T* __rest
 
 template <typename T>
 hipError_t launch_pes(hipStream_t s, T* Wm, const T* err, const T* act, int rows, int cols, int ld, T kappa) {
-  hipLaunchKernelGGL((k_pes<T>), dim3((cols + 1023) / 1024, rows), dim3(256), 0, s, Wm, err, act, rows, cols, ld, kappa);
+  hipLaunchKernelGGL((k_pes<T>), dim3((cols + 1023) / 1024, (rows + PES_ROWS - 1) / PES_ROWS), dim3(256), 0, s, Wm, err, act, rows, cols, ld, kappa);
   return hipGetLastError();
 }
 

@@ -235,6 +235,7 @@ struct BatchOp {
 // names the operator body that runs them.  The arguments of every body live in device memory (they do not change
 // from timestep to timestep; the step counter is read from StepCtx).
 // ---------------------------------------------------------------------------------------------
+constexpr int PES_ROWS = 8;      // rows per workgroup of the PES update (pes_body)
 template <typename T> struct PesArgs { T* Wm; const T* err; const T* act; int rows, cols, ld; T kappa; };
 template <typename T> struct VojaArgs { T* E; const T* spk; const T* key; const T* learn; const T* scale; int rows, cols, ld; T lr_dt; };
 
