@@ -1930,6 +1930,11 @@ struct Sim final : ssn_sim {
             const std::vector<int>& members = chains[(size_t)in->chain];
             if (&insts[(size_t)members[0]] != in) continue;                 // emitted with its chain's first member
             const int ofs = (int)chain_tab.size();
+            if (getenv("SSN_DEBUG_PLAN")) {
+              fprintf(stderr, "[ssn]   chain in round %d (len %lld):", r, (long long)op.len);
+              for (int mi : members) fprintf(stderr, " k%d", mops[(size_t)units[(size_t)insts[(size_t)mi].unit].mop].kind);
+              fprintf(stderr, "\n");
+            }
             chain_tab.push_back((int)members.size());
             for (int mi : members) { chain_tab.push_back(units[(size_t)insts[(size_t)mi].unit].mop); chain_tab.push_back(insts[(size_t)mi].sub); }
             const int blocks = (int)std::max<long long>(1, (op.len + ssn::GLUE_ROWS - 1) / ssn::GLUE_ROWS);
