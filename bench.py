@@ -12,7 +12,8 @@ path, seed 0.  ``--workload slam`` (configs[2]): ``SLAMNetwork`` at the same siz
 
 One "step" = one block of ``--block`` simulator timesteps (default 1000 = one simulated second; 250 for the SLAM
 workload) with all inputs already resident in HBM.  The timed region is exactly K blocks between barrier +
-torch.cuda.synchronize() pairs; the max over ranks is taken; rank 0 prints one JSON line.
+torch.cuda.synchronize() pairs - enqueued by one run_steps call on one GPU, as sim.run(T) enqueues them (no host
+synchronisation between blocks); the max over ranks is taken; rank 0 prints one JSON line.
 
 ``--gpus N`` with N > 1 and no WORLD_SIZE in the environment: this process starts
 ``python -m torch.distributed.run --nproc-per-node N bench.py ...`` itself - before anything touches the GPU - and relays
@@ -463,27 +464,28 @@ def pathint_main(args):
         sim, model = runner.sim, runner.model
     build_s = time.time() - t0
 
-    def run_block():
-        if runner is None:
-            # profile=True: a HIP event pair on the simulator's own stream around every launch of the dominant kernel
-            # (two event records per block; the roofline figures below are these launches of the timed region itself)
-            sim.run_steps(args.block, profile=True, collect=False)
-        else:
-            runner.run_block()
-
     if runner is None:
         sim.prepare(n_total)
     else:
         runner.prepare(n_total)
-    for _ in range(args.warmup):
-        run_block()
+    def run_blocks(k):
+        if runner is None:
+            # one call enqueues all k blocks (as sim.run(T) does); a call per block would put a host synchronisation and a cold
+            # launch queue behind every block: 3.09 vs 3.03 ms per block (tools/experiments/sync_per_block.py).  profile=True: a
+            # HIP event pair on the simulator's own stream around every launch of the dominant kernel
+            if k > 0:
+                sim.run_steps(k * args.block, profile=True, collect=False)
+        else:
+            for _ in range(k):
+                runner.run_block()
+
+    run_blocks(args.warmup)
     if runner is not None:
         runner.flush()
     barrier()
     c_warm = sim.counters() if runner is None else None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_block()
+    run_blocks(args.steps)
     if runner is not None:
         runner.flush()                       # rank 0: the read-out of the last block is part of the job
     barrier()
