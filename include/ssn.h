@@ -190,7 +190,7 @@ typedef struct ssn_counters {
   int32_t fft_transforms;           /* DFT-structured matvecs of a timestep that run as k_dft (FFT) instead of the matrix */
   int32_t fft_bluestein;            /* ... of which through Bluestein's convolution (a prime factor > 32)           */
   int32_t block_members;            /* member workgroups per ensemble of the whole-block kernel (flag 1073741824; 1 = not split, 0 = no block kernel) */
-  int32_t reserved;
+  int32_t batch_products_skipped; /* time-batched products not multiplied out because their whole input was zero over the block (cumulative) */
 } ssn_counters;
 
 /* Per-kernel device time of the generic (one launch per operator) plan, collected by ssn_run_steps(profile = 2):

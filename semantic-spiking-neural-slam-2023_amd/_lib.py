@@ -54,7 +54,7 @@ class Counters(C.Structure):
                 ("dominant_units_per_launch", C.c_int64), ("last_run_ms", C.c_double), ("device_bytes", C.c_int64),
                 ("block_tpb", C.c_int32), ("block_npt", C.c_int32), ("block_enc_lds", C.c_int32),
                 ("block_threads", C.c_int32), ("fft_transforms", C.c_int32), ("fft_bluestein", C.c_int32),
-                ("block_members", C.c_int32), ("reserved", C.c_int32)]
+                ("block_members", C.c_int32), ("batch_products_skipped", C.c_int32)]
 
 
 class KernelTime(C.Structure):

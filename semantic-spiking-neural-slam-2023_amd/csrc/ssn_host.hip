@@ -165,6 +165,7 @@ struct Sim final : ssn_sim {
   std::vector<int64_t> seg_spikes;                                       // spike signals whose list is segmented
   std::vector<std::pair<int, float2*>> dft_tables;                      // transform length -> twiddle table
   std::vector<ssn::BatchOp<T>> pre_ops, post_ops;
+  int batch_skipped = 0;                      // products of the batched stages whose whole input was zero over a block (run_batch)
   std::vector<ssn_range> pre_to_core, core_to_post;
   std::vector<unsigned char> batched_mask;    // signals owned by a batched stage (for ssn_read_signal)
   std::vector<MOp> mops;                     // [head][middle programs...][tail][head copy]
@@ -2474,6 +2475,7 @@ struct Sim final : ssn_sim {
         }
       }
       if (track && (ops[i].kind == ssn::M_MATVEC_SET || ops[i].kind == ssn::M_MATVEC_INC) && !ops[i].src_prev && all_zero(ops[i].src, ops[i].cols)) {
+        ++batch_skipped;
         if (ops[i].kind == ssn::M_MATVEC_SET) {        // W @ 0: the result rows of the block are zero (an increment adds nothing)
           hipError_t e = hipMemset2DAsync(bsig + n_sig + ops[i].dst, (size_t)n_sig * sizeof(T), 0, (size_t)ops[i].len * sizeof(T), (size_t)B, stream);
           if (e != hipSuccess) return e;
@@ -3052,7 +3054,7 @@ struct Sim final : ssn_sim {
     out->block_enc_lds = fused_block ? blk.enc_lds : 0;
     out->block_threads = fused_block ? blk.threads : 0;
     out->block_members = fused_block ? std::max(1, blk.P) : 0;
-    out->reserved = 0;
+    out->batch_products_skipped = batch_skipped;
     out->fft_transforms = 0; out->fft_bluestein = 0;
     for (auto& it : items) if (it.type == IT_DFT) { out->fft_transforms += 1; out->fft_bluestein += it.dft.M > 0 ? 1 : 0; }
     return SSN_OK;

@@ -59,6 +59,34 @@ def test_pathint_f32_within_cosine_bar(Simulator, ssp_dim, n):
     assert ce.max() < 1e-3, ce.max()
 
 
+def test_pathint_blocks_after_the_init_window_skip_the_zero_input_product(Simulator, monkeypatch):
+    """The init-SSP input of the path integrator is zero from t = 50 ms on (reference run_pathint.py:136): in every block of
+    timesteps that lies behind it the time-batched `to_Fourier` product has an all-zero input and is not multiplied out
+    (run_batch's zero tracking, ssn_host.hip).  64-step blocks put four of five blocks behind the window: f64 against the
+    oracle, and bit-equal to a run with the tracking switched off."""
+    pm = small_pathint(ssp_dim=55, n=70, T=10.0, limit=0.2)
+    model = build(pm.model)
+    ref = OracleSimulator(model)
+    ref.run_steps(320)
+    outs = {}
+    for skip in (True, False):
+        if skip:
+            monkeypatch.delenv("SSN_NO_ZERO_SKIP", raising=False)
+        else:
+            monkeypatch.setenv("SSN_NO_ZERO_SKIP", "1")
+        with Simulator(None, model=model, dtype="f64", block_steps=64) as sim:
+            sim.run_steps(200)
+            sim.run_steps(120)
+            outs[skip] = np.array(sim.data[pm.probe])
+            assert sim.counters()["batch_products_skipped"] == (5 if skip else 0)       # blocks of 64, 64, 64, 8 | 64, 56 steps: all but the first lie behind t = 50 ms
+    np.testing.assert_allclose(outs[True], ref.probe_data(0), atol=1e-9, rtol=0)
+    np.testing.assert_array_equal(outs[True], outs[False])
+    monkeypatch.delenv("SSN_NO_ZERO_SKIP", raising=False)
+    with Simulator(None, model=model, dtype="f32", block_steps=64) as sim:
+        sim.run_steps(320)
+        assert H.cosine_error(np.array(sim.data[pm.probe])[20:], ref.probe_data(0)[20:]).max() < 1e-3
+
+
 @pytest.mark.parametrize("shape", ["n=50000", "d=4033", "n=12000"])
 def test_pathint_shapes_of_the_large_configurations(Simulator, shape):
     """Ensembles too large for the whole-block kernel (BASELINE config 4: 50 000 neurons per VCO - the per-timestep
