@@ -376,8 +376,10 @@ def test_dft_kernel_matches_the_transform_matrices(Simulator):
     from sspslam_amd.networks import CircularConvolution
     from sspslam_amd.builder import dft_structure
     FOURSTEP, BIG = 536870912, 268435456
+    # (even lengths: 40 = 8 x 5, 44 = 4 x 11 and 70 = 2 x 7 x 5 run a radix-8 / 4 / 2 pass as in-register butterflies between
+    #  generic ones - dft_pass_small; the odd lengths' chirp-z transforms run them in place - dft_pass_inplace)
     for d, inv_a, inv_b in ((25, False, True), (55, True, False), (217, False, False), (97, False, True), (1015, True, False),
-                            (1801, True, False), (2049, False, True)):
+                            (40, False, False), (44, True, False), (70, False, True), (1801, True, False), (2049, False, True)):
         rng = np.random.RandomState(d)
         fa, fb = rng.randn(d) / np.sqrt(d), rng.randn(d) / np.sqrt(d)
         with nengo.Network(seed=1) as m:
