@@ -65,8 +65,14 @@ def parse():
     ap.add_argument("--mem-n-neurons", type=int, default=0, help="slam: memory / recall / error / ovc population size (0 = 10 * ssp_dim)")
     ap.add_argument("--circonv-n-neurons", type=int, default=100)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--eval-points", type=int, default=4000,
-                    help="decoder-solve eval points per VCO (nengo's default max(1500, 2n) = 20000 costs ~10x the build)")
+    ap.add_argument("--eval-points", type=eval_points_arg, default=4000,
+                    help="decoder-solve eval points per ensemble, or `default` for nengo's own rule max(clip(500 d, 750, 2500), 2 n) "
+                         "= 20000 per 10000-neuron VCO (reference pathintegration.py:162-166 leaves it to nengo).  The stepping cost "
+                         "is the same either way; 4000 is a build-time shortcut (~10x fewer rows in every decoder solve), and the "
+                         "line says which was used (config.eval_points_per_vco)")
+    ap.add_argument("--no-model-cache", action="store_true",
+                    help="build every model from scratch (default: built models are kept under $SSN_CACHE_DIR or ~/.cache/sspslam_amd, "
+                         "sspslam_amd/modelcache.py; config.build_cache says whether this run hit)")
     ap.add_argument("--cpu-steps", type=int, default=200, help="timed oracle timesteps of the cpu_baseline / parity leg (0 = skip)")
     ap.add_argument("--cpu-warmup", type=int, default=100, help="untimed oracle timesteps before them (BASELINE.md section 2)")
     ap.add_argument("--sim-block", type=int, default=0,
@@ -91,6 +97,15 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path with several ranks sharing one GPU (RCCL needs one GPU per rank)")
     return ap.parse_args()
+
+
+def eval_points_arg(v):
+    """--eval-points: an integer, or `default` (None -> the builder applies nengo's rule per ensemble)."""
+    return None if str(v).lower() in ("default", "nengo", "none") else int(v)
+
+
+def eval_points_label(args):
+    return args.eval_points if args.eval_points is not None else f"nengo default: max(clip(500 d, 750, 2500), 2 n) = {max(1500, 2 * args.pi_n_neurons)} per VCO"
 
 
 def launch_ranks(args):
@@ -309,11 +324,13 @@ def slam_leg(args, H, build, Simulator, OracleSimulator, dt, timed_steps, warm_s
                               mem_n_neurons=args.mem_n_neurons or 10 * args.ssp_dim, circonv_n_neurons=args.circonv_n_neurons,
                               ssp_dim=args.ssp_dim)
     model = build(sm.model, dt=dt, n_eval_points=args.eval_points)
+    build_cache = model.stats.get("cache")
     out = {"workload": f"SLAMNetwork 2-D ssp_dim={args.ssp_dim} pi_n_neurons={args.pi_n_neurons}/VCO mem_n_neurons={args.mem_n_neurons or 10 * args.ssp_dim} "
                        f"circonv_n_neurons={args.circonv_n_neurons} 10 landmarks ({model.n_neurons} neurons), configs[2]; landmark 0 placed "
                        "0.07 from the start of the path (in view from t = 0)", "dtype": "f32"}
     with Simulator(None, model=model, dtype="f32", device=device) as sim:
         out["build_seconds"] = round(time.time() - t0, 1)
+        out["build_cache"] = build_cache
         sim.prepare(n_run)
         sim.run_steps(max(k, warm_steps), collect=False)          # (the parity window: the run starts at t = 0)
         t0 = time.perf_counter()
@@ -342,9 +359,10 @@ def slam_main(args):
     """--workload slam: configs[2] as the headline object, sharded over the ranks at N > 1 (ShardedSLAM)."""
     torch, dist, world, rank, local_rank = init_dist(args)
     from sspslam_amd import harness as H
-    from sspslam_amd.builder import build
+    from sspslam_amd.modelcache import cached_build
     from sspslam_amd.simulator import Simulator
     from sspslam_amd.sharding import ShardedSLAM
+    build = (lambda net, **kw: cached_build(net, cache=False if args.no_model_cache else None, **kw))
     dt = 0.001
     block = args.block or 250
     n_total = (args.steps + args.warmup) * block
@@ -365,8 +383,8 @@ def slam_main(args):
                        device=local_rank)
         wall = leg["timesteps_timed"] * dt / leg["value"]
         out.update(value=leg["value"], ms_per_step=round(1e3 * wall / args.steps, 4),
-                   config={"workload": leg["workload"], "timesteps_per_step": block, "dt": dt, "eval_points_per_vco": args.eval_points,
-                           "parallelism": "1 GPU", "build_seconds": leg["build_seconds"]},
+                   config={"workload": leg["workload"], "timesteps_per_step": block, "dt": dt, "eval_points_per_vco": eval_points_label(args),
+                           "parallelism": "1 GPU", "build_seconds": leg["build_seconds"], "build_cache": leg.get("build_cache")},
                    roofline=leg["roofline"], slam=leg)
         for key in ("cpu_baseline", "parity", "gpu_over_cpu"):
             if key in leg:
@@ -401,7 +419,7 @@ def slam_main(args):
     out.update(value=round(args.steps * block * dt / wall, 4), ms_per_step=round(1e3 * wall / args.steps, 4),
                config={"workload": f"SLAMNetwork 2-D ssp_dim={args.ssp_dim} pi_n_neurons={args.pi_n_neurons}/VCO "
                                    f"mem_n_neurons={args.mem_n_neurons or 10 * args.ssp_dim} circonv_n_neurons={args.circonv_n_neurons} 10 landmarks, configs[2]",
-                       "timesteps_per_step": block, "dt": dt, "eval_points_per_vco": args.eval_points, "build_seconds": round(build_s, 1),
+                       "timesteps_per_step": block, "dt": dt, "eval_points_per_vco": eval_points_label(args), "build_seconds": round(build_s, 1),
                        "parallelism": f"neuron-sharded x{world}: ensemble arrays by ensemble, dense populations by neuron, one all-reduce of "
                                       f"{n_ex} values per timestep ({args.dist_backend}), "
                                       + ("whole run enqueued on one stream (ssn_phase_async)" if r._stream_ordered() else "host loop (gloo rehearsal)")},
@@ -416,9 +434,10 @@ def pathint_main(args):
     import numpy as np
     torch, dist, world, rank, local_rank = init_dist(args)
     from sspslam_amd import harness as H
-    from sspslam_amd.builder import build
+    from sspslam_amd.modelcache import cached_build
     from sspslam_amd.simulator import Simulator
     from sspslam_amd.sharding import ShardedPathIntegration
+    build = (lambda net, **kw: cached_build(net, cache=False if args.no_model_cache else None, **kw))
 
     dt = 0.001
     args.block = args.block or 1000
@@ -505,9 +524,9 @@ def pathint_main(args):
         "value_is": "device-resident stepping rate: inputs tabulated and uploaded before the timed region, probe samples left in HBM",
         "config": {"workload": f"PathIntegration 2-D ssp_dim={space.ssp_dim} pi_n_neurons={args.pi_n_neurons}/VCO "
                                f"({K} VCOs, {N} LIF neurons), configs[1]",
-                   "timesteps_per_step": args.block, "dt": dt, "eval_points_per_vco": args.eval_points,
+                   "timesteps_per_step": args.block, "dt": dt, "eval_points_per_vco": eval_points_label(args),
                    "parallelism": "1 GPU" if not sharded else f"VCO-sharded x{world}, all-gather per {args.block} steps ({args.dist_backend})",
-                   "build_seconds": round(build_s, 1)},
+                   "build_seconds": round(build_s, 1), "build_cache": (model.stats.get("cache") if model is not None else None)},
     }
 
     if sharded:

@@ -163,7 +163,7 @@ struct Sim final : ssn_sim {
   std::set<int> sparse_w;                     // decoder buffers multiplied with a LIF spike vector
   std::vector<std::pair<int64_t, std::pair<int*, int*>>> spike_lists;   // spike signal offset -> (list, count)
   std::vector<int64_t> seg_spikes;                                       // spike signals whose list is segmented
-  std::vector<std::pair<int, float2*>> dft_tables;                      // transform length -> twiddle table
+  std::vector<std::pair<int64_t, float2*>> dft_tables;                  // dft_key(kind, sizes) -> table (twiddles, chirps, spectra, DFT matrices)
   std::vector<ssn::BatchOp<T>> pre_ops, post_ops;
   int batch_skipped = 0;                      // products of the batched stages whose whole input was zero over a block (run_batch)
   std::vector<ssn_range> pre_to_core, core_to_post;
@@ -232,6 +232,7 @@ struct Sim final : ssn_sim {
   hipGraph_t async_graph[3] = {nullptr, nullptr, nullptr};
   void* async_buf = nullptr;
   bool async_captured = false, async_active = false;
+  hipStream_t async_stream = nullptr;         // the caller's stream a stream-ordered run is in flight on (while async_active)
   static constexpr int N_ITEM_TYPES = 16;
   double type_ms[N_ITEM_TYPES] = {};             // profile = 2: device time per plan-item type
   int64_t type_launches[N_ITEM_TYPES] = {};
@@ -240,6 +241,7 @@ struct Sim final : ssn_sim {
 
   ~Sim() override {
     hipSetDevice(device);
+    if (async_active && async_stream) hipStreamSynchronize(async_stream);
     if (stream) hipStreamSynchronize(stream);
     if (graph_exec) hipGraphExecDestroy(graph_exec);
     if (graph) hipGraphDestroy(graph);
@@ -675,7 +677,11 @@ struct Sim final : ssn_sim {
     return c * L;
   }
 
-  int dft_table(int key, const std::vector<float2>& h, float2** out) {
+  // Injective key of a table: what it is (kind) and every size its contents depend on - a network with circular convolutions
+  // of two different lengths must never be handed the other length's table.
+  enum { DK_TWIDDLE = 1, DK_CHIRP = 2, DK_CHIRP_SPECTRUM = 3, DK_CHIRP_SPECTRUM_INPLACE = 4, DK_DFT4_G1 = 5, DK_DFT4_G2 = 6 };
+  static int64_t dft_key(int kind, int a, int b = 0) { return ((int64_t)kind << 56) | ((int64_t)(uint32_t)a << 28) | (int64_t)(uint32_t)b; }
+  int dft_table(int64_t key, const std::vector<float2>& h, float2** out) {
     for (auto& t : dft_tables) if (t.first == key) { *out = t.second; return SSN_OK; }
     float2* d = nullptr;
     CHK(dmalloc(&d, (int64_t)h.size() * (int64_t)sizeof(float2)));
@@ -715,7 +721,7 @@ struct Sim final : ssn_sim {
     return best;
   }
   int dft4_tables(int N1, int N2, const float** g1_out, const float** g2_out) {
-    const int key1 = (1 << 24) + N1 * 4096 + N2, key2 = (1 << 25) + N1 * 4096 + N2;
+    const int64_t key1 = dft_key(DK_DFT4_G1, N1, N2), key2 = dft_key(DK_DFT4_G2, N1, N2);
     for (auto& t : dft_tables) if (t.first == key1) *g1_out = (const float*)t.second;
     for (auto& t : dft_tables) if (t.first == key2) *g2_out = (const float*)t.second;
     if (*g1_out && *g2_out) return SSN_OK;
@@ -780,7 +786,7 @@ struct Sim final : ssn_sim {
       if (sp.first) {
         const int L = M > 0 ? M : d;
         float2* tw = nullptr;
-        CHK(dft_table(L, twiddles(L), &tw));
+        CHK(dft_table(dft_key(DK_TWIDDLE, L), twiddles(L), &tw));
         if (M > 0) CHK(bluestein_tables(d, M, a));
         const float* g1 = nullptr; const float* g2 = nullptr;
         CHK(dft4_tables(sp.first, sp.second, &g1, &g2));
@@ -804,7 +810,7 @@ struct Sim final : ssn_sim {
     }
     if (rad.empty() || rad.size() > 12) return SSN_OK;
     float2* tw = nullptr;
-    CHK(dft_table(L, twiddles(L), &tw));
+    CHK(dft_table(dft_key(DK_TWIDDLE, L), twiddles(L), &tw));
     bool small_only = M > 0 && !getenv("SSN_DFT_NO_INPLACE");          // every pass an in-register one: both transforms in place
     for (int r : rad) small_only = small_only && (r == 8 || r == 4 || r == 2);
     if (M > 0) CHK(bluestein_tables(d, M, a, small_only ? &rad : nullptr));
@@ -847,13 +853,13 @@ struct Sim final : ssn_sim {
         fb[(size_t)k] = make_float2((float)(sr / M), (float)(si / M));
       }
       float2* dw = nullptr; float2* dfb = nullptr;
-      CHK(dft_table(-d, w, &dw));
+      CHK(dft_table(dft_key(DK_CHIRP, d), w, &dw));
       if (inplace_radices) {                             // the in-place engine multiplies in digit-reversed order
         std::vector<float2> fp((size_t)M);
         for (int k = 0; k < M; ++k) fp[(size_t)dif_position(k, M, *inplace_radices)] = fb[(size_t)k];
         fb.swap(fp);
       }
-      CHK(dft_table(-(1 << 20) - d - (M << 3) - (inplace_radices ? 4 : 0), fb, &dfb));     // (the spectrum depends on M and on the engine)
+      CHK(dft_table(dft_key(inplace_radices ? DK_CHIRP_SPECTRUM_INPLACE : DK_CHIRP_SPECTRUM, d, M), fb, &dfb));     // (the spectrum depends on d, M and the engine)
       a->M = M; a->chirp = dw; a->fb = dfb; a->inplace = inplace_radices ? 1 : 0;
     }
     return SSN_OK;
@@ -2730,6 +2736,7 @@ struct Sim final : ssn_sim {
       return fail(SSN_EINVAL, "ssn_phase_async: the exchange buffer changed inside a run (call ssn_phase_sync first)");
     }
     HIPCHK(hipGraphLaunch(async_exec[phase], ext ? ext : stream));
+    async_stream = ext ? ext : stream;
     next_phase = phase == 0 ? 1 : (phase == 1 ? 0 : 1);
     if (phase >= 1) steps_done += 1;
     return SSN_OK;
@@ -2922,6 +2929,10 @@ struct Sim final : ssn_sim {
 
   int reset() override {
     HIPCHK(hipSetDevice(device));
+    if (async_active) {          // phase graphs may still be queued on the caller's stream: they come first
+      HIPCHK(hipStreamSynchronize(async_stream ? async_stream : stream));
+      async_active = false;
+    }
     HIPCHK(hipStreamSynchronize(stream));
     CHK(upload(sig_init.data(), sig, 1, n_sig, n_sig));
     for (auto& b : bufs)
@@ -2941,6 +2952,7 @@ struct Sim final : ssn_sim {
   int set_table(int id, const double* rows, const void* rows_dev, int64_t n_rows, int64_t width,
                 const int32_t* idx, int64_t n_idx, int64_t first_step) override {
     HIPCHK(hipSetDevice(device));
+    if (async_active) return fail(SSN_EINVAL, "a stream-ordered run is in flight on the caller's stream: call ssn_phase_sync first");
     if (id < 0 || id >= (int)tables.size()) return fail(SSN_EINVAL, "table id %d out of range", id);
     if (width != tables[id].width) return fail(SSN_EINVAL, "table %d is %lld wide, got %lld", id, (long long)tables[id].width, (long long)width);
     if (n_rows < 0 || n_idx < 0 || (!idx && n_idx)) return fail(SSN_EINVAL, "bad table arguments");
@@ -2972,6 +2984,7 @@ struct Sim final : ssn_sim {
 
   int reserve_probes(int64_t n) override {
     HIPCHK(hipSetDevice(device));
+    if (async_active) return fail(SSN_EINVAL, "a stream-ordered run is in flight on the caller's stream: call ssn_phase_sync first");
     HIPCHK(hipStreamSynchronize(stream));
     reserve_first = steps_done;
     reserve_n = n;
@@ -3001,6 +3014,7 @@ struct Sim final : ssn_sim {
 
   int read_probe(int id, double* dst, void* dst_dev, int64_t first, int64_t count) override {
     HIPCHK(hipSetDevice(device));
+    if (async_active) return fail(SSN_EINVAL, "a stream-ordered run is in flight on the caller's stream: call ssn_phase_sync first");
     if (id < 0 || id >= (int)pslots.size()) return fail(SSN_EINVAL, "probe id %d out of range", id);
     if (first < 0 || count < 0 || first + count > probe_count(id))
       return fail(SSN_EINVAL, "probe %d holds %lld samples, asked for [%lld,+%lld)", id, (long long)probe_count(id), (long long)first, (long long)count);
@@ -3016,6 +3030,7 @@ struct Sim final : ssn_sim {
 
   int rw_signal(int64_t off, int64_t count, double* dst, const double* src) override {
     HIPCHK(hipSetDevice(device));
+    if (async_active) return fail(SSN_EINVAL, "a stream-ordered run is in flight on the caller's stream: call ssn_phase_sync first");
     CHK(check_range(off, count, "signal access"));
     if (!dst) {
       CHK(upload(src, sig + off, 1, count, count));
@@ -3032,6 +3047,7 @@ struct Sim final : ssn_sim {
 
   int rw_buffer(int id, double* dst, const double* src, int64_t count) override {
     HIPCHK(hipSetDevice(device));
+    if (async_active) return fail(SSN_EINVAL, "a stream-ordered run is in flight on the caller's stream: call ssn_phase_sync first");
     if (id < 0 || id >= (int)bufs.size()) return fail(SSN_EINVAL, "buffer id %d out of range", id);
     Buf& b = bufs[id];
     if (b.kind != SSN_BUF_REAL || count != b.count) return fail(SSN_EINVAL, "buffer %d: real buffer of %lld elements expected", id, (long long)b.count);

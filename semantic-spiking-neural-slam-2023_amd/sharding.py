@@ -23,7 +23,7 @@ import threading
 import numpy as np
 
 from . import frontend as nengo
-from .builder import build
+from .modelcache import cached_build as build      # (a rank's shard is keyed by its (rank, world) like any other build argument)
 
 
 def shard_range(K, rank, world):
@@ -560,12 +560,25 @@ class ShardedSLAM:
             with torch.cuda.stream(self._stream):
                 stream = self._stream.cuda_stream
                 assert stream, "a created HIP stream has a non-zero handle"
-                self.sim.phase_async(0, buf, stream)
-                for i in range(n):
-                    if self.world > 1:
-                        self.dist.all_reduce(self._buf)
-                    self.sim.phase_async(2 if i + 1 < n else 1, buf, stream)
-                self.sim.phase_sync(stream)
+                # Whatever fails while the run is being enqueued (a phase refused, a collective that raises), the stream is
+                # drained and the library's in-flight mark cleared before the error travels on: reset / read_buffer /
+                # set_table synchronise the simulator's own stream only and must not race with graphs still queued here.
+                enqueue_error = None
+                try:
+                    self.sim.phase_async(0, buf, stream)
+                    for i in range(n):
+                        if self.world > 1:
+                            self.dist.all_reduce(self._buf)
+                        self.sim.phase_async(2 if i + 1 < n else 1, buf, stream)
+                except BaseException as e:           # noqa: BLE001 - re-raised below, after the stream has been drained
+                    enqueue_error = e
+                try:
+                    self.sim.phase_sync(stream)
+                except Exception:
+                    if enqueue_error is None:
+                        raise
+                if enqueue_error is not None:
+                    raise enqueue_error
             torch.cuda.current_stream().wait_stream(self._stream)
         else:
             self._agree(err)

@@ -353,16 +353,18 @@ class Simulator:
             else:
                 self.prepare(steps)
         buf_probes = [(k, v[2]) for k, v in self._probe_index.items() if v[0] == "buf"]
-        done = 0
-        self._collector = None
+        self._collector = self._tab_worker = None
         try:
             self._step_loop(steps, profile, pipelined, buf_probes)
         except BaseException:
-            # a failed run must not leave the helper threads or the bulk arrays of the pipelined read-back behind: the next
-            # run_steps would otherwise collect into stale arrays
-            if self._collector is not None:
-                self._collector.join()
-            self._collector, self._bulk, self._bulk_error = None, None, None
+            # a failed run must not leave the helper threads or the bulk arrays of the pipelined read-back behind: the
+            # tabulation thread would go on calling the user's node closures (and this object) after the caller has seen the
+            # exception, and the next run_steps would collect into stale arrays
+            for th in (self._tab_worker, self._collector):
+                if th is not None:
+                    th.join()
+            self._collector = self._tab_worker = None
+            self._bulk, self._bulk_error = None, None
             raise
         self._uncollected = True
         if collect:
@@ -370,6 +372,7 @@ class Simulator:
         self._prepared_until = max(self._prepared_until, self.n_steps)
 
     _collector = None
+    _tab_worker = None
     _chunk_len = PIPELINE_CHUNK
 
     def _step_loop(self, steps, profile, pipelined, buf_probes):
@@ -403,7 +406,7 @@ class Simulator:
                             box.update(r=self._tabulate_chunk(nxt, n_next))
                         except BaseException as e:       # noqa: BLE001 - re-raised on the caller's thread
                             box["e"] = e
-                    worker = threading.Thread(target=tab)
+                    worker = self._tab_worker = threading.Thread(target=tab)
                     worker.start()
             for _, p in buf_probes:          # stop before the next timestep whose sample is due (taken at the top of the loop)
                 r = (self.n_steps + 1) % p["every"]
@@ -419,6 +422,7 @@ class Simulator:
                 collector.start()
             if worker is not None:
                 worker.join()
+                self._tab_worker = None
                 if "r" not in box:
                     raise fe.SimulationError("evaluating the input nodes for the next chunk failed") from box.get("e")
                 pipelined = box["r"]
@@ -541,10 +545,10 @@ class Simulator:
 
     # -- neuron-sharded models (builder.shard_phases): the caller completes the partial sums between the phases ---------
     def run_phase(self, phase):
-        """0: up to the exchange; 1: the updates; 2: the updates followed by the next timestep up to its exchange."""
-        if phase == -1:                  # build the graphs for this exchange buffer now (no launch)
-            self._check(self._lib.ssn_phase_async(self._h, -1, C.c_void_p(exchange_buf_ptr or None), C.c_void_p(None)))
-            return
+        """0: up to the exchange; 1: the updates; 2: the updates followed by the next timestep up to its exchange.
+        (The graphs of the stream-ordered path are built through ``phase_async(-1, buffer, None)``.)"""
+        if phase not in (0, 1, 2):
+            raise fe.SimulationError(f"run_phase({phase}): 0, 1 or 2")
         if phase in (0, 2) and self._prepared_until < self.n_steps + (1 if phase == 0 else 2):
             raise fe.SimulationError("neuron-sharded model: call prepare(n_steps) before stepping")
         self._check(self._lib.ssn_run_phase(self._h, int(phase)))
@@ -555,6 +559,9 @@ class Simulator:
     def phase_async(self, phase, exchange_buf_ptr, stream_ptr):
         """Stream-ordered variant of ``run_phase``: enqueues [unpack] -> the phase -> [pack] as one graph launch on the
         caller's HIP stream and returns; ``phase_sync`` waits and checks.  No host synchronisation per timestep."""
+        if phase == -1:                  # only build the graphs for this exchange buffer (no launch, nothing to prepare)
+            self._check(self._lib.ssn_phase_async(self._h, -1, C.c_void_p(exchange_buf_ptr or None), C.c_void_p(None)))
+            return
         if phase in (0, 2) and self._prepared_until < self.n_steps + (1 if phase == 0 else 2):
             raise fe.SimulationError("neuron-sharded model: call prepare(n_steps) before stepping")
         self._check(self._lib.ssn_phase_async(self._h, int(phase), C.c_void_p(exchange_buf_ptr or None), C.c_void_p(stream_ptr or None)))

@@ -7,7 +7,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import sspslam_amd.frontend as nengo
-from sspslam_amd.builder import build
+from sspslam_amd.modelcache import cached_build as build
 from sspslam_amd.networks import CircularConvolution
 from sspslam_amd.simulator import Simulator
 

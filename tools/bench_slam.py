@@ -8,7 +8,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sspslam_amd import harness as H
-from sspslam_amd.builder import build
+from sspslam_amd.modelcache import cached_build as build
 from sspslam_amd.simulator import Simulator
 
 d, pi_n, M, c, steps, m_eval = [int(a) for a in sys.argv[1:7]]

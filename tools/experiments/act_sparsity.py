@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, "/root/repo")
 import numpy as np
 from sspslam_amd import harness as H
-from sspslam_amd.builder import build
+from sspslam_amd.modelcache import cached_build as build
 from sspslam_amd.simulator import Simulator
 sm = H.make_config3_model(seed=0, T=20.0, dt=0.001)
 bm = build(sm.model, n_eval_points=4000)

@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
 from sspslam_amd import harness as H
-from sspslam_amd.builder import build
+from sspslam_amd.modelcache import cached_build as build
 from sspslam_amd.simulator import Simulator
 dt, view_rad, M, d = 0.001, 0.2, 10150, 1015
 s = H.make_ssp_space(2, d)

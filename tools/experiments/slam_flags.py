@@ -4,7 +4,7 @@ usage: python tools/experiments/slam_flags.py [flags[,ENV=value...] ...]      (d
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sspslam_amd import harness as H
-from sspslam_amd.builder import build
+from sspslam_amd.modelcache import cached_build as build
 from sspslam_amd.simulator import Simulator
 flag_sets = sys.argv[1:] or ["0", "256"]
 SPG = [int(x) for x in os.environ.get("SSN_SPG", "0").split(",")]

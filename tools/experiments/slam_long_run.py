@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
 from sspslam_amd import harness as H
-from sspslam_amd.builder import build
+from sspslam_amd.modelcache import cached_build as build
 from sspslam_amd.simulator import Simulator
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 s = H.make_ssp_space(2, 1015)

@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sspslam_amd import harness as H
-from sspslam_amd.builder import build
+from sspslam_amd.modelcache import cached_build as build
 from sspslam_amd.simulator import Simulator
 s = H.make_ssp_space(2, 1015)
 path, vels = H.make_random_path(70.0, dt=0.001, limit=0.1, seed=0)
