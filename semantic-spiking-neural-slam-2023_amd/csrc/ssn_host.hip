@@ -140,6 +140,8 @@ struct Sim final : ssn_sim {
   double dt = 0.001;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;          // downloads (see download())
+  double* up_stage = nullptr;                 // device staging of upload() (float64 as it arrives from the host)
+  int64_t up_cap = 0;
   void* dl_stage = nullptr;                   // pinned host staging of download()
   int64_t dl_cap = 0;
   std::mutex dl_mutex;
@@ -271,6 +273,7 @@ struct Sim final : ssn_sim {
     if (d_pslots) hipFree(d_pslots);
     if (copy_stream) { hipStreamSynchronize(copy_stream); hipStreamDestroy(copy_stream); }
     if (dl_stage) hipHostFree(dl_stage);
+    if (up_stage) hipFree(up_stage);
     if (stream) hipStreamDestroy(stream);
   }
 
@@ -286,12 +289,28 @@ struct Sim final : ssn_sim {
   int upload(const double* src, T* dst, int64_t rows, int64_t cols, int64_t ld) {
     const int64_t n = rows * cols;
     if (n == 0) return SSN_OK;
+    // float64 staging on the device: uploads of up to 64 MB share one buffer that stays (the tables of a chunked run are
+    // replaced at every chunk boundary - a hipMalloc / hipFree pair per table there cost more than the copy); larger ones
+    // (weight matrices at build time, config 5's 14 GB clean-up table) take and release their own
+    constexpr int64_t KEEP = (int64_t)8 << 20;                 // elements
     double* stage = nullptr;
-    HIPCHK(hipMalloc((void**)&stage, (size_t)n * sizeof(double)));
+    bool own = false;
+    if (n <= KEEP) {
+      if (n > up_cap) {
+        if (up_stage) { hipFree(up_stage); up_stage = nullptr; up_cap = 0; }
+        const int64_t want = std::min<int64_t>(KEEP, std::max<int64_t>(2 * n, 1 << 16));
+        HIPCHK(hipMalloc((void**)&up_stage, (size_t)want * sizeof(double)));
+        up_cap = want;
+      }
+      stage = up_stage;
+    } else {
+      HIPCHK(hipMalloc((void**)&stage, (size_t)n * sizeof(double)));
+      own = true;
+    }
     hipError_t e = hipMemcpyAsync(stage, src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = ssn::launch_convert_in<T>(stream, stage, dst, rows, cols, ld);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    hipFree(stage);
+    if (own) hipFree(stage);
     HIPCHK(e);
     return SSN_OK;
   }

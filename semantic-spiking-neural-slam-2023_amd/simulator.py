@@ -155,25 +155,77 @@ def pack_model(model, dtype, device=0, steps_per_graph=0, block_steps=0, flags=0
     return desc, keep, sig_probes
 
 
-def tabulate(fn, width, steps, dt):
+class RowStage:
+    """Reusable host staging for the rows of one tabulated node (a fresh 160 MB array per chunk would spend longer in page
+    faults than the closures take to evaluate)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def rows(self, n, width):
+        if self.buf is None or self.buf.shape[0] < n or self.buf.shape[1] != width:
+            self.buf = np.empty((max(n, 2 * (0 if self.buf is None or self.buf.shape[1] != width else self.buf.shape[0])), width))
+        return self.buf[:n]
+
+
+def tabulate(fn, width, steps, dt, stage=None):
     """Evaluate a t-only node function for 1-based step numbers ``steps`` with nengo's time
-    ``t = step*dt`` (float64) and run-length-encode equal consecutive rows."""
+    ``t = step*dt`` (float64) and run-length-encode equal consecutive rows
+    (``idx[j]`` = row of step ``steps[j]``; -1 = a row of zeros, which is not stored).
+
+    A plain closure - the reference scripts' ``lambda t: table[int((t - dt) / dt)]``, ``run_pathint.py:134-136`` - is
+    called once per timestep in time order, exactly as nengo calls it, and its value is copied before the next call (a
+    closure may hand out one buffer again and again); everything else happens in bulk: neighbours are compared bit for bit
+    only where three sampled columns agree (runs of candidates as slices, no gathers), and the zero test runs on the
+    surviving rows.  The returned rows may alias ``stage`` (valid until the next call with the same stage)."""
     if hasattr(fn, "table"):          # vectorised provider: (rows, idx) for all steps at once
         rows, idx = fn.table(np.asarray(steps))
         return np.asarray(rows, dtype=np.float64).reshape(-1, width), np.asarray(idx, dtype=np.int32)
-    rows, idx = [], np.empty(len(steps), dtype=np.int32)
-    prev = None
-    asarray, f64 = np.asarray, np.float64
-    for j, t in enumerate((np.asarray(steps) * dt).tolist()):        # t = step*dt in float64, as nengo computes it
-        v = asarray(fn(t), dtype=f64).reshape(-1)
-        if v.size != width:
-            raise fe.SimulationError(f"node function returned {v.size} values, expected {width}")
-        key = v.tobytes()                                             # (bitwise row comparison: cheaper than array_equal)
-        if key != prev:
-            rows.append(v)
-            prev = key
-        idx[j] = len(rows) - 1
-    return (np.stack(rows) if rows else np.zeros((0, width))), idx
+    ts = (np.asarray(steps) * dt).tolist()                            # t = step*dt in float64, as nengo computes it
+    n = len(ts)
+    if n == 0:
+        return np.zeros((0, width)), np.zeros(0, dtype=np.int32)
+    rows = (stage or RowStage()).rows(n, width)
+    for j, t in ((0, ts[0]), (n - 1, ts[-1])):                        # (sizes are checked on the first and the last value:
+        if np.size(fn(t)) != width:                                   #  an assignment would broadcast a scalar silently)
+            raise fe.SimulationError(f"node function returned {np.size(fn(t))} values, expected {width}")
+    try:
+        for j, t in enumerate(ts):                                    # ONE Python call per timestep, in time order
+            rows[j] = fn(t)
+    except ValueError as e:
+        raise fe.SimulationError(f"node function returned a value that is not {width} wide") from e
+    bits = rows.view(np.uint64)                                       # bitwise row comparison (-0.0 is not 0.0, NaN equals itself)
+    cols = sorted({0, width // 2, width - 1})
+
+    def runs(mask):                                                   # [lo, hi) of every run of True
+        edge = np.flatnonzero(np.diff(np.concatenate(([False], mask, [False])).astype(np.int8)))
+        return zip(edge[0::2].tolist(), edge[1::2].tolist())
+
+    change = np.ones(n, dtype=bool)
+    if n > 1:
+        same = np.ones(n - 1, dtype=bool)
+        for c in cols:
+            same &= bits[1:, c] == bits[:-1, c]
+        for lo, hi in runs(same):          # neighbours that agree on the sampled columns: compared in full, slice against slice
+            same[lo:hi] = (bits[lo + 1:hi + 1] == bits[lo:hi]).all(axis=1)
+        change[1:] = ~same
+    zero = np.ones(n, dtype=bool)
+    for c in cols:
+        zero &= bits[:, c] == 0
+    for lo, hi in runs(zero):              # rows whose sampled columns are zero: tested in full
+        zero[lo:hi] = ~bits[lo:hi].any(axis=1)
+    first = np.flatnonzero(change)                                    # first timestep of every run of equal rows
+    run = np.cumsum(change) - 1                                       # run of every timestep
+    if 2 * first.size >= n:
+        # mostly distinct rows (a path table; int((t - dt) / dt) repeats a row now and then): the staged rows are the table as
+        # they stand - a run points at its first row, the repeats in between are dead weight of the upload, nothing is copied
+        slot = first.copy()
+        slot[zero[first]] = -1
+        return rows, slot[run].astype(np.int32)
+    z = zero[first]
+    slot = np.cumsum(~z) - 1                                          # stored position of every non-zero run's row
+    slot[z] = -1
+    return np.ascontiguousarray(rows[first[~z]]), slot[run].astype(np.int32)
 
 
 class Simulator:
@@ -299,17 +351,32 @@ class Simulator:
         self._check(self._lib.ssn_set_table_device(self._h, table_id, C.c_void_p(rows_dev_ptr), n_rows, tb["width"],
                                                    idx.ctypes.data, idx.size, first_step))
 
-    PIPELINE_CHUNK = 2048
-    PIPELINE_CHUNK_CHEAP = 8192      # chunk length once the input nodes have proved cheap to tabulate (vectorised .table twins)
+    # A long run straight from run() is cut into chunks: the node closures of chunk k + 1 are evaluated on a helper thread and
+    # the samples of chunk k - 1 are read back on another while the device steps chunk k.  What is NOT hidden: the tabulation
+    # of the first chunk, the read-back of the last one, and ~0.3 ms of idle device at every boundary.  So the first chunk is
+    # short, every later one is as long as its tabulation can hide behind the chunk before it (measured rates, at most
+    # PIPELINE_GROWTH x its predecessor), and the run ends with a short chunk.
+    PIPELINE_FIRST = 512
+    PIPELINE_MIN = 256
+    PIPELINE_MAX = 8192
+    PIPELINE_TAIL = 1024
+    PIPELINE_GROWTH = 4.0
+    PIPELINE_CHUNK = 2048            # runs of at most twice this many steps are prepared in one piece
 
     def _tabulate_chunk(self, first, n):
         """(first, n, [(rows, idx) per table]) for the n timesteps after 0-based step ``first``."""
         steps = np.arange(first + 1, first + n + 1)
         tabs = []
-        for tb in self.model.tables:
-            rows, idx = tabulate(tb["fn"], tb["width"], steps, self.dt)
+        if self._stages is None:
+            self._stages = [RowStage() for _ in self.model.tables]
+        for tb, stage in zip(self.model.tables, self._stages):
+            # (the stage is free again: the tables of the chunk before were uploaded - synchronously - before this one's
+            #  tabulation started)
+            rows, idx = tabulate(tb["fn"], tb["width"], steps, self.dt, stage)
             tabs.append((np.ascontiguousarray(rows, dtype=np.float64), np.ascontiguousarray(idx, dtype=np.int32)))
         return first, n, tabs
+
+    _stages = None
 
     # -- running -------------------------------------------------------------------------------
     def run(self, time_in_seconds, progress_bar=None):
@@ -334,14 +401,10 @@ class Simulator:
                 self._check(self._lib.ssn_reserve_probes(self._h, steps))
                 self._fetched = {}
                 self._reserved_until = self.n_steps + steps
-                import time as _time
-                t_tab = _time.perf_counter()
-                pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_CHUNK, steps))
-                t_tab = (_time.perf_counter() - t_tab) / max(1, pipelined[1])
-                # Every chunk boundary costs ~0.7 ms of idle device (the run returns, tables are replaced, helper threads
-                # start): when evaluating the nodes takes well under the device's ~3 us per timestep the later chunks are
-                # four times as long; slow node closures keep the short chunks, whose tabulation hides behind the device run
-                self._chunk_len = self.PIPELINE_CHUNK_CHEAP if t_tab < 0.5e-6 else self.PIPELINE_CHUNK
+                t_tab = time.perf_counter()
+                pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_FIRST, steps))
+                self._tab_rate = (time.perf_counter() - t_tab) / max(1, pipelined[1])      # seconds per timestep, host
+                self._dev_rate = None                                                        # ... device: known after the first chunk
                 if collect:
                     # the samples of chunk k are fetched (float64, straight into one array per probe) on a helper thread
                     # while the device steps chunk k + 1: the library downloads on its own stream
@@ -373,7 +436,21 @@ class Simulator:
 
     _collector = None
     _tab_worker = None
-    _chunk_len = PIPELINE_CHUNK
+    _tab_rate = None
+    _dev_rate = None
+
+    def _next_chunk_len(self, cur, remaining):
+        """Length of the chunk after one of ``cur`` timesteps (``remaining`` timesteps are left behind that one)."""
+        grow = self.PIPELINE_GROWTH
+        if self._dev_rate and self._tab_rate:            # its tabulation runs while the device steps `cur` timesteps
+            grow = min(grow, 0.8 * self._dev_rate / max(self._tab_rate, 1e-9))
+        n = int(max(self.PIPELINE_MIN, min(self.PIPELINE_MAX, cur * grow)))
+        if n >= 1024:
+            n -= n % 1024                                # whole time-batched blocks where the chunk holds several
+        tail = self.PIPELINE_TAIL
+        if remaining <= n + tail:                        # the run's last samples are read back with nothing to hide behind:
+            n = remaining - tail if remaining > 2 * tail else remaining      # keep the last chunk short
+        return max(1, min(n, remaining))
 
     def _step_loop(self, steps, profile, pipelined, buf_probes):
         done = 0
@@ -400,10 +477,12 @@ class Simulator:
                 if done + chunk < steps:
                     import threading
                     box = {}
-                    n_next = min(self._chunk_len, steps - done - chunk)
+                    n_next = self._next_chunk_len(chunk, steps - done - chunk)
                     def tab(box=box, nxt=nxt, n_next=n_next):
                         try:
+                            t0 = time.perf_counter()
                             box.update(r=self._tabulate_chunk(nxt, n_next))
+                            box["t"] = (time.perf_counter() - t0) / n_next
                         except BaseException as e:       # noqa: BLE001 - re-raised on the caller's thread
                             box["e"] = e
                     worker = self._tab_worker = threading.Thread(target=tab)
@@ -411,7 +490,10 @@ class Simulator:
             for _, p in buf_probes:          # stop before the next timestep whose sample is due (taken at the top of the loop)
                 r = (self.n_steps + 1) % p["every"]
                 chunk = min(chunk, p["every"] - r if r else p["every"])
+            t_dev = time.perf_counter()
             self._check(self._lib.ssn_run_steps(self._h, chunk, int(profile)))
+            if chunk >= self.PIPELINE_MIN:
+                self._dev_rate = (time.perf_counter() - t_dev) / chunk
             self.n_steps += chunk
             done += chunk
             if getattr(self, "_bulk", None) is not None and done < steps:
@@ -426,8 +508,9 @@ class Simulator:
                 if "r" not in box:
                     raise fe.SimulationError("evaluating the input nodes for the next chunk failed") from box.get("e")
                 pipelined = box["r"]
+                self._tab_rate = box.get("t", self._tab_rate)
                 if self.n_steps != pipelined[0]:          # a weight-probe boundary cut the chunk short: re-tabulate from here
-                    pipelined = self._tabulate_chunk(self.n_steps, min(self._chunk_len, steps - done))
+                    pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_FIRST, steps - done))
         if collector is not None:
             collector.join()
         self._collector = None

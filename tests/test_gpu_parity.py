@@ -11,7 +11,7 @@ import pytest
 
 import sspslam_amd.frontend as nengo
 from sspslam_amd import harness as H
-from sspslam_amd.builder import build
+from sspslam_amd.modelcache import cached_build as build      # (one build per model and session: conftest.py gives the suite a cache)
 from oracle import OracleSimulator
 
 from helpers import small_pathint
@@ -1032,6 +1032,19 @@ def test_long_run_pipelines_input_tabulation(Simulator):
         np.testing.assert_array_equal(sim.data[pm.probe], want)
         sim.run_steps(100)
         assert sim.data[pm.probe].shape[0] == 7100
+    # the same with plain per-timestep closures (what the reference scripts pass, run_pathint.py:134-136): no `.table` twin,
+    # one Python call per timestep on the helper thread, rows staged and run-length encoded in bulk (simulator.tabulate)
+    saved = [tb["fn"] for tb in model.tables]
+    try:
+        for tb in model.tables:
+            tb["fn"] = (lambda f: (lambda t: f(t)))(tb["fn"])
+            assert not hasattr(tb["fn"], "table")
+        with Simulator(None, model=model, dtype="f64") as sim:
+            sim.run_steps(7000)
+            np.testing.assert_array_equal(sim.data[pm.probe], want)
+    finally:
+        for tb, f in zip(model.tables, saved):
+            tb["fn"] = f
 
 
 def test_block_kernel_other_lif_parameters(Simulator):

@@ -227,10 +227,75 @@ def test_vectorised_input_tables_equal_the_per_step_closures():
         got = np.where(idx[:, None] >= 0, rows[np.maximum(idx, 0)], 0.0) if len(rows) else np.zeros((len(steps), 3))
         plain = lambda t: fn(t)                                      # no .table attribute: the per-step path
         rows2, idx2 = tabulate(plain, 3, steps, dt)
-        np.testing.assert_array_equal(got, rows2[idx2])
+        got2 = np.where(idx2[:, None] >= 0, rows2[np.maximum(idx2, 0)], 0.0) if len(rows2) else np.zeros((len(steps), 3))
+        np.testing.assert_array_equal(got, got2)
+        if until is not None:
+            assert (idx2[steps * dt >= until] == -1).all() and len(rows2) < 60      # zero rows are not stored
         k = np.array([int((t - dt) / dt) for t in (steps * dt).tolist()])
         assert until is not None or (k != steps - 1).any()           # the quirk is exercised
         # a later chunk only (what the pipelined tabulation asks for)
         r3, i3 = fn.table(np.arange(2049, 4097))
         np.testing.assert_array_equal(np.where(i3[:, None] >= 0, r3[np.maximum(i3, 0)], 0.0) if len(r3) else np.zeros((2048, 3)),
                                       got[2048:4096])
+
+
+def test_plain_closure_tabulation_is_exact_and_copies_at_call_time():
+    """simulator.tabulate on closures without a `.table` twin: one call per timestep in time order, the value copied before
+    the next call (a closure may hand out ONE buffer again and again), consecutive equal rows stored once, zero rows not at
+    all - and the rows it reports are, bit for bit, what per-step calls return."""
+    from sspslam_amd.simulator import tabulate, RowStage
+    dt = 0.001
+    rng = np.random.RandomState(3)
+    table = rng.randn(5000, 7)
+    table[100:140] = table[100]                      # a stretch of equal rows
+    table[200:260] = 0.0                             # zeros inside the table
+    table[300, 3] = -0.0
+    table[301] = table[300]
+    table[301, 3] = 0.0                              # differs from its neighbour in the sign of a zero only
+    calls = []
+    buf = np.empty(7)
+
+    def reusing(t):                                  # hands out the same array object every time
+        calls.append(t)
+        buf[:] = table[int((t - dt) / dt)] if t < 4.0 else 0.0
+        return buf
+
+    steps = np.arange(1, 4501)
+    stage = RowStage()
+    rows, idx = tabulate(reusing, 7, steps, dt, stage)
+    assert calls[2:] == (steps * dt).tolist() and calls[:2] == [steps[0] * dt, steps[-1] * dt]      # two size checks, then time order
+    want = np.stack([table[int((t - dt) / dt)] if t < 4.0 else np.zeros(7) for t in (steps * dt).tolist()])
+    got = np.where(idx[:, None] >= 0, rows[np.maximum(idx, 0)], 0.0)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert (idx[3999:] == -1).all() and (idx[200:260] == -1).all()
+    assert idx[300] != idx[301]                      # -0.0 and 0.0 are different rows
+    assert len(set(idx[100:140].tolist())) == 1
+    # a narrow, mostly constant node goes the compacting way; a scalar-returning function for a wider node is refused
+    rows2, idx2 = tabulate(lambda t: [1.0, 2.0] if t < 2.0 else [3.0, 4.0], 2, steps, dt)
+    assert rows2.tolist() == [[1.0, 2.0], [3.0, 4.0]] and idx2[:1999].tolist() == [0] * 1999 and (idx2[1999:] == 1).all()
+    with pytest.raises(Exception):
+        tabulate(lambda t: 1.0, 3, steps, dt)
+
+
+def test_chunk_schedule_of_a_pipelined_run():
+    """Simulator._next_chunk_len: chunks cover the run exactly, grow only as fast as the measured tabulation hides behind the
+    device, stay inside [PIPELINE_MIN, PIPELINE_MAX] and leave a short last chunk (its read-back is not overlapped)."""
+    from sspslam_amd.simulator import Simulator
+    for dev, tab in ((3e-6, 0.1e-6), (3e-6, 2.0e-6), (3e-6, 6e-6), (None, None)):
+        sim = Simulator.__new__(Simulator)
+        sim._dev_rate, sim._tab_rate = dev, tab
+        for steps in (5000, 20000, 20001, 100000):
+            chunks = [min(Simulator.PIPELINE_FIRST, steps)]
+            left = steps - chunks[0]
+            while left > 0:
+                n = sim._next_chunk_len(chunks[-1], left)
+                assert 1 <= n <= left
+                chunks.append(n)
+                left -= n
+            assert sum(chunks) == steps
+            assert max(chunks) <= Simulator.PIPELINE_MAX
+            assert chunks[-1] <= 2 * Simulator.PIPELINE_TAIL
+            if dev and tab and tab > dev:            # tabulation-bound: chunks shrink to the minimum instead of stalling the device longer
+                assert sorted(chunks[1:-2])[len(chunks[1:-2]) // 2] <= Simulator.PIPELINE_FIRST
+            if dev and tab and tab < 0.2 * dev:
+                assert len(chunks) <= 4 + steps // Simulator.PIPELINE_MAX
