@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSN_ABI_VERSION 6
+#define SSN_ABI_VERSION 7
 
 enum ssn_status {
   SSN_OK = 0,
@@ -191,6 +191,11 @@ typedef struct ssn_counters {
   int32_t fft_bluestein;            /* ... of which through Bluestein's convolution (a prime factor > 32)           */
   int32_t block_members;            /* member workgroups per ensemble of the whole-block kernel (flag 1073741824; 1 = not split, 0 = no block kernel) */
   int32_t batch_products_skipped; /* time-batched products not multiplied out because their whole input was zero over the block (cumulative) */
+  /* whole-block kernel (f32): (wave, round) slots stepped since create / reset, and how many of them were silent - no neuron of the
+   * slot spiked in the timestep, so the spike-time arithmetic and the decode were left out (ABI 7; the VALU roofline of bench.py
+   * prices the two paths with these) */
+  int64_t block_slots;
+  int64_t block_slots_silent;
 } ssn_counters;
 
 /* Per-kernel device time of the generic (one launch per operator) plan, collected by ssn_run_steps(profile = 2):

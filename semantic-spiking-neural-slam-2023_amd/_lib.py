@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSN_HIP_LIB") or os.path.join(_HERE, "libssn_hip.so")     # override: A/B builds of the library
 
-SSN_ABI_VERSION = 6
+SSN_ABI_VERSION = 7
 SSN_F32, SSN_F64 = 0, 1
 SSN_BUF_REAL, SSN_BUF_I32 = 0, 1
 NEURON_CODE = {"lif": 0, "lifrate": 1, "relu": 2}
@@ -54,7 +54,8 @@ class Counters(C.Structure):
                 ("dominant_units_per_launch", C.c_int64), ("last_run_ms", C.c_double), ("device_bytes", C.c_int64),
                 ("block_tpb", C.c_int32), ("block_npt", C.c_int32), ("block_enc_lds", C.c_int32),
                 ("block_threads", C.c_int32), ("fft_transforms", C.c_int32), ("fft_bluestein", C.c_int32),
-                ("block_members", C.c_int32), ("batch_products_skipped", C.c_int32)]
+                ("block_members", C.c_int32), ("batch_products_skipped", C.c_int32),
+                ("block_slots", C.c_int64), ("block_slots_silent", C.c_int64)]
 
 
 class KernelTime(C.Structure):

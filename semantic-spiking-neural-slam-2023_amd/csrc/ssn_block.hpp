@@ -182,6 +182,33 @@ __device__ inline void lif_state_part(f32x2 w, const LifConstV3& c, f32x2& W0, f
   asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(dl), "v"(P), "s"((f32x2)(c.c1)));
   em = dl * P;
 }
+// The input half in three pieces, so that a wave whose neurons are all silent in a timestep can leave out the spike-time
+// arithmetic (round 4): lif_spike_test produces U = V - 1, the spike indicators and the stay-refractory term; lif_finish_spiking
+// is the rest of lif_input_part; lif_finish_silent is what that rest computes when every indicator is 0 - bit for bit:
+// Wn = clamp(0 * 2^100 - U) = clamp(-U), w' = fma(0, nu, Wn + nmt) = Wn + nmt (nu is a number in [0, 1] after its clamp, so
+// 0 * nu = +0, and Wn + nmt >= 0).
+__device__ inline f32x2 lif_spike_test(f32x2 Jm1, f32x2 w, f32x2 W0, f32x2 em, const LifConstV3& c, f32x2 big, f32x2& U, f32x2& nmt) {
+  nmt = pk_sub_clamp01(w, (f32x2)(c.m1));                                    // clamp(w - 1 - K dt)
+  U = __builtin_elementwise_fma(Jm1 + W0, em, -W0);
+  return pk_mul_clamp01(U, big);
+}
+__device__ inline void lif_finish_spiking(f32x2 Jm1, f32x2& w, f32x2 U, f32x2 nmt, f32x2 spk, const LifConstV3& c, f32x2 big) {
+  f32x2 rc;
+  rc.x = __builtin_amdgcn_rcpf(Jm1.x);
+  rc.y = __builtin_amdgcn_rcpf(Jm1.y);
+  const f32x2 omu = __builtin_elementwise_fma(-U, rc, (f32x2)(1.0f));       // 1 - (V - 1) / (J - 1)
+  f32x2 lg2;
+  lg2.x = __builtin_amdgcn_logf(omu.x);
+  lg2.y = __builtin_amdgcn_logf(omu.y);
+  const f32x2 nu = pk_fma_clamp01_trans_vvs(lg2, (f32x2)(c.ktau_ln2), (f32x2)(c.ktau_ref));
+  const f32x2 Wn = pk_fma_clamp01_vs_negv(spk, big, U);
+  w = __builtin_elementwise_fma(spk, nu, Wn + nmt);
+}
+__device__ inline void lif_finish_silent(f32x2& w, f32x2 U, f32x2 nmt) {
+  f32x2 Wn;
+  asm("v_pk_mul_f32 %0, %1, -1.0 op_sel_hi:[1,0] clamp" : "=v"(Wn) : "v"(U));          // clamp(-U)
+  w = Wn + nmt;
+}
 __device__ inline f32x2 lif_input_part(f32x2 Jm1, f32x2& w, f32x2 W0, f32x2 em, const LifConstV3& c, f32x2 big) {
   const f32x2 nmt = pk_sub_clamp01(w, (f32x2)(c.m1));                        // clamp(w - 1 - K dt)
   const f32x2 U = __builtin_elementwise_fma(Jm1 + W0, em, -W0);
@@ -394,9 +421,6 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
     }
   }
 
-#ifndef SSN_BLOCK_IL
-#define SSN_BLOCK_IL 2
-#endif
   constexpr int ILE = F32 ? (SSN_BLOCK_IL < NG ? SSN_BLOCK_IL : NG) : 1;      // groups stepped side by side (see the time loop)
   G en[ILE][LDSW > 0 ? LDSW : 1];            // ENC_LDS: encoders (and bias) of the groups about to be processed
   if constexpr (ENC_LDS) {
@@ -409,6 +433,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
   unsigned long long bst[5] = {0, 0, 0, 0, 0}, bt0 = 0, bt1 = 0, bt2 = 0, bt3 = 0, bt4 = 0, bt5 = 0, bm0 = 0, br0 = 0;
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(bm0), "=s"(br0) :: "memory");
 #endif
+  unsigned int n_slots = 0, n_silent = 0;      // (wave-uniform: scalar registers)
   for (int j0 = 0; j0 < a.B; j0 += CH) {
     const int cn = min(CH, a.B - j0);
     __syncthreads();                         // previous chunk: every wave is past its last xs read / os write
@@ -493,11 +518,45 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
             for (int d = 0; d < LDSW; ++d) en[u][d] = *lds_group(d, gn);
           }
         }
+#ifndef SSN_BLOCK_SKIP
+#define SSN_BLOCK_SKIP 1
+#endif
+        // f32: a wave's neurons of this round are often ALL silent - the host deals neurons to (wave, round) slots by the part
+        // of the oscillator's cycle in which they can fire (Sim::reorder_block_neurons), so that whole slots fall silent together -
+        // and a silent slot needs neither the spike time (two v_rcp, two v_log and two packed operations per neuron pair) nor
+        // the decode: 6 of a pair's 22 packed and all 4 of its transcendental instructions.  The branch is wave-uniform.
+        bool skip_decode = false;
+        if constexpr (F32 && SSN_BLOCK_SKIP != 0) {
+          ++n_slots;
+          f32x2 Uu[IL], nm[IL];
+          f32x2 any2 = {0.0f, 0.0f};
+#pragma unroll
+          for (int u = 0; u < IL; ++u) {
+            const int g = g0 + u < NG ? g0 + u : NG - 1;
+            f32x2 W0, em;
+            lif_state_part(s[g], lc, W0, em);
+            spk[u] = lif_spike_test(J[u], s[g], W0, em, lc, big, Uu[u], nm[u]);
+            if (g0 + u < NG) any2 += spk[u];
+          }
+          if (__builtin_amdgcn_ballot_w64(any2.x + any2.y != 0.0f) != 0ull) {
+#pragma unroll
+            for (int u = 0; u < IL; ++u)
+              if (g0 + u < NG) lif_finish_spiking(J[u], s[g0 + u], Uu[u], nm[u], spk[u], lc, big);
+          } else {
+#pragma unroll
+            for (int u = 0; u < IL; ++u)
+              if (g0 + u < NG) lif_finish_silent(s[g0 + u], Uu[u], nm[u]);
+            skip_decode = true;
+            ++n_silent;
+          }
+        }
 #pragma unroll
         for (int u = 0; u < IL; ++u) {
           const int g = g0 + u;
           if (g >= NG) continue;
-          if constexpr (F32) {
+          if constexpr (F32 && SSN_BLOCK_SKIP != 0) {
+            // (stepped above)
+          } else if constexpr (F32) {
             f32x2 W0, em;
             lif_state_part(s[g], lc, W0, em);
             spk[u] = lif_input_part(J[u], s[g], W0, em, lc, big);
@@ -528,6 +587,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
           // the state word is final HERE: without this the compiler sinks the rcp / log half of every group's step to the
           // end of the timestep and keeps its operands live until then
           if constexpr (F32) asm volatile("" : "+v"(s[g]));
+          if (skip_decode) continue;                 // (no lane of the wave spiked: every product below would add +0)
 #pragma unroll
           for (int r = 0; r < DOUT; ++r) {           // spk is 0 or 1: exact add
             if constexpr (F32) accg[r] = __builtin_elementwise_fma(spk[u], dc[g][r], accg[r]);
@@ -648,6 +708,12 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
     }
   }
 #endif
+  if constexpr (F32 && SSN_BLOCK_SKIP != 0) {
+    if (lane == 0 && a.slot_stats) {
+      atomicAdd(a.slot_stats, (unsigned long long)n_slots);
+      atomicAdd(a.slot_stats + 1, (unsigned long long)n_silent);
+    }
+  }
   __syncthreads();
   if (member == 0) {                         // last chunk's decoded rows
     const int j0 = (a.B - 1) / CH * CH, cn = a.B - j0;

@@ -81,6 +81,10 @@ struct Buf {
   // spike-sparse decoders (k_spmv_partial): logical [rows][cols] stored neuron-major [cols][ldt]
   bool transposed = false;
   int64_t ldt = 0;
+  // neuron order on the device (whole-block kernel, Sim::reorder_block_neurons): column c of the rows of ensemble k holds the
+  // neuron perm[k * cols + c] of the caller's order; perm_rows = rows per ensemble.  Empty: the caller's order.
+  std::shared_ptr<std::vector<int32_t>> perm;
+  int perm_rows = 1;
 };
 
 enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_DFT, IT_VECOPS, IT_GRID_LHS, IT_GRID_GEMM, IT_ARGMAX_PART, IT_ROUND };
@@ -354,6 +358,18 @@ struct Sim final : ssn_sim {
 
   // host [rows][cols] double -> device layout of buffer b
   int upload_buf(Buf& b, const double* src) {
+    std::vector<double> ordered;
+    if (b.perm) {                      // the device's neuron order (columns permuted within every ensemble's rows)
+      ordered.resize((size_t)(b.rows * b.cols));
+      const int32_t* pm = b.perm->data();
+      for (int64_t r = 0; r < b.rows; ++r) {
+        const int32_t* pk = pm + (r / b.perm_rows) * b.cols;
+        const double* in = src + r * b.cols;
+        double* out = ordered.data() + r * b.cols;
+        for (int64_t c = 0; c < b.cols; ++c) out[c] = in[pk[c]];
+      }
+      src = ordered.data();
+    }
     if (b.transposed) {
       T* tmp = nullptr;
       HIPCHK(hipMalloc((void**)&tmp, (size_t)(b.rows * b.ld) * sizeof(T)));
@@ -381,6 +397,21 @@ struct Sim final : ssn_sim {
   }
 
   int download_buf(Buf& b, double* dst) {
+    if (b.perm) {                      // back to the caller's neuron order
+      std::shared_ptr<std::vector<int32_t>> pm = b.perm;
+      b.perm.reset();
+      std::vector<double> dev((size_t)(b.rows * b.cols));
+      const int rc = download_buf(b, dev.data());
+      b.perm = pm;
+      CHK(rc);
+      for (int64_t r = 0; r < b.rows; ++r) {
+        const int32_t* pk = pm->data() + (r / b.perm_rows) * b.cols;
+        const double* in = dev.data() + r * b.cols;
+        double* out = dst + r * b.cols;
+        for (int64_t c = 0; c < b.cols; ++c) out[pk[c]] = in[c];
+      }
+      return SSN_OK;
+    }
     if (b.transposed) {
       T* tmp = nullptr;
       HIPCHK(hipMalloc((void**)&tmp, (size_t)(b.rows * b.ld) * sizeof(T)));
@@ -884,6 +915,80 @@ struct Sim final : ssn_sim {
     return SSN_OK;
   }
 
+  // Neuron order for the whole-block kernel (f32).  k_ens_block leaves out the spike-time arithmetic and the decode of a
+  // (wave, round) slot - 64 lanes x SSN_BLOCK_IL neuron pairs - in which no neuron spikes (ssn_block.hpp).  With neurons in
+  // sampling order some neuron of every slot always spikes; so the neurons of each ensemble are dealt to the slots by WHEN they
+  // can fire.  For the oscillator ensembles (reference pathintegration.py:162-166: 3-D, state on a circle in the plane of the
+  // first two dimensions, third dimension the frequency input) neuron i is driven above threshold while
+  //   rho_i cos(theta - phi_i) > 1 - bias_i      (rho_i, phi_i: its scaled encoder in that plane; theta: the oscillator's phase)
+  // i.e. always (class 0), never (class 2), or for theta within alpha_i = acos((1 - bias_i) / rho_i) of phi_i (class 1).  Class 1
+  // is cut into bands of similar alpha and sorted by phi inside a band: a slot then holds neurons of one sector and falls
+  // silent when the phase is elsewhere.  Any order is a valid order - sums over an ensemble's neurons do not depend on it beyond
+  // rounding - so the heuristic only decides how often the shortcut applies (other 3-D ensembles: rarely, harmlessly).  The
+  // permutation lives in the buffers' upload / download (Buf::perm): callers keep seeing their own order.
+  int reorder_block_neurons(const ssn_model_desc* m, const ssn_op_desc& eo, int nthr, int npt) {
+    const int64_t K = eo.i[1], n = eo.i[2], din = eo.i[3], dout = eo.i[4];
+    if (din != 3 || n < 256) return SSN_OK;
+    const double* enc = (const double*)m->buffers[eo.i[5]].data;        // [K][din][n]
+    const double* bias = (const double*)m->buffers[eo.i[6]].data;       // [K][n]
+    // positions of the ensemble's row in slot order: slot (round j, wave w) = positions of the groups j * IL ... j * IL + IL - 1
+    // at the wave's 128 columns, group after group (neuron index of (group g, thread t, component c) = (g * nthr + t) * 2 + c)
+    const int ng = npt / 2, il = std::min<int>(SSN_BLOCK_IL, ng), waves = nthr / 64;
+    std::vector<int32_t> pos;
+    pos.reserve((size_t)n);
+    for (int j = 0; j * il < ng; ++j)
+      for (int w = 0; w < waves; ++w)
+        for (int u = 0; u < il && j * il + u < ng; ++u)
+          for (int q = 0; q < 128; ++q) {
+            const int64_t p = ((int64_t)(j * il + u) * nthr + w * 64) * 2 + q;
+            if (p < n) pos.push_back((int32_t)p);
+          }
+    if ((int64_t)pos.size() != n) return SSN_OK;                        // (a variant this layout does not describe: keep the order)
+    auto perm = std::make_shared<std::vector<int32_t>>((size_t)(K * n));
+    struct Key { int cls; double a, phi; int32_t i; };
+    std::vector<Key> keys((size_t)n);
+    const int slot = 128 * il;
+    for (int64_t k = 0; k < K; ++k) {
+      const double* e0 = enc + (k * din + 0) * n; const double* e1 = enc + (k * din + 1) * n; const double* b = bias + k * n;
+      int n1 = 0;
+      for (int64_t i = 0; i < n; ++i) {
+        const double rho = std::hypot(e0[i], e1[i]), mth = 1.0 - b[i];
+        Key& q = keys[(size_t)i];
+        q.i = (int32_t)i; q.phi = std::atan2(e1[i], e0[i]);
+        if (!(rho > 0.0) || mth >= rho) { q.cls = 2; q.a = mth - rho; }
+        else if (mth <= -rho) { q.cls = 0; q.a = 0.0; }
+        else { q.cls = 1; q.a = std::acos(mth / rho); ++n1; }
+      }
+      // class 0 | class 1 by descending alpha | class 2 by how far below threshold
+      std::sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) {
+        if (x.cls != y.cls) return x.cls < y.cls;
+        if (x.cls == 1 && x.a != y.a) return x.a > y.a;
+        if (x.cls == 2 && x.a != y.a) return x.a < y.a;
+        return x.i < y.i;
+      });
+      // bands of class 1: whole slots each, about four bands; inside a band by phi
+      size_t lo = 0;
+      while (lo < keys.size() && keys[lo].cls == 0) ++lo;
+      const size_t hi = lo + (size_t)n1;
+      const size_t band = std::max<size_t>(slot, ((size_t)n1 / 4 + slot - 1) / slot * slot);
+      for (size_t s0 = lo; s0 < hi; s0 += band)
+        std::sort(keys.begin() + (long)s0, keys.begin() + (long)std::min(hi, s0 + band), [](const Key& x, const Key& y) {
+          return x.phi != y.phi ? x.phi < y.phi : x.i < y.i;
+        });
+      int32_t* pk = perm->data() + k * n;
+      for (int64_t r = 0; r < n; ++r) pk[pos[(size_t)r]] = keys[(size_t)r].i;
+    }
+    struct Target { int64_t id; int rows; };
+    for (const Target t : {Target{eo.i[5], (int)din}, Target{eo.i[6], 1}, Target{eo.i[7], (int)dout}, Target{eo.i[9], 1}, Target{eo.i[10], 1}}) {
+      Buf& b = bufs[(size_t)t.id];
+      if (b.cols != n) return fail(SSN_EINVAL, "ensemble array buffer %lld has %lld columns, expected %lld", (long long)t.id, (long long)b.cols, (long long)n);
+      b.perm = perm; b.perm_rows = t.rows;
+      if (b.packed == 2) continue;                                      // (the refractory view of the voltage buffer: no storage of its own to re-upload)
+      CHK(upload_buf(b, (const double*)m->buffers[t.id].data));
+    }
+    return SSN_OK;
+  }
+
   // Core stage == one recurrent ensemble array (the path integrator's VCO array): x assembled in the
   // kernel prologue, decoded rows / synapse update / hand-off / step counter in one barrier-free finish
   // kernel.  Returns false (and plans nothing) when the core does not have that shape.
@@ -1027,6 +1132,13 @@ struct Sim final : ssn_sim {
       blk.dec_neuron_major = ea.fast == 1 ? 1 : 0;
       blk.np = ea.np;
       blk.P = split_P; blk.n_member = n_member; blk.xslots = nullptr; blk.xerr = nullptr;
+      {
+        unsigned long long* d_ss = nullptr;
+        if ((*rc = dmalloc(&d_ss, 16)) != SSN_OK) return true;
+        fused_bufs.push_back((void*)d_ss);
+        hipMemset(d_ss, 0, 16);
+        blk.slot_stats = d_ss;
+      }
       if (split_P > 1) {
         unsigned int* d_x = nullptr; int* d_e = nullptr;
         if ((*rc = dmalloc(&d_x, (int64_t)3 * K * 64 * 4)) != SSN_OK) return true;
@@ -1038,6 +1150,8 @@ struct Sim final : ssn_sim {
       dom_units = (int64_t)ea.K * ea.n * block;
       dom_bytes = (double)dom_units * (ea.din + ea.dout + 5) * sizeof(T);
       fused_core = fused_block = true;
+      if (sizeof(T) == 4 && split_P == 1 && !(getenv("SSN_BLOCK_SORT") && atoi(getenv("SSN_BLOCK_SORT")) == 0))
+        *rc = reorder_block_neurons(m, eo, blk_npt == 2 ? blk_threads : blk_tpb, blk_npt);
       return true;
     }
     // ---- plan B: [k_ensarray (fused prologue), k_ens_finish] ------------------------------------------
@@ -2965,6 +3079,7 @@ struct Sim final : ssn_sim {
     if (!pslots.empty()) HIPCHK(hipMemcpy(d_pslots, pslots.data(), pslots.size() * sizeof(ssn::ProbeSlot), hipMemcpyHostToDevice));
     dom_launches = 0; dom_ms = 0.0;
     for (int t = 0; t < N_ITEM_TYPES; ++t) { type_ms[t] = 0.0; type_launches[t] = 0; }
+    if (fused_block && blk.slot_stats) HIPCHK(hipMemset(blk.slot_stats, 0, 16));
     return SSN_OK;
   }
 
@@ -3090,6 +3205,12 @@ struct Sim final : ssn_sim {
     out->block_threads = fused_block ? blk.threads : 0;
     out->block_members = fused_block ? std::max(1, blk.P) : 0;
     out->batch_products_skipped = batch_skipped;
+    out->block_slots = 0; out->block_slots_silent = 0;
+    if (fused_block && blk.slot_stats) {
+      unsigned long long ss[2] = {0, 0};
+      hipSetDevice(device);
+      if (hipMemcpy(ss, blk.slot_stats, sizeof ss, hipMemcpyDeviceToHost) == hipSuccess) { out->block_slots = (int64_t)ss[0]; out->block_slots_silent = (int64_t)ss[1]; }
+    }
     out->fft_transforms = 0; out->fft_bluestein = 0;
     for (auto& it : items) if (it.type == IT_DFT) { out->fft_transforms += 1; out->fft_bluestein += it.dft.M > 0 ? 1 : 0; }
     return SSN_OK;
@@ -3211,6 +3332,6 @@ int ssn_device_count(void) {
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 const char* ssn_last_error(void) { return g_err.c_str(); }
-const char* ssn_version(void) { return "libssn_hip 0.7 (gfx950, ABI 6)"; }
+const char* ssn_version(void) { return "libssn_hip 0.8 (gfx950, ABI 7)"; }
 
 }  // extern "C"

@@ -129,8 +129,14 @@ struct BlockArgs {
   int n_member;        // neurons per member (a multiple of 4)
   unsigned int* xslots;   // [3 buffers][K][16 members][4 words], all words = the sentinel at launch (host memset)
   int* xerr;           // set to 1 by a member that waited too long for a partner (the launch then produced garbage)
+  unsigned long long* slot_stats;   // [2]: (wave, round) slots stepped / silent among them (f32; one atomic pair per wave and launch)
 };
 constexpr unsigned int BLOCK_XCHG_SENTINEL = 0x7fc0deadu;      // a NaN payload no sum produces
+// neuron groups of a thread that k_ens_block steps side by side (ssn_block.hpp; the host deals neurons to (wave, round) slots
+// accordingly: Sim::reorder_block_neurons)
+#ifndef SSN_BLOCK_IL
+#define SSN_BLOCK_IL 2
+#endif
 
 // k_dft: the real-DFT maps of a circular-convolution network (reference binding.py:23-74) as a mixed-radix FFT.
 struct DftArgs {

@@ -16,6 +16,7 @@ to a kernel (``node.native``).  Errors from the library surface as ``SimulationE
 ``BuildError`` (nengo's exception names).
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -261,6 +262,13 @@ class Simulator:
         self._fetched = {}
         self._prepared_until = 0
         self.n_steps = 0
+        # SSN_TRACE_RUN=1: (phase, start, end, detail) of every host-side phase of a pipelined run, perf_counter seconds
+        # (tools/bench_end_to_end.py prints the timeline)
+        self.trace = [] if os.environ.get("SSN_TRACE_RUN") else None
+
+    def _tr(self, name, t0, detail=None):
+        if self.trace is not None:
+            self.trace.append((name, t0, time.perf_counter(), detail))
 
     # -- plumbing ------------------------------------------------------------------------------
     def _check(self, rc, build=False):
@@ -398,11 +406,14 @@ class Simulator:
                 # the device steps chunk k (ssn_run_steps releases the GIL); tables are uploaded between chunks
                 if getattr(self, "_uncollected", False):
                     self._collect()
+                t_tab = time.perf_counter()
                 self._check(self._lib.ssn_reserve_probes(self._h, steps))
+                self._tr("reserve", t_tab)
                 self._fetched = {}
                 self._reserved_until = self.n_steps + steps
                 t_tab = time.perf_counter()
                 pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_FIRST, steps))
+                self._tr("tabulate first", t_tab, pipelined[1])
                 self._tab_rate = (time.perf_counter() - t_tab) / max(1, pipelined[1])      # seconds per timestep, host
                 self._dev_rate = None                                                        # ... device: known after the first chunk
                 if collect:
@@ -467,9 +478,11 @@ class Simulator:
             worker = None
             if pipelined is not None:
                 first, n_tab, tabs = pipelined
+                t_up = time.perf_counter()
                 for tid, (rows, idx) in enumerate(tabs):
                     self._check(self._lib.ssn_set_table(self._h, tid, rows.ctypes.data, rows.shape[0], self.model.tables[tid]["width"],
                                                         idx.ctypes.data, idx.size, first))
+                self._tr("upload tables", t_up, n_tab)
                 self._prepared_until = first + n_tab
                 chunk = min(chunk, n_tab)
                 nxt = self.n_steps + chunk
@@ -492,6 +505,7 @@ class Simulator:
                 chunk = min(chunk, p["every"] - r if r else p["every"])
             t_dev = time.perf_counter()
             self._check(self._lib.ssn_run_steps(self._h, chunk, int(profile)))
+            self._tr("run", t_dev, chunk)
             if chunk >= self.PIPELINE_MIN:
                 self._dev_rate = (time.perf_counter() - t_dev) / chunk
             self.n_steps += chunk
@@ -499,11 +513,15 @@ class Simulator:
             if getattr(self, "_bulk", None) is not None and done < steps:
                 import threading
                 if collector is not None:
+                    t_j = time.perf_counter()
                     collector.join()
+                    self._tr("wait for read-back", t_j)
                 collector = self._collector = threading.Thread(target=self._collect_bulk)
                 collector.start()
             if worker is not None:
+                t_j = time.perf_counter()
                 worker.join()
+                self._tr("wait for tabulation", t_j)
                 self._tab_worker = None
                 if "r" not in box:
                     raise fe.SimulationError("evaluating the input nodes for the next chunk failed") from box.get("e")
@@ -512,7 +530,9 @@ class Simulator:
                 if self.n_steps != pipelined[0]:          # a weight-probe boundary cut the chunk short: re-tabulate from here
                     pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_FIRST, steps - done))
         if collector is not None:
+            t_j = time.perf_counter()
             collector.join()
+            self._tr("wait for read-back", t_j)
         self._collector = None
         if getattr(self, "_bulk", None) is not None:
             self._collect_bulk()                     # the last chunk
@@ -537,6 +557,7 @@ class Simulator:
 
     def _collect_bulk(self):
         """Fetch the samples completed so far into the per-probe arrays of a pipelined run (helper thread)."""
+        t_c = time.perf_counter()
         try:
             for key, arr in self._bulk.items():
                 kind, j, p = self._probe_index[key]
@@ -548,6 +569,7 @@ class Simulator:
                 self._fetched[key] = n
         except BaseException as e:               # noqa: BLE001 - surfaced by run_steps on the caller's thread
             self._bulk_error = e
+        self._tr("read-back", t_c)
 
     def _collect(self):
         """Fetch the probe samples produced since the last fetch (incremental within a reservation)."""

@@ -87,7 +87,10 @@ def test_config5_full_size_properties(Simulator):
     assert d == 1801
     path, vels = H.make_random_path(10.0, limit=0.1, seed=0, domain_dim=3)
     path = path.copy()
-    path[:, 0] += 0.5 - path[0, 0]            # start at x0 = 0.5: grid rows of x0 > 0.2 lie beyond 2^32 bytes in the f32 table
+    # start at (0.5, 0.5, .): the grid's rows are numbered axis 1 first (np.meshgrid's 'xy' order, reference sspspace.py:424-466),
+    # and rows of x1 > 0.2 lie beyond 2^32 bytes in the f32 table
+    path[:, 0] += 0.5 - path[0, 0]
+    path[:, 1] += 0.5 - path[0, 1]
     sm = H.make_slam_model(space, path, vels, n_landmarks=20, pi_n_neurons=800, mem_n_neurons=10 * d, circonv_n_neurons=100,
                            view_rad=0.6)
     with sm.model:

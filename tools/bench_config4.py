@@ -1,6 +1,8 @@
 """BASELINE config 4 on ONE GPU: PathIntegration d = 4033 (n_rotates 24, n_scales 28 -> 2017 VCOs), n = 50 000 neurons
 per VCO = 1.0e8 LIF neurons (an 8-GPU configuration: 6 GB of parameters + state in f32).  No oracle at this size: the
-run is checked against the true SSP of the path.  usage: bench_config4.py [n_per_vco] [steps] [n_eval]"""
+run is checked against the true SSP of the path.  usage: bench_config4.py [n_per_vco] [steps] [n_eval] [ssp_dim]
+(ssp_dim given: HexagonalSSPSpace(ssp_dim=...) as the reference scripts construct it - 4033 yields d = 3751 = 25 x 25 scales
+x rotations, reference sspspace.py:683-686 - instead of the n_rotates = 24, n_scales = 28 space that really has 4033 dimensions)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,7 +13,7 @@ from sspslam_amd.simulator import Simulator
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 m_eval = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
-s = H.make_ssp_space(2, n_scales=28, n_rotates=24)
+s = H.make_ssp_space(2, int(sys.argv[4])) if len(sys.argv) > 4 else H.make_ssp_space(2, n_scales=28, n_rotates=24)
 print("ssp_dim", s.ssp_dim, flush=True)
 path, vels = H.make_random_path(10.0, limit=0.1, seed=0)
 pm = H.make_pathint_model(s, path, vels, n)

@@ -1,6 +1,7 @@
 """Where the wall time of a whole `sim.run(T)` + `sim.data[probe]` goes at config 2 (PCIe-inclusive rate):
 input tabulation + upload (prepare), the device run, probe read-back.  usage: bench_end_to_end.py [T]"""
 import os, sys, time
+os.environ["SSN_TRACE_RUN"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sspslam_amd import harness as H
@@ -43,3 +44,25 @@ out = sim.data[pm.probe]
 t2 = time.perf_counter()
 print("pipelined run_steps %.1f ms + data[probe] %.1f ms; helper-thread fetches: %s" %
       ((t1 - t0) * 1e3, (t2 - t1) * 1e3, ", ".join("%.1f-%.1f ms" % ((a - t0) * 1e3, (b - t0) * 1e3) for _, a, b in marks)), flush=True)
+
+
+# the library-side timeline of pipelined runs (Simulator.trace), with the harness's vectorised input nodes and with plain closures
+for label, strip in (("harness nodes (.table twins)", False), ("plain per-timestep closures", True)):
+    sim.reset()
+    sim.clear_probe_data()
+    saved = [tb["fn"] for tb in bm.tables]
+    if strip:
+        for tb in bm.tables:
+            tb["fn"] = (lambda f: (lambda t: f(t)))(tb["fn"])
+    for rep in range(2):
+        sim.reset(); sim.clear_probe_data()
+        sim.trace.clear()
+        t0 = time.perf_counter()
+        sim.run(T)
+        out = sim.data[pm.probe]
+        t1 = time.perf_counter()
+    for tb, f in zip(bm.tables, saved):
+        tb["fn"] = f
+    print("%s: %.1f ms end to end -> %.1f sim-s/wall-s" % (label, (t1 - t0) * 1e3, T / (t1 - t0)))
+    for name, a, b, detail in sim.trace:
+        print("   %7.2f .. %7.2f ms  (%6.2f)  %s%s" % ((a - t0) * 1e3, (b - t0) * 1e3, (b - a) * 1e3, name, "" if detail is None else " [%s]" % detail))
