@@ -596,11 +596,14 @@ def pathint_main(args):
                 out["roofline"] = {"bound": "hbm", "achieved": round(streaming_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(streaming_gbs / HBM_PEAK_GBS, 4), **common}
         sim._collect()
-        gpu_probe = sim.data[pm.probe]
+        gpu_probe_view = sim.data[pm.probe]
+        gpu_probe = np.array(gpu_probe_view[:max(1, args.cpu_warmup + args.cpu_steps)])      # (the parity window; the rest is released)
         # ---- end to end: what the reference's timer wraps (run_pathint.py:160-165) + the read-back its next lines do -----
         if not args.no_end_to_end:
             T = args.steps * args.block * dt
             e2e = {}
+            del gpu_probe_view
+            data = None
             for label, strip in (("warm_up", False), ("harness_nodes", False), ("plain_closures", True)):
                 # (the first pass is untimed: it pays the first-use allocations of the read-back path - pinned staging, one
                 #  array per probe - as the W warm-up blocks of the timed region pay the step loop's)
@@ -616,7 +619,10 @@ def pathint_main(args):
                 for tb, f in zip(model.tables, saved):
                     tb["fn"] = f
                 assert data.shape[0] == args.steps * args.block
+                # the result is released OUTSIDE the timed region (the pass before this change timed `data = ...` while the
+                # previous pass's 162 MB array was still bound to the name: ~9 ms of munmap inside the timer)
                 sim.clear_probe_data()
+                data = None
             out["value_end_to_end"] = e2e["harness_nodes"]
             out["end_to_end"] = {"unit": "sim-sec/wall-sec", "simulated_seconds": T, "value": e2e["harness_nodes"],
                                  "value_plain_closures": e2e["plain_closures"],

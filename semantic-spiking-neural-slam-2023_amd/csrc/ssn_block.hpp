@@ -519,14 +519,32 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
           }
         }
 #ifndef SSN_BLOCK_SKIP
-#define SSN_BLOCK_SKIP 1
+#define SSN_BLOCK_SKIP 2
 #endif
         // f32: a wave's neurons of this round are often ALL silent - the host deals neurons to (wave, round) slots by the part
         // of the oscillator's cycle in which they can fire (Sim::reorder_block_neurons), so that whole slots fall silent together -
         // and a silent slot needs neither the spike time (two v_rcp, two v_log and two packed operations per neuron pair) nor
         // the decode: 6 of a pair's 22 packed and all 4 of its transcendental instructions.  The branch is wave-uniform.
-        bool skip_decode = false;
-        if constexpr (F32 && SSN_BLOCK_SKIP != 0) {
+        // SSN_BLOCK_SKIP == 2: slots AT REST are left out altogether.  A neuron whose input current is <= 0 and whose state word is
+        // exactly 1 (V = 0, not refractory) leaves the step as it entered it, bit for bit: W0 = 1, the integration time is a full
+        // step, U = J * em - 1 < 0, no spike, Wn = clamp(1 - J * em) = 1, nmt = 0, w' = 1 - and adds +0 to every decoded sum.  The
+        // test costs 8 packed / plain instructions per round: r = clamp(J) + (w - 1)^2 over the slot's neurons is 0 only then.
+        bool at_rest = false;
+        if constexpr (F32 && SSN_BLOCK_SKIP == 2) {
+          ++n_slots;
+          f32x2 r2 = {0.0f, 0.0f};
+#pragma unroll
+          for (int u = 0; u < IL; ++u) {
+            if (g0 + u >= NG) continue;
+            f32x2 pj;
+            asm("v_pk_add_f32 %0, %1, 1.0 op_sel_hi:[1,0] clamp" : "=v"(pj) : "v"(J[u]));      // clamp(J): J[] holds J - 1
+            const f32x2 q = s[g0 + u] - 1.0f;
+            r2 += __builtin_elementwise_fma(q, q, pj);
+          }
+          at_rest = __builtin_amdgcn_ballot_w64(__builtin_bit_cast(unsigned long long, r2) != 0ull) == 0ull;
+          if (at_rest) ++n_silent;
+        }
+        if constexpr (F32 && SSN_BLOCK_SKIP == 1) {
           ++n_slots;
           f32x2 Uu[IL], nm[IL];
           f32x2 any2 = {0.0f, 0.0f};
@@ -542,19 +560,27 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
 #pragma unroll
             for (int u = 0; u < IL; ++u)
               if (g0 + u < NG) lif_finish_spiking(J[u], s[g0 + u], Uu[u], nm[u], spk[u], lc, big);
+            // the decode belongs to this branch (spk is 0 or 1: exact adds) - the scheduler interleaves its independent FMAs
+            // with the rcp -> log chains above; behind the branch the compiler turned a skipped decode into 80 v_cndmask
+#pragma unroll
+            for (int u = 0; u < IL; ++u) {
+              if (g0 + u >= NG) continue;
+#pragma unroll
+              for (int r = 0; r < DOUT; ++r) accg[r] = __builtin_elementwise_fma(spk[u], dc[g0 + u][r], accg[r]);
+            }
           } else {
 #pragma unroll
             for (int u = 0; u < IL; ++u)
               if (g0 + u < NG) lif_finish_silent(s[g0 + u], Uu[u], nm[u]);
-            skip_decode = true;
             ++n_silent;
           }
         }
+        if (!at_rest) {
 #pragma unroll
         for (int u = 0; u < IL; ++u) {
           const int g = g0 + u;
           if (g >= NG) continue;
-          if constexpr (F32 && SSN_BLOCK_SKIP != 0) {
+          if constexpr (F32 && SSN_BLOCK_SKIP == 1) {
             // (stepped above)
           } else if constexpr (F32) {
             f32x2 W0, em;
@@ -587,12 +613,13 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
           // the state word is final HERE: without this the compiler sinks the rcp / log half of every group's step to the
           // end of the timestep and keeps its operands live until then
           if constexpr (F32) asm volatile("" : "+v"(s[g]));
-          if (skip_decode) continue;                 // (no lane of the wave spiked: every product below would add +0)
+          if constexpr (F32 && SSN_BLOCK_SKIP == 1) continue;      // (decoded inside the spiking branch above)
 #pragma unroll
           for (int r = 0; r < DOUT; ++r) {           // spk is 0 or 1: exact add
             if constexpr (F32) accg[r] = __builtin_elementwise_fma(spk[u], dc[g][r], accg[r]);
             else accg[r] = fma(spk[u], dc[g][r], accg[r]);
           }
+        }
         }
 #ifndef SSN_BLOCK_NO_SCHED_BARRIER
         if constexpr (F32) __builtin_amdgcn_sched_barrier(0);

@@ -194,6 +194,8 @@ struct Sim final : ssn_sim {
   std::vector<RoundLaunch> round_launches;
   std::vector<Launch> launch_list;            // one timestep
   std::vector<Launch> graph_list;             // steps_per_graph timesteps, software-pipelined (empty: replay launch_list)
+  std::vector<Launch> phase2_list;            // neuron-sharded models: the updates of timestep s and timestep s + 1 up to its exchange,
+                                              // planned as ONE set of rounds (empty: the two halves one after the other)
   int graph_rounds = 0;
   std::vector<void*> round_bufs;
 
@@ -2276,6 +2278,31 @@ struct Sim final : ssn_sim {
       launches_per_step = ((int)graph_list.size() + G - 1) / G;       // (average of the replayed sequence)
     }
 
+    // ---- neuron-sharded models: what runs between two exchanges - the updates of timestep s (phase 1) and timestep s + 1 up to
+    // its exchange (phase 0) - as ONE set of rounds.  A phase-0 operator of s + 1 waits only for the phase-1 operators whose
+    // results it reads: table rows, the encoder products of tabulated inputs and whatever else does not hang on a filter state
+    // start beside the filter updates, PES and Voja instead of behind them.  The clock is read with an offset (phase-0
+    // instances: + 1) and advanced once behind the last round, as in the pipelined step graph.
+    phase2_list.clear();
+    if (phased && !(flags & 8388608) && !getenv("SSN_PHASE2_SEQUENTIAL")) {
+      std::vector<std::vector<Rng>> acc_p(units.size());
+      for (size_t u = 0; u < units.size(); ++u) { if (units[u].mop >= 0) micro_access(acc_p[u], mops[(size_t)units[u].mop], false); else acc_p[u] = units[u].acc; }
+      std::vector<Inst> comb;
+      std::vector<std::vector<int>> chains_comb;
+      int nr = 0;
+      for (int ph = 1; ph >= 0; --ph)
+        for (size_t u = 0; u < units.size(); ++u) {
+          if (units[u].phase != ph) continue;
+          if (units[u].mop >= 0 && mops[(size_t)units[u].mop].kind == ssn::M_STEP_END) continue;
+          const int r = place(comb, 0, (int)u, acc_p, 0, chains_comb);
+          comb.back().sub = ph == 0 ? 1 : 0;
+          nr = std::max(nr, r + 1);
+        }
+      emit(comb, nr, phase2_list, chains_comb);
+      if (getenv("SSN_DEBUG_PLAN")) fprintf(stderr, "[ssn] phased plan: %zu launches per timestep apart (phase 0 + phase 1), %zu with the updates of s and the head of s + 1 planned together\n", launch_list.size(), phase2_list.size());
+      launches_per_step = (int)phase2_list.size();
+    }
+
     T* d_arena = nullptr; ssn::GlueBlock* d_map = nullptr;
     CHK(dmalloc(&d_arena, (int64_t)arena.size() + 16));
     round_bufs.push_back(d_arena);
@@ -2735,6 +2762,15 @@ struct Sim final : ssn_sim {
   }
 
   hipError_t launch_phase(int phase) {
+    if (phase == 2) {          // updates of timestep s + timestep s + 1 up to its exchange
+      if (round_mode && !phase2_list.empty()) {
+        for (const Launch& l : phase2_list) { hipError_t e = launch_one(l); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, 1LL);
+        return hipGetLastError();
+      }
+      hipError_t e = launch_phase(1);
+      return e == hipSuccess ? launch_phase(0) : e;
+    }
     if (round_mode) {
       for (const Launch& l : launch_list) {
         if (l.phase != phase) continue;
@@ -2756,8 +2792,7 @@ struct Sim final : ssn_sim {
       if (fused_core || core_empty) return fail(SSN_EUNSUPPORTED, "neuron-sharded models run on the generic per-timestep plan");
       for (int h = 0; h < 3; ++h) {        // [2]: phase 1 of a timestep + phase 0 of the next one in one launch
         HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        hipError_t e = launch_phase(h == 2 ? 1 : h);
-        if (h == 2 && e == hipSuccess) e = launch_phase(0);
+        hipError_t e = launch_phase(h);
         hipError_t e2 = hipStreamEndCapture(stream, &phase_graph[h]);
         HIPCHK(e);
         HIPCHK(e2);
@@ -2837,8 +2872,7 @@ struct Sim final : ssn_sim {
       HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
       hipError_t e = hipSuccess;
       if (h >= 1 && buf) e = exchange_copy_async(buf, false, stream);
-      if (e == hipSuccess) e = launch_phase(h == 2 ? 1 : h);
-      if (h == 2 && e == hipSuccess) e = launch_phase(0);
+      if (e == hipSuccess) e = launch_phase(h);
       if (h != 1 && buf && e == hipSuccess) e = exchange_copy_async(buf, true, stream);
       hipError_t e2 = hipStreamEndCapture(stream, &async_graph[h]);
       HIPCHK(e);

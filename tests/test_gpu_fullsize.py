@@ -175,6 +175,6 @@ def test_long_window_config3_f32_tracks_f64(Simulator):
     rec32, _ = H.map_recall(sm.ssp_space, sm.lm_space, model.params[am.memory], fe.LIF(), W["f32"])
     rec64, _ = H.map_recall(sm.ssp_space, sm.lm_space, model.params[am.memory], fe.LIF(), W["f64"])
     nr = np.linalg.norm(rec64, axis=1)
-    seen = nr > 1e-3 * nr.max()
+    seen = nr > 0.05 * nr.max()            # (a landmark glimpsed for a few timesteps recalls a vector of norm ~1e-5: rounding noise)
     assert seen.any() and H.cosine_error(rec32[seen], rec64[seen]).max() < 1e-3
     assert _similarity(outs["f32"], sm.real_ssp[:steps])[200:].mean() > 0.9
