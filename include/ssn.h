@@ -224,6 +224,15 @@ int ssn_set_table(ssn_sim* sim, int32_t table_id, const double* rows, int64_t n_
 int ssn_set_table_device(ssn_sim* sim, int32_t table_id, const void* rows_dev, int64_t n_rows,
                          int64_t width, const int32_t* idx, int64_t n_idx, int64_t first_step);
 
+/* The same in two halves for chunked runs (Simulator.run(T) over many chunks: the node closures of chunk k + 1 are evaluated
+ * while the device steps chunk k, reference run_pathint.py:160-165 times the whole of it): ssn_stage_table takes rows ALREADY in
+ * the simulator's dtype (float for SSN_F32, double for SSN_F64) and copies them by DMA into a second set of device buffers - it
+ * may be called from another host thread while ssn_run_steps is in flight; ssn_commit_tables, called between two runs, makes
+ * every staged table the current one.  (ABI 7) */
+int ssn_stage_table(ssn_sim* sim, int32_t table_id, const void* rows_typed, int64_t n_rows, int64_t width,
+                    const int32_t* idx, int64_t n_idx, int64_t first_step);
+int ssn_commit_tables(ssn_sim* sim);
+
 /* Make room for the probe samples of the next n_steps (drops samples already read). */
 int ssn_reserve_probes(ssn_sim* sim, int64_t n_steps);
 /* Simulator.run_steps(n): blocking. profile = 1 times every dominant-kernel launch with events; profile = 2 times

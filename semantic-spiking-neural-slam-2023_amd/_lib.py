@@ -68,6 +68,8 @@ EXPORTS = {
     "ssn_reset": (C.c_int, [C.c_void_p]),
     "ssn_set_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64]),
     "ssn_set_table_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64]),
+    "ssn_stage_table": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64]),
+    "ssn_commit_tables": (C.c_int, [C.c_void_p]),
     "ssn_reserve_probes": (C.c_int, [C.c_void_p, C.c_int64]),
     "ssn_run_steps": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32]),
     "ssn_read_probe": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64]),

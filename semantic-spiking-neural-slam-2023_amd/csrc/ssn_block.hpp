@@ -220,8 +220,14 @@ __device__ inline f32x2 lif_input_part(f32x2 Jm1, f32x2& w, f32x2 W0, f32x2 em, 
   f32x2 lg2;
   lg2.x = __builtin_amdgcn_logf(omu.x);
   lg2.y = __builtin_amdgcn_logf(omu.y);
-  const f32x2 nu = pk_fma_clamp01_trans_vvs(lg2, (f32x2)(c.ktau_ln2), (f32x2)(c.ktau_ref));
-  const f32x2 Wn = pk_fma_clamp01_vs_negv(spk, big, U);
+  // Wn = clamp(spk * 2^100 - U) and nu = clamp(lg2 * K tau_rc ln 2 + K tau_ref) as ONE asm statement, Wn first: the wait state a
+  // non-transcendental reader of v_log's result needs (see pk_fma_clamp01_trans_vvs) is filled by an instruction that has to be
+  // issued anyway instead of an s_nop - 20 s_nop per wave and timestep at 20 neurons per lane (round 4)
+  f32x2 nu, Wn;
+  asm("v_pk_fma_f32 %0, %2, %3, %4 neg_lo:[0,0,1] neg_hi:[0,0,1] clamp\n\t"
+      "v_pk_fma_f32 %1, %5, %6, %7 clamp"
+      : "=&v"(Wn), "=v"(nu)
+      : "v"(spk), "s"(big), "v"(U), "v"(lg2), "v"((f32x2)(c.ktau_ln2)), "s"((f32x2)(c.ktau_ref)));
   w = __builtin_elementwise_fma(spk, nu, Wn + nmt);
   return spk;
 }
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
           }
         }
 #ifndef SSN_BLOCK_SKIP
-#define SSN_BLOCK_SKIP 2
+#define SSN_BLOCK_SKIP 0      // (1 and 2 were measured slower than the plain loop in round 4: see the comments below and DESIGN.md section 3.1)
 #endif
         // f32: a wave's neurons of this round are often ALL silent - the host deals neurons to (wave, round) slots by the part
         // of the oscillator's cycle in which they can fire (Sim::reorder_block_neurons), so that whole slots fall silent together -

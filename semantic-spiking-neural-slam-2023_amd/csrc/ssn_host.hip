@@ -87,7 +87,8 @@ struct Buf {
   int perm_rows = 1;
 };
 
-enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_DFT, IT_VECOPS, IT_GRID_LHS, IT_GRID_GEMM, IT_ARGMAX_PART, IT_ROUND };
+enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_DFT, IT_VECOPS, IT_GRID_LHS, IT_GRID_GEMM, IT_ARGMAX_PART, IT_ROUND,
+                IT_GRID_DOT };      // (a body of the round grid only)
 
 }  // namespace
 
@@ -96,6 +97,8 @@ struct ssn_sim {
   virtual int reset() = 0;
   virtual int set_table(int id, const double* rows, const void* rows_dev, int64_t n_rows, int64_t width,
                         const int32_t* idx, int64_t n_idx, int64_t first_step) = 0;
+  virtual int stage_table(int id, const void* rows_t, int64_t n_rows, int64_t width, const int32_t* idx, int64_t n_idx, int64_t first_step) = 0;
+  virtual int commit_tables() = 0;
   virtual int reserve_probes(int64_t n) = 0;
   virtual int run_steps(int64_t n, int profile) = 0;
   virtual int run_phase(int phase) = 0;
@@ -210,6 +213,12 @@ struct Sim final : ssn_sim {
   std::vector<void*> table_rows;
   std::vector<int*> table_idx;
   std::vector<int64_t> table_rows_cap, table_idx_cap;
+  // staged tables (ssn_stage_table / ssn_commit_tables): the NEXT chunk's inputs arrive in a second set of buffers by DMA on the
+  // copy stream while the compute stream still reads the current ones; commit swaps the sets between two runs
+  struct Staged { void* rows = nullptr; int* idx = nullptr; int64_t rows_cap = 0, idx_cap = 0; bool valid = false;
+                  int64_t n_rows = 0, width = 0, n_idx = 0, first_step = 0; std::vector<int32_t> idx_host; };
+  std::vector<Staged> staged;
+  std::mutex stage_mutex;
   std::vector<ssn_probe_desc> probes;
   std::vector<ssn::ProbeSlot> pslots;
   ssn::ProbeSlot* d_pslots = nullptr;
@@ -262,6 +271,7 @@ struct Sim final : ssn_sim {
     for (auto& b : bufs) if (b.d) hipFree(b.d);
     for (auto p : table_rows) if (p) hipFree(p);
     for (auto p : table_idx) if (p) hipFree(p);
+    for (auto& g : staged) { if (g.rows) hipFree(g.rows); if (g.idx) hipFree(g.idx); }
     for (auto& s : pslots) if (s.data) hipFree(s.data);
     for (auto& it : items) if (it.type == IT_ENS && it.ens.partials) hipFree(it.ens.partials);
     for (auto p : scratch_bufs) if (p) hipFree(p);
@@ -620,6 +630,7 @@ struct Sim final : ssn_sim {
     table_idx.assign(m->n_tables, nullptr);
     table_rows_cap.assign(m->n_tables, 0);
     table_idx_cap.assign(m->n_tables, 0);
+    staged.resize((size_t)m->n_tables);
     CHK(dmalloc(&d_tables, std::max<int64_t>(1, m->n_tables) * (int64_t)sizeof(ssn::TableSlot)));
     if (m->n_tables) HIPCHK(hipMemcpy(d_tables, tables.data(), tables.size() * sizeof(ssn::TableSlot), hipMemcpyHostToDevice));
     probes.assign(m->probes, m->probes + m->n_probes);
@@ -1152,7 +1163,9 @@ struct Sim final : ssn_sim {
       dom_units = (int64_t)ea.K * ea.n * block;
       dom_bytes = (double)dom_units * (ea.din + ea.dout + 5) * sizeof(T);
       fused_core = fused_block = true;
-      if (sizeof(T) == 4 && split_P == 1 && !(getenv("SSN_BLOCK_SORT") && atoi(getenv("SSN_BLOCK_SORT")) == 0))
+      // (only worth anything with a kernel built with SSN_BLOCK_SKIP = 1 or 2 - both measured slower than the plain loop, round 4 -
+      //  so the neuron order is the caller's unless SSN_BLOCK_SORT=1 asks for the slot order)
+      if (sizeof(T) == 4 && split_P == 1 && getenv("SSN_BLOCK_SORT") && atoi(getenv("SSN_BLOCK_SORT")) == 1)
         *rc = reorder_block_neurons(m, eo, blk_npt == 2 ? blk_threads : blk_tpb, blk_npt);
       return true;
     }
@@ -1490,7 +1503,15 @@ struct Sim final : ssn_sim {
           const Buf& w = bufs[o.i[4]];
           const char* gmin = getenv("SSN_GRID_MIN_MB");
           const int64_t grid_min_bytes = (gmin ? atoll(gmin) : 64) << 20;
-          const bool grid_route = sizeof(T) == 4 && o.i[5] > 0 && !(flags & 524288) && o.i[2] * o.i[3] * (int64_t)sizeof(T) >= grid_min_bytes;
+          bool grid_route = sizeof(T) == 4 && o.i[5] > 0 && !(flags & 524288) && o.i[2] * o.i[3] * (int64_t)sizeof(T) >= grid_min_bytes;
+          // Round 4: a smaller grid (2-D, 10^4 rows: 40 MB of HBM stream per timestep at d = 1015) also goes through its factor
+          // tables when the step runs as rounds - as bodies of the round grid (no MFMA product: 10^4 dot products of length 2K
+          // from two L2-resident 100 x 2K tables), so nothing is launched on its own.  SSN_GRID_DOT_MIN_MB moves the threshold.
+          const char* dmin = getenv("SSN_GRID_DOT_MIN_MB");
+          const bool grid_dot = !grid_route && sizeof(T) == 4 && o.i[5] > 0 && !(flags & (524288 | 2097152)) && o.i[2] < 65536 &&
+                                o.i[10] * (int64_t)sizeof(T) <= 48 * 1024 &&
+                                o.i[2] * o.i[3] * (int64_t)sizeof(T) >= ((dmin ? atoll(dmin) : 16) << 20);
+          grid_route = grid_route || grid_dot;
           // K-split of the grid product (partial products summed by the argmax's first stage): enough workgroups to hide latency
           int gsplit = grid_route && o.i[2] >= 65536 ? (int)std::min<int64_t>(4, std::max<int64_t>(1, o.i[10] / 448)) : 1;
           if (grid_route && o.i[2] >= 65536 && getenv("SSN_GRID_SPLIT")) gsplit = std::max(1, std::min(8, atoi(getenv("SSN_GRID_SPLIT"))));
@@ -1520,7 +1541,7 @@ struct Sim final : ssn_sim {
             Item sl; sl.type = IT_GRID_LHS; sl.src = X; sl.aux0 = (const T*)fl.d; sl.ld = (int)fl.ld; sl.dst = A;
             sl.rows = na; sl.cols = k2;
             items.push_back(sl);
-            it.type = IT_GRID_GEMM; it.src = A; it.Wm = (T*)fr.d; it.ld = (int)fr.ld; it.rows = na; it.n = nn; it.cols = k2;
+            it.type = grid_dot ? IT_GRID_DOT : IT_GRID_GEMM; it.src = A; it.Wm = (T*)fr.d; it.ld = (int)fr.ld; it.rows = na; it.n = nn; it.cols = k2;
             it.seg = gsplit;
           }
           if (sizeof(T) == 8) {
@@ -2150,6 +2171,18 @@ struct Sim final : ssn_sim {
               }
               break;
             }
+            case IT_GRID_LHS: {
+              ssn::GridLhsArgs<T> a{it.src, it.aux0, it.ld, it.dst, it.cols, it.rows, it.cols / 2};
+              if (ao < 0) ao = (long long)put(&a, sizeof a);
+              entry(ssn::RK_GRID_LHS, (it.rows * (it.cols / 2) + 255) / 256, 1, 64, 0, (size_t)ao);
+              continue;
+            }
+            case IT_GRID_DOT: {
+              ssn::GridDotArgs<T> a{it.src, it.cols, it.Wm, it.ld, it.dst, it.n, it.cols, it.rows};
+              if (ao < 0) ao = (long long)put(&a, sizeof a);
+              entry(ssn::RK_GRID_DOT, (it.n + 15) / 16, it.rows, xb, 0, (size_t)ao);
+              continue;
+            }
             case IT_PES: {
               ssn::PesArgs<T> a{it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar};
               if (ao < 0) ao = (long long)put(&a, sizeof a);
@@ -2437,7 +2470,7 @@ struct Sim final : ssn_sim {
       case IT_GRID_LHS:
         acc_ptr(a, it.src, false); acc_ptr(a, it.aux0, false); acc_ptr(a, it.dst, true);
         break;
-      case IT_GRID_GEMM:
+      case IT_GRID_GEMM: case IT_GRID_DOT:
         acc_ptr(a, it.src, false); acc_ptr(a, it.Wm, false); acc_ptr(a, it.dst, true);
         break;
       case IT_ARGMAX_PART:
@@ -2704,6 +2737,7 @@ struct Sim final : ssn_sim {
       }
       case IT_ARGMAX_PART: return ssn::launch_argmax_partial<T>(stream, it.src, (long long)it.rows, it.dst, it.n, std::max(1, it.seg));
       case IT_GRID_LHS: return ssn::launch_grid_lhs<T>(stream, it.src, it.aux0, it.ld, it.dst, it.cols, it.rows, it.cols / 2);
+      case IT_GRID_DOT: return hipErrorInvalidValue;      // (planned only where the step runs as rounds)
       case IT_GRID_GEMM: return ssn::launch_gemm_nt<T>(stream, it.src, it.cols, it.Wm, it.ld, it.dst, it.n, it.rows, it.n, it.cols, std::max(1, it.seg));
       case IT_SPMV: {
         ssn::SpmvBatch<T> b{};
@@ -3150,6 +3184,63 @@ struct Sim final : ssn_sim {
     return SSN_OK;
   }
 
+  // Rows already in the simulator's type (the caller converted them): pure DMA into the inactive buffer set on the copy
+  // stream - no kernel, so it proceeds while a compute kernel owns every CU, and any host thread may call it during ssn_run_steps.
+  int stage_table(int id, const void* rows_t, int64_t n_rows, int64_t width, const int32_t* idx, int64_t n_idx, int64_t first_step) override {
+    HIPCHK(hipSetDevice(device));
+    if (id < 0 || id >= (int)tables.size()) return fail(SSN_EINVAL, "table id %d out of range", id);
+    if (width != tables[id].width) return fail(SSN_EINVAL, "table %d is %lld wide, got %lld", id, (long long)tables[id].width, (long long)width);
+    if (n_rows < 0 || n_idx < 0 || (!idx && n_idx) || (!rows_t && n_rows)) return fail(SSN_EINVAL, "bad table arguments");
+    for (int64_t i = 0; i < n_idx; ++i)
+      if (idx[i] >= n_rows) return fail(SSN_EINVAL, "table row index %d >= n_rows %lld", idx[i], (long long)n_rows);
+    std::lock_guard<std::mutex> lock(stage_mutex);
+    if (!copy_stream) HIPCHK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    Staged& g = staged[(size_t)id];
+    g.valid = false;
+    const int64_t need = std::max<int64_t>(1, n_rows * width);
+    if (need > g.rows_cap) {
+      if (g.rows) hipFree(g.rows);
+      g.rows = nullptr;
+      CHK(dmalloc((T**)&g.rows, need * (int64_t)sizeof(T)));
+      g.rows_cap = need;
+    }
+    if (n_idx > g.idx_cap) {
+      if (g.idx) hipFree(g.idx);
+      g.idx = nullptr;
+      CHK(dmalloc(&g.idx, n_idx * 4));
+      g.idx_cap = n_idx;
+    }
+    if (n_rows) HIPCHK(hipMemcpyAsync(g.rows, rows_t, (size_t)(n_rows * width) * sizeof(T), hipMemcpyHostToDevice, copy_stream));
+    if (n_idx) HIPCHK(hipMemcpyAsync(g.idx, idx, (size_t)n_idx * 4, hipMemcpyHostToDevice, copy_stream));
+    HIPCHK(hipStreamSynchronize(copy_stream));          // (the host arrays are the caller's again)
+    g.n_rows = n_rows; g.width = width; g.n_idx = n_idx; g.first_step = first_step;
+    g.idx_host.assign(idx, idx + n_idx);
+    g.valid = true;
+    return SSN_OK;
+  }
+
+  int commit_tables() override {
+    HIPCHK(hipSetDevice(device));
+    if (async_active) return fail(SSN_EINVAL, "a stream-ordered run is in flight on the caller's stream: call ssn_phase_sync first");
+    std::lock_guard<std::mutex> lock(stage_mutex);
+    bool any = false;
+    for (auto& g : staged) any = any || g.valid;
+    if (!any) return SSN_OK;
+    HIPCHK(hipStreamSynchronize(stream));              // the run that read the current set has ended
+    if (table_idx_host.size() < tables.size()) table_idx_host.resize(tables.size());
+    for (size_t id = 0; id < staged.size(); ++id) {
+      Staged& g = staged[id];
+      if (!g.valid) continue;
+      std::swap(g.rows, table_rows[id]); std::swap(g.idx, table_idx[id]);
+      std::swap(g.rows_cap, table_rows_cap[id]); std::swap(g.idx_cap, table_idx_cap[id]);
+      table_idx_host[id].swap(g.idx_host);
+      tables[id] = ssn::TableSlot{table_rows[id], table_idx[id], g.n_rows, g.width, g.n_idx, g.first_step};
+      g.valid = false;
+    }
+    HIPCHK(hipMemcpy(d_tables, tables.data(), tables.size() * sizeof(ssn::TableSlot), hipMemcpyHostToDevice));
+    return SSN_OK;
+  }
+
   int reserve_probes(int64_t n) override {
     HIPCHK(hipSetDevice(device));
     if (async_active) return fail(SSN_EINVAL, "a stream-ordered run is in flight on the caller's stream: call ssn_phase_sync first");
@@ -3311,6 +3402,11 @@ int ssn_set_table_device(ssn_sim* sim, int32_t id, const void* rows_dev, int64_t
   if (!sim || !rows_dev) return fail(SSN_EINVAL, "null argument");
   return sim->set_table(id, nullptr, rows_dev, n_rows, width, idx, n_idx, first_step);
 }
+int ssn_stage_table(ssn_sim* sim, int32_t id, const void* rows_t, int64_t n_rows, int64_t width, const int32_t* idx, int64_t n_idx, int64_t first_step) {
+  if (!sim) return fail(SSN_EINVAL, "null simulator");
+  return sim->stage_table(id, rows_t, n_rows, width, idx, n_idx, first_step);
+}
+int ssn_commit_tables(ssn_sim* sim) { return sim ? sim->commit_tables() : fail(SSN_EINVAL, "null simulator"); }
 int ssn_reserve_probes(ssn_sim* sim, int64_t n) { return sim ? sim->reserve_probes(n) : fail(SSN_EINVAL, "null simulator"); }
 int ssn_run_steps(ssn_sim* sim, int64_t n, int32_t profile) { return sim ? sim->run_steps(n, profile) : fail(SSN_EINVAL, "null simulator"); }
 int ssn_read_probe(ssn_sim* sim, int32_t id, double* dst, int64_t first, int64_t count) {

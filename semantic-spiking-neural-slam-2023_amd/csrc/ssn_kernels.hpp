@@ -1950,6 +1950,18 @@ __global__ __launch_bounds__(256) void k_grid_lhs(const T* __restrict__ X, const
   A[(size_t)a * lda + 2 * k + 1] = xi * er - xr * ei;          // -Im(conj(X) E)
 }
 
+// the same as a body of the round grid: 256 (a, k) pairs per block
+template <typename T>
+__device__ __forceinline__ void grid_lhs_body(const GridLhsArgs<T>& g, const int bx) {
+  const int i = bx * 256 + (int)threadIdx.x;
+  if (i >= g.na * g.K) return;
+  const int a = i / g.K, k = i - a * g.K;
+  const T xr = g.X[2 * k], xi = g.X[2 * k + 1];
+  const T er = g.E[(size_t)a * g.lde + 2 * k], ei = g.E[(size_t)a * g.lde + 2 * k + 1];
+  g.A[(size_t)a * g.lda + 2 * k] = xr * er + xi * ei;
+  g.A[(size_t)a * g.lda + 2 * k + 1] = xi * er - xr * ei;
+}
+
 template <typename T>
 hipError_t launch_grid_lhs(hipStream_t s, const T* X, const T* E, int lde, T* A, int lda, int na, int K) {
   hipLaunchKernelGGL((k_grid_lhs<T>), dim3((unsigned)((na * K + 255) / 256)), dim3(256), 0, s, X, E, lde, A, lda, na, K);

@@ -250,8 +250,14 @@ enum RoundKind {
   RK_GATE, RK_ARGMAX, // whole-vector micro-operators: one block each (args: MicroOp)
   RK_MATVEC_R1, RK_MATVEC_R4, RK_SPMV, RK_NEURONS, RK_DFT, RK_PES, RK_VOJA,
   RK_ENS_3_4_S, RK_ENS_3_5_S, RK_ENS_1_1_D,     // k_ensarray<din, dout, spike-sparse | dense decoders>
-  RK_ENS_SMALL                                  // arrays of many small 1-D ensembles: a wave per ensemble, 16 per block (ens_small_body)
+  RK_ENS_SMALL,                                 // arrays of many small 1-D ensembles: a wave per ensemble, 16 per block (ens_small_body)
+  RK_GRID_LHS, RK_GRID_DOT                      // clean-up over a sample grid from its factor tables (round 4): left operand; similarities
 };
+// Clean-up similarities of a 2-D sample grid without the pass over its table (reference slam.py:209-215: 10^4 x d every timestep,
+// 40 MB at d = 1015): sims[a * nn + r] = sum_k A[a][k] * W[r][k] with A = Re / -Im of conj(X) * lhs[a] (grid_lhs_body) and W the
+// factors of the remaining axis - two 100 x 2K tables that stay in L2 instead of the table streamed from HBM.
+template <typename T> struct GridLhsArgs { const T* X; const T* E; int lde; T* A; int lda; int na; int K; };
+template <typename T> struct GridDotArgs { const T* A; int lda; const T* W; int ldw; T* dst; int nn; int k2; int na; };
 struct GlueBlock { int op; int chunk; };        // micro-operator index (into RoundArgs::mops); chunk of it (low 24 bits), timestep offset (high 8)
 // op < 0: a CHAIN of element-aligned micro-operators - RoundArgs::chain[-op - 1 ...] = {n, op_0, sub_0, ..., op_{n-1}, sub_{n-1}} -
 // run back to back by this block on elements [chunk * GLUE_ROWS, ...): a dependent operator whose every shared element

@@ -259,6 +259,13 @@ __device__ __forceinline__ void round_block(const RoundArgs<T>& ra, int vb, unsi
     case RK_ENS_3_5_S: ens_body<T, 3, 5, 1>(*(const EnsArgs<T>*)e.args, bx, smem); break;
     case RK_ENS_1_1_D: ens_body<T, 1, 1, 2>(*(const EnsArgs<T>*)e.args, bx, smem); break;
     case RK_ENS_SMALL: ens_small_body<T>(*(const EnsArgs<T>*)e.args, bx); break;
+    case RK_GRID_LHS: grid_lhs_body<T>(*(const GridLhsArgs<T>*)e.args, bx); break;
+    case RK_GRID_DOT: {      // row block bx of the remaining-axis factors against left-operand row by: similarities [by * nn + 16 bx ...)
+      const GridDotArgs<T> g = *(const GridDotArgs<T>*)e.args;
+      const MatvecArgs<T> m{g.W, g.A + (size_t)by * g.lda, g.dst + (size_t)by * g.nn, g.nn, g.k2, g.ldw, 1};
+      matvec_body<T, true, 4>(m, bx, smem);
+      break;
+    }
     case RK_PES: pes_body<T>(*(const PesArgs<T>*)e.args, bx, by); break;
     case RK_VOJA: voja_body<T>(*(const VojaArgs<T>*)e.args, bx); break;
     default: break;

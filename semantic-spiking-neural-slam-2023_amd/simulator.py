@@ -242,6 +242,7 @@ class Simulator:
                 model = build(network, dt=dt, seed=seed, n_eval_points=n_eval_points, vco_shard=vco_shard)
         self.model = model
         self.dtype = "f64" if dtype in ("f64", "float64", np.float64) else "f32"
+        self._block_align = int(block_steps) if block_steps else 1024      # (the library's default block of a staged model)
         desc, keep, self._sig_probes = pack_model(model, self.dtype, device, steps_per_graph, block_steps, flags)
         self._h = C.c_void_p()
         t0 = time.time()
@@ -366,23 +367,28 @@ class Simulator:
     # PIPELINE_GROWTH x its predecessor), and the run ends with a short chunk.
     PIPELINE_FIRST = 512
     PIPELINE_MIN = 256
-    PIPELINE_MAX = 8192
-    PIPELINE_TAIL = 1024
+    PIPELINE_MAX = 16384
+    PIPELINE_TAIL = 512
     PIPELINE_GROWTH = 4.0
     PIPELINE_CHUNK = 2048            # runs of at most twice this many steps are prepared in one piece
 
     def _tabulate_chunk(self, first, n):
-        """(first, n, [(rows, idx) per table]) for the n timesteps after 0-based step ``first``."""
+        """Tabulate every t-only node for the n timesteps after 0-based step ``first`` and STAGE the tables on the device
+        (``ssn_stage_table``: DMA into a second set of buffers, legal while another thread's ``ssn_run_steps`` is in flight -
+        this runs on the helper thread of a pipelined run); ``ssn_commit_tables`` between two chunks makes them current.
+        Returns (first, n)."""
         steps = np.arange(first + 1, first + n + 1)
-        tabs = []
         if self._stages is None:
             self._stages = [RowStage() for _ in self.model.tables]
-        for tb, stage in zip(self.model.tables, self._stages):
-            # (the stage is free again: the tables of the chunk before were uploaded - synchronously - before this one's
-            #  tabulation started)
+        t_np = np.float64 if self.dtype == "f64" else np.float32
+        for tid, (tb, stage) in enumerate(zip(self.model.tables, self._stages)):
+            # (the stage is free again: the call below copies the rows before it returns)
             rows, idx = tabulate(tb["fn"], tb["width"], steps, self.dt, stage)
-            tabs.append((np.ascontiguousarray(rows, dtype=np.float64), np.ascontiguousarray(idx, dtype=np.int32)))
-        return first, n, tabs
+            rows = np.ascontiguousarray(rows, dtype=t_np)              # the simulator's own type: the upload is a plain copy
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+            self._check(self._lib.ssn_stage_table(self._h, tid, rows.ctypes.data, rows.shape[0], tb["width"],
+                                                  idx.ctypes.data, idx.size, first))
+        return first, n
 
     _stages = None
 
@@ -456,8 +462,9 @@ class Simulator:
         if self._dev_rate and self._tab_rate:            # its tabulation runs while the device steps `cur` timesteps
             grow = min(grow, 0.8 * self._dev_rate / max(self._tab_rate, 1e-9))
         n = int(max(self.PIPELINE_MIN, min(self.PIPELINE_MAX, cur * grow)))
-        if n >= 1024:
-            n -= n % 1024                                # whole time-batched blocks where the chunk holds several
+        align = getattr(self, "_block_align", 1024)
+        if n >= align:
+            n -= n % align                               # whole time-batched blocks where the chunk holds several
         tail = self.PIPELINE_TAIL
         if remaining <= n + tail:                        # the run's last samples are read back with nothing to hide behind:
             n = remaining - tail if remaining > 2 * tail else remaining      # keep the last chunk short
@@ -477,12 +484,10 @@ class Simulator:
             chunk = steps - done
             worker = None
             if pipelined is not None:
-                first, n_tab, tabs = pipelined
+                first, n_tab = pipelined
                 t_up = time.perf_counter()
-                for tid, (rows, idx) in enumerate(tabs):
-                    self._check(self._lib.ssn_set_table(self._h, tid, rows.ctypes.data, rows.shape[0], self.model.tables[tid]["width"],
-                                                        idx.ctypes.data, idx.size, first))
-                self._tr("upload tables", t_up, n_tab)
+                self._check(self._lib.ssn_commit_tables(self._h))      # (staged by _tabulate_chunk while the chunk before ran)
+                self._tr("commit tables", t_up, n_tab)
                 self._prepared_until = first + n_tab
                 chunk = min(chunk, n_tab)
                 nxt = self.n_steps + chunk
