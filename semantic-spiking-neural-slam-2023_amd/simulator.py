@@ -369,6 +369,7 @@ class Simulator:
     PIPELINE_MIN = 256
     PIPELINE_MAX = 16384
     PIPELINE_TAIL = 512
+    PIPELINE_MID = 2048
     PIPELINE_GROWTH = 4.0
     PIPELINE_CHUNK = 2048            # runs of at most twice this many steps are prepared in one piece
 
@@ -465,9 +466,16 @@ class Simulator:
         align = getattr(self, "_block_align", 1024)
         if n >= align:
             n -= n % align                               # whole time-batched blocks where the chunk holds several
-        tail = self.PIPELINE_TAIL
-        if remaining <= n + tail:                        # the run's last samples are read back with nothing to hide behind:
-            n = remaining - tail if remaining > 2 * tail else remaining      # keep the last chunk short
+        # The run's last samples are read back with nothing to hide behind, and the read-back of a long chunk (2.9 ms for 8 736
+        # samples of 1015) outlasts a short last chunk: the run ends ... long, PIPELINE_MID, PIPELINE_TAIL - each read-back fits
+        # under the chunk after it.
+        tail, mid = self.PIPELINE_TAIL, (2 * align if 512 <= align <= 2048 else self.PIPELINE_MID)      # (whole blocks again)
+        if remaining <= tail:
+            n = remaining
+        elif remaining <= mid + tail:
+            n = remaining - tail
+        elif remaining <= n + mid + tail:
+            n = remaining - mid - tail if remaining - mid - tail >= self.PIPELINE_MIN else remaining - tail
         return max(1, min(n, remaining))
 
     def _step_loop(self, steps, profile, pipelined, buf_probes):

@@ -294,8 +294,8 @@ def test_chunk_schedule_of_a_pipelined_run():
                 left -= n
             assert sum(chunks) == steps
             assert max(chunks) <= Simulator.PIPELINE_MAX
-            assert chunks[-1] <= 2 * Simulator.PIPELINE_TAIL
+            assert chunks[-1] <= Simulator.PIPELINE_TAIL and (len(chunks) < 3 or chunks[-2] <= Simulator.PIPELINE_MID + Simulator.PIPELINE_TAIL)
             if dev and tab and tab > dev:            # tabulation-bound: chunks shrink to the minimum instead of stalling the device longer
                 assert sorted(chunks[1:-2])[len(chunks[1:-2]) // 2] <= Simulator.PIPELINE_FIRST
             if dev and tab and tab < 0.2 * dev:
-                assert len(chunks) <= 4 + steps // Simulator.PIPELINE_MAX
+                assert len(chunks) <= 5 + steps // Simulator.PIPELINE_MAX
