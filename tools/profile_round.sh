@@ -13,14 +13,14 @@ B="$R/bench.py --steps 3 --warmup 1 --cpu-steps 0 --no-end-to-end --slam-cpu-ste
 # (the stats pass runs the DRIVER's command shape - 20 timed blocks behind 5 warm-up ones: the first launches of a short run are
 #  ~13 % slower, and the average of a 3-block run does not agree with the bench line's)
 BS="$R/bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-end-to-end --slam-cpu-steps 0"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -o r3 -- python3 $BS --slam-steps 256 > $R/$OUT/bench_under_rocprof.json 2> $R/$OUT/stats.err || exit 1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -o r4 -- python3 $BS --slam-steps 256 > $R/$OUT/bench_under_rocprof.json 2> $R/$OUT/stats.err || exit 1
 find $R/$OUT/stats -name "*kernel_trace*" -delete; find $R/$OUT/stats -name "*agent_info*" -delete
 echo stats done
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_ens_block --output-format csv -d $R/$OUT/pmc_fetch -o r3 -- python3 $B --slam-steps 0 > $R/$OUT/pmc_fetch.log 2>&1 || exit 2
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_ens_block --output-format csv -d $R/$OUT/pmc_write -o r3 -- python3 $B --slam-steps 0 > $R/$OUT/pmc_write.log 2>&1 || exit 3
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_ens_block --output-format csv -d $R/$OUT/pmc_fetch -o r4 -- python3 $B --slam-steps 0 > $R/$OUT/pmc_fetch.log 2>&1 || exit 2
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_ens_block --output-format csv -d $R/$OUT/pmc_write -o r4 -- python3 $B --slam-steps 0 > $R/$OUT/pmc_write.log 2>&1 || exit 3
 echo block pmc done
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_round --output-format csv -d $R/$OUT/slam_fetch -o r3 -- python3 $R/tools/experiments/slam_flags.py 0 > $R/$OUT/slam_fetch.log 2>&1 || exit 4
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_round --output-format csv -d $R/$OUT/slam_write -o r3 -- python3 $R/tools/experiments/slam_flags.py 0 > $R/$OUT/slam_write.log 2>&1 || exit 5
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_round --output-format csv -d $R/$OUT/slam_fetch -o r4 -- python3 $R/tools/experiments/slam_flags.py 0 > $R/$OUT/slam_fetch.log 2>&1 || exit 4
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_round --output-format csv -d $R/$OUT/slam_write -o r4 -- python3 $R/tools/experiments/slam_flags.py 0 > $R/$OUT/slam_write.log 2>&1 || exit 5
 echo slam pmc done
 cd $R
 # summaries (the raw counter files stay on the box: gpurun merges at most 64 MiB back)
