@@ -138,6 +138,7 @@ struct Sim final : ssn_sim {
     int seg = 0;                                   // > 0: segmented spike list (k_neurons), segments per spmv chunk
     int level = -1;                                // scheduling round of the operator (builder): equal level = independent
     int phase = -1;                                // neuron-sharded models: 0 before the per-timestep exchange, 1 after (set by plan())
+    T* lp_dst = nullptr; const T* lp_src = nullptr; T lp_a = 0, lp_b = 0;      // IT_PES: folded filter of the row factors (build_rounds)
     int batch = 1;                                 // this item and the next batch-1 items (same kind, independent) share one launch
     bool merged = false;                           // launched by the item that leads its batch
     ssn::DftArgs dft;
@@ -1865,10 +1866,37 @@ struct Sim final : ssn_sim {
     all.insert(all.end(), extra.begin(), extra.end());
   }
 
-  int build_rounds(const std::vector<std::vector<MOp>>& programs, const std::vector<int>& item_prog) {
+  int build_rounds(const std::vector<std::vector<MOp>>& programs_in, const std::vector<int>& item_prog) {
     struct Unit { int mop = -1; int item = -1; int phase = 0; bool writes = false; std::vector<Rng> acc; };
     std::vector<Unit> units;
     mops.clear();
+    std::vector<std::vector<MOp>> programs = programs_in;
+    // Round 4: the critical recurrence of a SLAM timestep - memory spikes -> sparse decode -> PES (may not touch W before the
+    // decode has read it) -> filter of the activities PES reads (may not run before PES) -> next timestep's spikes (may not
+    // overwrite what that filter reads) - is four rounds of WAR hazards.  The filter update folded into the PES body (the
+    // workgroup that has read row r's factor advances it) takes one of them out.  Round 2 measured this fold slower because the
+    // oscillators' own four-round recurrence kept the period at four; it pays together with the oscillator array completing
+    // its previous timestep itself (below).  SSN_PES_FOLD=0: off.
+    if (!phased && !(getenv("SSN_PES_FOLD") && atoi(getenv("SSN_PES_FOLD")) == 0))
+      for (size_t i = 0; i < items.size(); ++i) {
+        Item& pe = items[i];
+        if (pe.type != IT_PES || pe.cols > 1024 || !(pe.aux0 >= sig && pe.aux0 < sig + n_sig)) continue;
+        const long long f0 = pe.aux0 - sig;
+        bool done = false;
+        int pj = 0;
+        for (size_t j = 0; j < items.size() && !done; ++j) {
+          if (items[j].type != IT_PROGRAM) continue;
+          std::vector<MOp>& pr = programs[(size_t)item_prog[(size_t)pj++]];
+          if (j < i) continue;                                  // (the filter update follows the rule in program order: reads before updates)
+          for (size_t q = 0; q < pr.size(); ++q)
+            if (pr[q].kind == ssn::M_LOWPASS && pr[q].dst == f0 && pr[q].len == pe.rows) {
+              pe.lp_dst = sig + pr[q].dst; pe.lp_src = sig + pr[q].src; pe.lp_a = pr[q].a; pe.lp_b = pr[q].b;
+              pr.erase(pr.begin() + (long)q);
+              done = true;
+              break;
+            }
+        }
+      }
     // Element-wise micro-operators are cut at every range endpoint of the other operators.  The builder merges
     // neighbouring resets / hand-offs into one long operator (one fill over all accumulators of a network); as a unit
     // it would inherit the hazards of every signal it spans - the reset of an accumulator that is read in the last
@@ -2184,7 +2212,7 @@ struct Sim final : ssn_sim {
               continue;
             }
             case IT_PES: {
-              ssn::PesArgs<T> a{it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar};
+              ssn::PesArgs<T> a{it.Wm, it.aux0, it.aux1, it.rows, it.cols, it.ld, it.scalar, it.lp_dst, it.lp_src, it.lp_a, it.lp_b};
               if (ao < 0) ao = (long long)put(&a, sizeof a);
               entry(ssn::RK_PES, (it.cols + 1023) / 1024, (it.rows + ssn::PES_ROWS - 1) / ssn::PES_ROWS, 64, 0, (size_t)ao);
               continue;
@@ -2485,6 +2513,7 @@ struct Sim final : ssn_sim {
         break;
       case IT_PES:
         acc_ptr(a, it.Wm, true); acc_sig(a, it.aux0 - sig, it.rows, false); acc_sig(a, it.aux1 - sig, it.cols, false);
+        if (it.lp_dst) { acc_sig(a, it.lp_dst - sig, it.rows, true); acc_sig(a, it.lp_src - sig, it.rows, false); }
         break;
       case IT_VOJA:
         acc_ptr(a, it.Wm, true); acc_sig(a, it.src - sig, it.rows, false); acc_sig(a, it.aux0 - sig, it.cols, false); acc_sig(a, it.aux1 - sig, 1, false);

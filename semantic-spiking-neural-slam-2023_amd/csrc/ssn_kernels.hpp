@@ -1569,6 +1569,13 @@ __device__ __forceinline__ void pes_body(const PesArgs<T>& a, const int bx, cons
   T e[PES_ROWS];
 #pragma unroll
   for (int q = 0; q < PES_ROWS; ++q) e[q] = r0 + q < a.rows ? a.kappa * a.err[r0 + q] : T(0);
+  if (a.lp_dst) {
+    // folded filter of the row factors (planned only where one column tile covers the matrix: this workgroup is the only reader
+    // of its eight factors): every wave has its copies before thread q advances factor q
+    __syncthreads();
+    const int q = threadIdx.x;
+    if (bx == 0 && q < PES_ROWS && r0 + q < a.rows) a.lp_dst[r0 + q] = a.lp_a * a.lp_dst[r0 + q] + a.lp_b * a.lp_src[r0 + q];
+  }
   const int c0 = bx * 1024;
 #pragma unroll
   for (int q = 0; q < PES_ROWS; ++q) {
@@ -1584,7 +1591,7 @@ __device__ __forceinline__ void pes_body(const PesArgs<T>& a, const int bx, cons
 template <typename T>
 __global__ __launch_bounds__(256) void k_pes(T* __restrict__ Wm, const T* __restrict__ err, const T* __restrict__ act,
                                              int rows, int cols, int ld, T kappa) {
-  pes_body<T>(PesArgs<T>{Wm, err, act, rows, cols, ld, kappa}, (int)blockIdx.x, (int)blockIdx.y);
+  pes_body<T>(PesArgs<T>{Wm, err, act, rows, cols, ld, kappa, nullptr, nullptr, T(0), T(0)}, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 template <typename T>

@@ -242,7 +242,11 @@ struct BatchOp {
 // from timestep to timestep; the step counter is read from StepCtx).
 // ---------------------------------------------------------------------------------------------
 constexpr int PES_ROWS = 8;      // rows per workgroup of the PES update (pes_body)
-template <typename T> struct PesArgs { T* Wm; const T* err; const T* act; int rows, cols, ld; T kappa; };
+template <typename T> struct PesArgs { T* Wm; const T* err; const T* act; int rows, cols, ld; T kappa;
+                                       // round plan (round 4): the Lowpass that filters the row factors (the memory population's activities, reference
+                                       // associativememory.py:38-43: PES(pre_synapse)) folded into the update - row r's factor is advanced by the
+                                       // workgroup that has just read it: lp_dst[r] = lp_a * lp_dst[r] + lp_b * lp_src[r]  (lp_dst == err; null: not folded)
+                                       T* lp_dst; const T* lp_src; T lp_a, lp_b; };
 template <typename T> struct VojaArgs { T* E; const T* spk; const T* key; const T* learn; const T* scale; int rows, cols, ld; T lr_dt; };
 
 enum RoundKind {
