@@ -663,7 +663,9 @@ struct Sim final : ssn_sim {
       for (auto& r : pre_to_core) CHK(check_range(r.lo, r.hi - r.lo, "pre->core boundary"));
       for (auto& r : core_to_post) CHK(check_range(r.lo, r.hi - r.lo, "core->post boundary"));
     }
-    steps_per_graph = m->steps_per_graph != 0 ? m->steps_per_graph : 16;
+    // default: 64 timesteps per step graph where the time-batched blocks hold whole graphs (the software-pipelined round plan
+    // fills and drains once per graph: SLAM config 3 106.3 us per timestep at 16, 105.9 at 32, 104.5 at 64 - round 4), else 16
+    steps_per_graph = m->steps_per_graph != 0 ? m->steps_per_graph : ((block == 0 || block % 64 == 0) ? 64 : 16);
     if (steps_per_graph > 64) return fail(SSN_EINVAL, "steps_per_graph %d: at most 64", steps_per_graph);
     CHK(plan(m));
     CHK(capture());
@@ -1761,7 +1763,7 @@ struct Sim final : ssn_sim {
 
   // k_round body of an ensemble array (-1: its variant has none, it is launched on its own)
   int ens_round_kind(const ssn::EnsArgs<T>& a) const {
-    if (a.defer || a.xrows || (flags & 4194304)) return -1;
+    if ((a.defer && a.defer != 2) || a.xrows || (flags & 4194304)) return -1;
     if (a.fast == 1 && a.din == 3 && a.dout == 4) return ssn::RK_ENS_3_4_S;
     if (a.fast == 1 && a.din == 3 && a.dout == 5) return ssn::RK_ENS_3_5_S;
     if (a.fast == 2 && a.din == 1 && a.dout == 1) {
@@ -1866,6 +1868,128 @@ struct Sim final : ssn_sim {
     all.insert(all.end(), extra.begin(), extra.end());
   }
 
+  // Round plan, recurrent ensemble arrays (the SLAM network's oscillators, reference pathintegration.py:180-182: ensemble k ->
+  // Lowpass -> ensemble k).  As separate operators the recurrence costs four dependent rounds per timestep: array (partial sums
+  // per 1024-neuron chunk) -> M_ENS_FINISH (sums) -> M_LOWPASS (filter state) -> M_LINCOMB (input) -> array.  When every input
+  // element of the array takes its recurrent term from a filter fed by a decoded row of the SAME ensemble - the proof
+  // try_fused_core makes for the whole-block kernel, here on the micro-operators of the round plan - the array does it all in
+  // its prologue (ens_body, defer == 2): the filter and the recurrent term of the lincomb leave the plan, the finish stays for
+  // the other readers of the decoded rows (the to_SSP read-out).
+  std::vector<std::pair<void*, size_t>> zero_on_reset;      // scratch that holds state across timesteps (partial sums, filter states)
+  int fold_recurrent_filter(std::vector<std::vector<MOp>>& programs, const std::vector<int>& item_prog) {
+    for (size_t ei = 0; ei < items.size(); ++ei) {
+      Item& E = items[ei];
+      if (E.type != IT_ENS || E.ens.direct || E.ens.defer || E.ens.xrows || E.ens.P < 2 || ens_round_kind(E.ens) < 0) continue;
+      ssn::EnsArgs<T>& a = E.ens;
+      const int64_t K = a.K, din = a.din, dout = a.dout;
+      // the finish operator and the host copy of the destination indices
+      MOp* F = nullptr;
+      for (auto& pr : programs) for (MOp& op : pr) if (op.kind == ssn::M_ENS_FINISH && op.p0 == (const void*)a.partials) F = &op;
+      if (!F) continue;
+      const int32_t* didx = nullptr;
+      for (auto& h : host_idx) if (h.first == F->p1 && h.second.second == K * dout) didx = h.second.first;
+      if (!didx) continue;
+      std::map<long long, int> row_of;                          // decoded signal -> row index k * dout + r
+      for (int64_t j = 0; j < K * dout; ++j) row_of[didx[j]] = (int)j;
+      // filters fed by decoded rows of this array whose state is read by lincombs into the array's input range only
+      const long long x0 = a.x_off, x1 = a.x_off + K * din;
+      std::vector<int> xrow((size_t)(K * din), -1);
+      std::vector<double> xalpha((size_t)(K * din), 0.0), lpa((size_t)(K * dout), 0.0), lpb((size_t)(K * dout), 0.0);
+      struct Hit { size_t prog, op; };
+      std::vector<Hit> filters;
+      std::vector<std::pair<Hit, size_t>> terms;                // (lincomb, term index) to remove
+      bool ok = true;
+      for (size_t pi = 0; pi < programs.size() && ok; ++pi)
+        for (size_t oi = 0; oi < programs[pi].size() && ok; ++oi) {
+          const MOp& L = programs[pi][oi];
+          if (L.kind != ssn::M_LOWPASS) continue;
+          bool fed = false, foreign = false;
+          for (long long q = 0; q < L.len; ++q) { if (row_of.count(L.src + q)) fed = true; }
+          if (!fed) continue;
+          // every reader of the state range must be a lincomb into [x0, x1) with the state as one of its terms, element for element
+          std::vector<std::pair<Hit, size_t>> my_terms;
+          for (size_t pj = 0; pj < programs.size() && !foreign; ++pj)
+            for (size_t oj = 0; oj < programs[pj].size() && !foreign; ++oj) {
+              const MOp& X = programs[pj][oj];
+              if (&X == &L) continue;
+              std::vector<Rng> acc;
+              micro_access(acc, X, false);
+              bool touches = false;
+              for (const Rng& r : acc) if (r.space == (const void*)sig && r.lo < L.dst + L.len && L.dst < r.hi) touches = true;
+              if (!touches) continue;
+              if (X.kind != ssn::M_LINCOMB || X.dst < x0 || X.dst + X.len > x1) { foreign = true; break; }
+              auto lt = lin_terms.find(X.p0);
+              if (lt == lin_terms.end()) { foreign = true; break; }
+              for (size_t t = 0; t < lt->second.size(); ++t) {
+                const long long ts = lt->second[t].src;
+                if (ts + X.len <= L.dst || L.dst + L.len <= ts) continue;
+                if (ts < L.dst || ts + X.len > L.dst + L.len) { foreign = true; break; }
+                my_terms.push_back({Hit{pj, oj}, t});
+              }
+            }
+          for (auto& it2 : items) if (it2.type != IT_PROGRAM) { std::vector<Rng> acc; item_access(acc, it2); for (const Rng& r : acc) if (r.space == (const void*)sig && r.lo < L.dst + L.len && L.dst < r.hi) foreign = true; }
+          for (auto& pb : probes) if (pb.src < L.dst + L.len && L.dst < pb.src + pb.width) foreign = true;
+          if (foreign || my_terms.empty()) continue;             // somebody else needs this state: it stays an operator
+          for (long long q = 0; q < L.len && ok; ++q) if (sig_init[(size_t)(L.dst + q)] != 0.0) ok = false;      // (x of the first timestep uses the state as it stands)
+          // map every input element to the row that feeds it
+          for (auto& mt : my_terms) {
+            const MOp& X = programs[mt.first.prog][mt.first.op];
+            const auto& tt = lin_terms[X.p0][mt.second];
+            for (long long q = 0; q < X.len && ok; ++q) {
+              const long long e = X.dst + q - x0, st = tt.src + q;
+              auto f = row_of.find(L.src + (st - L.dst));
+              if (f == row_of.end()) continue;                   // a state no row feeds (dropped all-zero decoder row): stays 0
+              if (f->second / dout != e / din || xrow[(size_t)e] >= 0) { ok = false; break; }
+              xrow[(size_t)e] = (int)(f->second % dout); xalpha[(size_t)e] = (double)tt.alpha * (double)X.b;
+              lpa[(size_t)f->second] = (double)L.a; lpb[(size_t)f->second] = (double)L.b;
+            }
+            terms.push_back(mt);
+          }
+          filters.push_back(Hit{pi, oi});
+        }
+      if (!ok || filters.empty()) continue;
+      // device tables, the second set of partial sums, the filter states
+      const int64_t nr = K * dout, ps = (int64_t)K * a.P * dout;
+      int* d_xrow = nullptr; T* d_xalpha = nullptr; T* d_a = nullptr; T* d_b = nullptr; T* d_f = nullptr; T* d_part = nullptr;
+      CHK(dmalloc(&d_xrow, K * din * 4)); CHK(dmalloc(&d_xalpha, K * din * (int64_t)sizeof(T)));
+      CHK(dmalloc(&d_a, nr * (int64_t)sizeof(T))); CHK(dmalloc(&d_b, nr * (int64_t)sizeof(T)));
+      CHK(dmalloc(&d_f, 2 * nr * (int64_t)sizeof(T))); CHK(dmalloc(&d_part, 2 * ps * (int64_t)sizeof(T)));
+      for (void* q : {(void*)d_xrow, (void*)d_xalpha, (void*)d_a, (void*)d_b, (void*)d_f}) scratch_bufs.push_back(q);
+      HIPCHK(hipMemcpy(d_xrow, xrow.data(), (size_t)(K * din) * 4, hipMemcpyHostToDevice));
+      CHK(upload(xalpha.data(), d_xalpha, 1, K * din, K * din));
+      CHK(upload(lpa.data(), d_a, 1, nr, nr)); CHK(upload(lpb.data(), d_b, 1, nr, nr));
+      HIPCHK(hipMemset(d_f, 0, (size_t)(2 * nr) * sizeof(T))); HIPCHK(hipMemset(d_part, 0, (size_t)(2 * ps) * sizeof(T)));
+      zero_on_reset.push_back({(void*)d_f, (size_t)(2 * nr) * sizeof(T)}); zero_on_reset.push_back({(void*)d_part, (size_t)(2 * ps) * sizeof(T)});
+      hipFree(a.partials);                                      // (the single set planned before; ~Sim frees the new one through the item)
+      F->p0 = d_part; F->src = ps;
+      a.partials = d_part; a.partials_stride = ps; a.defer = 2; a.sub = 0;
+      a.xrow = d_xrow; a.xalpha = d_xalpha; a.lp_a = d_a; a.lp_b = d_b; a.fstate = d_f;
+      // the recurrent terms leave their lincombs (new term lists), the filters leave the plan
+      std::map<const void*, std::vector<size_t>> drop;          // lincomb term list -> term indices to drop
+      for (auto& mt : terms) drop[programs[mt.first.prog][mt.first.op].p0].push_back(mt.second);
+      for (auto& pr : programs)
+        for (MOp& op : pr) {
+          if (op.kind != ssn::M_LINCOMB) continue;
+          auto d = drop.find(op.p0);
+          if (d == drop.end()) continue;
+          std::vector<ssn::LinTerm<T>> tt;
+          const auto& old = lin_terms[op.p0];
+          for (size_t t = 0; t < old.size(); ++t) if (std::find(d->second.begin(), d->second.end(), t) == d->second.end()) tt.push_back(old[t]);
+          ssn::LinTerm<T>* d_terms = nullptr;
+          CHK(dmalloc(&d_terms, (int64_t)std::max<size_t>(1, tt.size()) * (int64_t)sizeof(ssn::LinTerm<T>)));
+          scratch_bufs.push_back(d_terms);
+          if (!tt.empty()) HIPCHK(hipMemcpy(d_terms, tt.data(), tt.size() * sizeof(ssn::LinTerm<T>), hipMemcpyHostToDevice));
+          lin_terms[(const void*)d_terms] = tt;
+          op.p0 = d_terms; op.i0 = (long long)tt.size();
+        }
+      std::sort(filters.begin(), filters.end(), [](const Hit& x, const Hit& y) { return x.prog != y.prog ? x.prog > y.prog : x.op > y.op; });
+      for (const Hit& h : filters) programs[h.prog].erase(programs[h.prog].begin() + (long)h.op);
+      if (getenv("SSN_DEBUG_PLAN")) fprintf(stderr, "[ssn] recurrent array of %lld ensembles completes its own previous timestep: %zu filter operator(s) and %zu lincomb term(s) folded\n", (long long)K, filters.size(), terms.size());
+    }
+    (void)item_prog;
+    return SSN_OK;
+  }
+
   int build_rounds(const std::vector<std::vector<MOp>>& programs_in, const std::vector<int>& item_prog) {
     struct Unit { int mop = -1; int item = -1; int phase = 0; bool writes = false; std::vector<Rng> acc; };
     std::vector<Unit> units;
@@ -1951,6 +2075,10 @@ struct Sim final : ssn_sim {
       }
       return SSN_OK;
     };
+    // (opt-in, SSN_ENS_SELF_FINISH=1: measured in round 4 at SLAM config 3 - 117.9 us per timestep alone, 111.0 together with the PES
+    //  fold, against 106.4 for the PES fold alone: the prologue's dependent loads lengthen every workgroup of the bandwidth-bound
+    //  round, and the greedy placement does not turn the freed recurrence into a shorter cycle)
+    if (!phased && getenv("SSN_ENS_SELF_FINISH") && atoi(getenv("SSN_ENS_SELF_FINISH")) == 1) CHK(fold_recurrent_filter(programs, item_prog));
     int prog_i = 0;
     for (size_t i = 0; i < items.size(); ++i) {
       const Item& it = items[i];
@@ -1980,6 +2108,7 @@ struct Sim final : ssn_sim {
     std::vector<unsigned char> arena;
     auto put = [&](const void* src, size_t bytes) { const size_t off = (arena.size() + 15) / 16 * 16; arena.resize(off + bytes); memcpy(arena.data() + off, src, bytes); return off; };
     std::vector<long long> unit_arg(units.size(), -1);      // arena offset of a big operator's body arguments (shared by its instances)
+    std::map<int, std::pair<long long, long long>> ens_parity_arg;      // ... of a self-finishing array: one copy per timestep parity
     struct Fix { size_t rl; int entry; int what; size_t off; };     // what: 0 arena, 1 glue map, 2 micro-operator
     std::vector<Fix> fixes;
     round_launches.clear();
@@ -2163,6 +2292,17 @@ struct Sim final : ssn_sim {
               const ssn::EnsArgs<T>& a = it.ens;
               const int kind = ens_round_kind(a);
               if (kind >= 0) {
+                if (a.defer == 2) {          // the timestep offset of the instance decides which set of partial sums it writes: two copies
+                  auto f = ens_parity_arg.find(in->unit);
+                  if (f == ens_parity_arg.end()) {
+                    ssn::EnsArgs<T> c0 = a, c1 = a;
+                    c0.sub = 0; c1.sub = 1;
+                    const long long o0 = (long long)put(&c0, sizeof c0), o1 = (long long)put(&c1, sizeof c1);
+                    f = ens_parity_arg.insert({in->unit, {o0, o1}}).first;
+                  }
+                  entry(kind, ens_round_blocks(a), 1, 512, 0, (size_t)((in->sub & 1) ? f->second.second : f->second.first));
+                  continue;
+                }
                 if (ao < 0) ao = (long long)put(&a, sizeof a);
                 entry(kind, ens_round_blocks(a), 1, 512, 0, (size_t)ao);
                 continue;
@@ -3177,6 +3317,7 @@ struct Sim final : ssn_sim {
     dom_launches = 0; dom_ms = 0.0;
     for (int t = 0; t < N_ITEM_TYPES; ++t) { type_ms[t] = 0.0; type_launches[t] = 0; }
     if (fused_block && blk.slot_stats) HIPCHK(hipMemset(blk.slot_stats, 0, 16));
+    for (auto& z : zero_on_reset) HIPCHK(hipMemset(z.first, 0, z.second));
     return SSN_OK;
   }
 

@@ -157,7 +157,35 @@ __device__ __forceinline__ void ens_body(const EnsArgs<T>& a, const int bx, unsi
   T x[DIN];
   long long step = 0;
   if (a.xrows || a.defer) step = a.ctx->step + a.sub;
-  if (!a.defer) {
+  if (a.defer == 2) {
+    // Round plan (round 4): the array completes ITS OWN previous timestep.  Every workgroup of ensemble k sums the P partial
+    // sums that the ensemble's workgroups left at timestep s - 1 for the rows that feed its inputs, advances the recurrent
+    // filter states (identical values in every workgroup; workgroup p = 0 keeps them: fstate ping-pongs by timestep parity)
+    // and adds them to the rest of the input, which a micro-operator assembled in the signal vector.  The four rounds
+    // array -> finish -> Lowpass -> input -> array of every oscillator become one.
+    T* s_x = reinterpret_cast<T*>(smem) + 4 * DOUT;      // [DIN]
+    const int par = (int)(step & 1);
+    const long long NR = (long long)a.K * DOUT;
+    const T* prev = a.partials + (size_t)(par ^ 1) * a.partials_stride + (size_t)k * a.P * DOUT;
+    const int tid = threadIdx.x;
+    if (tid < DIN) {
+      const long long e = (long long)k * DIN + tid;
+      T xv = a.sig[a.x_off + e];
+      const int xr = a.xrow[e];
+      if (xr >= 0) {
+        const long long i = (long long)k * DOUT + xr;
+        T v = T(0);
+        for (int q = 0; q < a.P; ++q) v += prev[(size_t)q * DOUT + xr];
+        const T st = a.lp_a[i] * a.fstate[(size_t)(par ^ 1) * NR + i] + a.lp_b[i] * v;
+        if (p == 0) a.fstate[(size_t)par * NR + i] = st;
+        xv += a.xalpha[e] * st;
+      }
+      s_x[tid] = xv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < DIN; ++d) x[d] = s_x[d];
+  } else if (!a.defer) {
     const T* xsrc = a.sig;
     if (a.xrows) xsrc = a.xrows + (size_t)(step - a.ctx->block_start + 1) * a.n_sig;
 #pragma unroll

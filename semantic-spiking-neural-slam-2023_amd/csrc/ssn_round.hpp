@@ -127,6 +127,7 @@ __device__ __forceinline__ void glue_body(const MicroOp<T>& op, const int chunk,
     }
     case M_ENS_FINISH: {
       const T* part = (const T*)op.p0;
+      if (op.src > 0) part += (size_t)((ctx->step + sub) & 1) * (size_t)op.src;      // (the array keeps two sets of partial sums, by timestep parity)
       const int* didx = (const int*)op.p1;
       const int P = (int)op.i0, dout = (int)op.i1;
       const long long i = (long long)chunk * GLUE_ROWS + tid;
