@@ -111,7 +111,7 @@ typedef struct ssn_model_desc {
   int32_t n_buffers;
   int32_t n_ops;
   int32_t n_probes;
-  int32_t steps_per_graph;            /* timesteps captured per hipGraph (at most 64); 0 = library default (16), 1 = no graph */
+  int32_t steps_per_graph;            /* timesteps captured per hipGraph (at most 128); 0 = library default (64 where blocks hold whole graphs, else 16), 1 = no graph */
   const ssn_buffer_desc* buffers;
   const ssn_op_desc* ops;
   const ssn_probe_desc* probes;

@@ -666,7 +666,7 @@ struct Sim final : ssn_sim {
     // default: 64 timesteps per step graph where the time-batched blocks hold whole graphs (the software-pipelined round plan
     // fills and drains once per graph: SLAM config 3 106.3 us per timestep at 16, 105.9 at 32, 104.5 at 64 - round 4), else 16
     steps_per_graph = m->steps_per_graph != 0 ? m->steps_per_graph : ((block == 0 || block % 64 == 0) ? 64 : 16);
-    if (steps_per_graph > 64) return fail(SSN_EINVAL, "steps_per_graph %d: at most 64", steps_per_graph);
+    if (steps_per_graph > 128) return fail(SSN_EINVAL, "steps_per_graph %d: at most 128 (a glue block carries its timestep offset in 8 signed bits)", steps_per_graph);
     CHK(plan(m));
     CHK(capture());
     HIPCHK(hipStreamSynchronize(stream));
@@ -1822,10 +1822,12 @@ struct Sim final : ssn_sim {
     std::vector<double> load((size_t)nr, 0.0), lat((size_t)nr, 0.0);
     std::vector<double> us(N, 0.0);
     std::vector<int> blocks(N, 0);
+    std::map<int, double> serial;
     for (size_t i = 0; i < N; ++i) {
       double l = 0.0;
       cost(all[i].unit, &us[i], &l, &blocks[i]);
       load[(size_t)all[i].round] += us[i];
+      if (all[i].solo && all[i].chain >= 0) { serial[all[i].chain] += std::max(l, 1.0 + us[i]); l = serial[all[i].chain]; }      // a serial chain: one block, members back to back
       lat[(size_t)all[i].round] = std::max(lat[(size_t)all[i].round], l);
     }
     std::vector<Inst> extra;
@@ -2114,7 +2116,7 @@ struct Sim final : ssn_sim {
     round_launches.clear();
 
     // One instance of a unit: (unit, timestep offset inside the launch sequence, round).
-    struct Inst { int unit; int sub; int round; int lo = 0; int cnt = -1; int chain = -1; };      // blocks [lo, lo + cnt) of the unit's grid (cnt < 0: all)
+    struct Inst { int unit; int sub; int round; int lo = 0; int cnt = -1; int chain = -1; bool solo = false; };      // blocks [lo, lo + cnt) of the unit's grid (cnt < 0: all); solo: member of a serial chain
     // Chains: an element-wise micro-operator whose only hazards inside a round are with other element-wise micro-operators
     // on the SAME elements (equal ranges: a filter update behind the reduction it filters, the next step's input hand-off
     // behind that update) joins their round - one block then runs the chain's operators back to back on 256 elements, the
@@ -2126,6 +2128,57 @@ struct Sim final : ssn_sim {
         case ssn::M_ROW_IN: case ssn::M_ROW_OUT: case ssn::M_PROBE: case ssn::M_REDUCE_SET: case ssn::M_REDUCE_INC: return true;
         default: return false;
       }
+    };
+    // Serial chains (round 4, second half).  The long loop of a SLAM timestep - clean-up -> binding -> memory -> unbinding -> gate ->
+    // oscillator input, one synapse delay per hop - is partly made of operators that ONE workgroup executes: glue over 1 - 2
+    // thousand elements, the gate, the argmax + gather, the transforms of the circular convolutions.  A single-workgroup unit
+    // whose only predecessors in the round before its own are members of one such chain (or one such unit) joins it instead of
+    // opening a round: the chain's block (RK_SOLO, solo_body) runs its members in program order with a workgroup barrier
+    // between them - results pass through global memory inside one workgroup, workgroup-scope visibility is all that needs.
+    // Measured at SLAM config 3 (profiles/round4_serial_chains.txt): a member costs ~2 us (one trip for its data, one for its
+    // store to land before the barrier; ~4 us before the members' descriptors were staged in LDS), a transform ~9.5 us.
+    //   * glue / gate / argmax members only (default): 102.7 vs 104.7 us per timestep, any cap between 8 and 24 us;
+    //   * with the transforms as members (SSN_SOLO_DFT=1) the plan drops from 3.78 to 3.0 - 3.3 rounds per timestep and gets
+    //     SLOWER - 110.8 us at a cap of 12 us, 114.8 at 16, 129 at 22, 139 at 26: a round now lasts as long as its longest
+    //     chain (transform + members: 20 - 45 us) and the bandwidth-bound work does not fill the time under it;
+    //   * neuron-sharded plans (not pipelined over timesteps): no launch fewer, 157.8 vs 155.3 us - left off there.
+    // SSN_SOLO_CHAINS=0: off; SSN_SOLO_CAP_US: longest serial chain in estimated microseconds (default 16); SSN_SOLO_MAX_LEN:
+    // longest glue operator a single workgroup takes (default 2048 elements).
+    // LDS bytes of a transform as a round body
+    auto dft_lds = [&](const Item& it) {
+      size_t lds = (size_t)(it.dft.M > 0 ? it.dft.M : it.dft.N) * (it.dft.N1 > 0 ? 4 * sizeof(float) : 3 * sizeof(float2));
+      if (it.dft.inplace) {                         // in place: M + M / 8 points + M / (smallest radix) twiddles
+        int rmin = 8;
+        for (int q = 0; q < it.dft.nr; ++q) rmin = std::min(rmin, it.dft.radix[q]);
+        lds = (size_t)(it.dft.M + it.dft.M / 8 + it.dft.M / rmin) * sizeof(float2);
+      }
+      return lds;
+    };
+    const bool solo_on = !phased && !(flags & 134217728) && !(getenv("SSN_SOLO_CHAINS") && atoi(getenv("SSN_SOLO_CHAINS")) == 0);
+    const double solo_cap = getenv("SSN_SOLO_CAP_US") ? atof(getenv("SSN_SOLO_CAP_US")) : 16.0;
+    const bool solo_dft = getenv("SSN_SOLO_DFT") && atoi(getenv("SSN_SOLO_DFT")) == 1;      // transforms as chain members: measured slower (below)
+    const long long solo_max_len = getenv("SSN_SOLO_MAX_LEN") ? atoll(getenv("SSN_SOLO_MAX_LEN")) : 2048;
+    auto solo_lat = [&](const Unit& u) -> double {        // estimated serial time of the unit on one workgroup; < 0: not eligible
+      if (!solo_on) return -1.0;
+      if (u.mop >= 0) {
+        const MOp& op = mops[(size_t)u.mop];
+        switch (op.kind) {
+          // (measured on the chains of SLAM config 3: ~2 us per glue member - one trip for its data, one for the store to land
+          //  before the barrier - with its descriptor already in LDS; a transform ~9.5 us)
+          case ssn::M_GATE: case ssn::M_ARGMAX_GATHER: return 3.5;
+          case ssn::M_FILL: case ssn::M_AXPY_INC: case ssn::M_AXPY_SET: case ssn::M_LOWPASS: case ssn::M_TABLE:
+          case ssn::M_ROW_IN: case ssn::M_ROW_OUT: case ssn::M_PROBE:
+            return op.len <= solo_max_len ? 1.7 + 0.5 * (double)((op.len + ssn::GLUE_CHUNK - 1) / ssn::GLUE_CHUNK) : -1.0;
+          case ssn::M_LINCOMB:
+            return op.len <= solo_max_len ? 1.7 + (0.5 + 0.1 * (double)op.i0) * (double)((op.len + ssn::GLUE_CHUNK - 1) / ssn::GLUE_CHUNK) : -1.0;
+          case ssn::M_REDUCE_SET: case ssn::M_REDUCE_INC:
+            return op.len <= solo_max_len ? 1.7 + (double)((op.len + ssn::GLUE_ROWS - 1) / ssn::GLUE_ROWS) * (0.6 + 0.15 * (double)((op.i0 + 7) / 8)) : -1.0;
+          default: return -1.0;
+        }
+      }
+      const Item& it = items[(size_t)u.item];
+      if (solo_dft && it.type == IT_DFT && it.dft.N1 == 0 && sizeof(T) == 4 && dft_lds(it) <= 60 * 1024) return 9.5;
+      return -1.0;
     };
     // 0: no hazard, 1: hazards only on identical signal ranges (element-aligned), 2: any other hazard
     auto conflict_kind = [&](const std::vector<Rng>& x, const std::vector<Rng>& y) {
@@ -2145,15 +2198,54 @@ struct Sim final : ssn_sim {
       const bool can = chainable(uu);
       const long long len = can ? (long long)mops[(size_t)uu.mop].len : 0;
       int r_hard = base_round, r_soft = -1;
-      std::vector<size_t> soft;
+      std::vector<size_t> soft, hard;
       for (size_t v = from; v < placed.size(); ++v) {
-        if (placed[v].round < r_hard && placed[v].round < r_soft) continue;      // can neither raise a bound nor be a chain partner
+        if (placed[v].round < r_hard - 1 && placed[v].round < r_soft) continue;      // can neither raise a bound nor be a chain partner
         const Unit& vv = units[(size_t)placed[v].unit];
         const bool both = can && chainable(vv) && (long long)mops[(size_t)vv.mop].len == len;
         const int k = both ? conflict_kind(accs[(size_t)unit], accs[(size_t)placed[v].unit])
                            : (hazard(accs[(size_t)unit], accs[(size_t)placed[v].unit]) ? 2 : 0);
-        if (k == 2) r_hard = std::max(r_hard, placed[v].round + 1);
+        if (k == 2) { r_hard = std::max(r_hard, placed[v].round + 1); hard.push_back(v); }
         else if (k == 1) { r_soft = std::max(r_soft, placed[v].round); soft.push_back(v); }
+      }
+      // serial chain: every hard predecessor in round r_hard - 1 is a single-workgroup unit of ONE chain (or one such unit alone)
+      const double my_lat = solo_lat(uu);
+      if (my_lat >= 0.0 && r_hard - 1 >= base_round && r_hard - 1 > r_soft) {
+        int chain = -2;               // -2: none seen, -3: not joinable, -1: one unchained instance (lone), >= 0: a chain
+        size_t lone = 0;
+        for (size_t v : hard) {
+          if (placed[v].round != r_hard - 1) continue;
+          if (solo_lat(units[(size_t)placed[v].unit]) < 0.0 || placed[v].cnt >= 0) { chain = -3; break; }
+          if (placed[v].chain >= 0) {
+            if (chain == -2) chain = placed[v].chain;
+            else if (chain != placed[v].chain) { chain = -3; break; }
+          } else {
+            if (chain == -2) { chain = -1; lone = v; }
+            else { chain = -3; break; }
+          }
+        }
+        if (chain >= 0 || chain == -1) {
+          double total = my_lat;
+          bool ok = true;
+          int transforms = uu.mop < 0 ? 1 : 0;        // (at most one per chain: solo_body runs it outside its member loops)
+          if (chain >= 0 && chains[(size_t)chain].size() + 1 > (size_t)ssn::SOLO_MAX_MEMBERS) ok = false;
+          if (chain == -1) { total += solo_lat(units[(size_t)placed[lone].unit]); transforms += units[(size_t)placed[lone].unit].mop < 0 ? 1 : 0; }
+          else
+            for (int mi : chains[(size_t)chain]) {
+              const double l = solo_lat(units[(size_t)placed[(size_t)mi].unit]);
+              if (l < 0.0 || placed[(size_t)mi].round != r_hard - 1) { ok = false; break; }
+              total += l;
+              transforms += units[(size_t)placed[(size_t)mi].unit].mop < 0 ? 1 : 0;
+            }
+          if (ok && transforms <= 1 && total <= solo_cap) {
+            if (chain == -1) { chain = (int)chains.size(); placed[lone].chain = chain; chains.push_back({(int)lone}); }
+            for (int mi : chains[(size_t)chain]) placed[(size_t)mi].solo = true;
+            Inst in{unit, 0, r_hard - 1, 0, -1, chain, true};
+            chains[(size_t)chain].push_back((int)placed.size());
+            placed.push_back(in);
+            return in.round;
+          }
+        }
       }
       Inst in{unit, 0, std::max(r_hard, r_soft), 0, -1, -1};
       if (r_soft >= 0 && r_soft >= r_hard) {
@@ -2164,7 +2256,8 @@ struct Sim final : ssn_sim {
           if (chain == -2) chain = placed[v].chain;
           else if (chain != placed[v].chain) chain = -3;
         }
-        if (chain >= 0) { in.chain = chain; chains[(size_t)chain].push_back((int)placed.size()); }
+        if (chain >= 0 && placed[(size_t)chains[(size_t)chain][0]].solo && chains[(size_t)chain].size() + 1 > (size_t)ssn::SOLO_MAX_MEMBERS) chain = -3;
+        if (chain >= 0) { in.chain = chain; in.solo = placed[(size_t)chains[(size_t)chain][0]].solo; chains[(size_t)chain].push_back((int)placed.size()); }
         else in.round = r_soft + 1;            // element-aligned with members of two chains: a round of its own
       }
       placed.push_back(in);
@@ -2192,7 +2285,7 @@ struct Sim final : ssn_sim {
             int head = 0;
             for (int q = 0; q < rl.args.n; ++q) {
               const int k = rl.args.e[q].kind;
-              if (k == ssn::RK_DFT || k == ssn::RK_GATE || k == ssn::RK_ARGMAX || k == ssn::RK_GLUE) head = rl.args.e[q].first + rl.args.e[q].cnt;
+              if (k == ssn::RK_DFT || k == ssn::RK_SOLO || k == ssn::RK_GATE || k == ssn::RK_ARGMAX || k == ssn::RK_GLUE) head = rl.args.e[q].first + rl.args.e[q].cnt;
               else break;
             }
             const long long m = (long long)rl.n_blocks - head;
@@ -2221,7 +2314,7 @@ struct Sim final : ssn_sim {
           pending.push_back(q);
         };
         auto flush_entries = [&]() {
-          auto prio = [](const Pending& q) { return q.kind == ssn::RK_DFT ? 0 : (q.kind == ssn::RK_GATE || q.kind == ssn::RK_ARGMAX) ? 1 : q.kind == ssn::RK_GLUE ? 2 : 3; };
+          auto prio = [](const Pending& q) { return (q.kind == ssn::RK_DFT || q.kind == ssn::RK_SOLO) ? 0 : (q.kind == ssn::RK_GATE || q.kind == ssn::RK_ARGMAX) ? 1 : q.kind == ssn::RK_GLUE ? 2 : 3; };
           std::stable_sort(pending.begin(), pending.end(), [&](const Pending& a, const Pending& b) {
             if (prio(a) != prio(b)) return prio(a) < prio(b);
             return prio(a) == 3 && a.cnt > b.cnt;
@@ -2237,13 +2330,43 @@ struct Sim final : ssn_sim {
           }
           pending.clear();
         };
-        // glue: one entry for all chunked micro-operators of the round
+        // serial chains: one block each, members in program order behind workgroup barriers (RK_SOLO; see solo_lat)
         part_lo = 0; part_cnt = -1;
+        for (const Inst* in : by_round[(size_t)r]) {
+          if (!(in_chain(in) && in->solo)) continue;
+          const std::vector<int>& members = chains[(size_t)in->chain];
+          if (&insts[(size_t)members[0]] != in) continue;
+          phase = units[(size_t)in->unit].phase;
+          const int ofs = (int)chain_tab.size();
+          size_t lds = 64;
+          chain_tab.push_back((int)members.size());
+          if (getenv("SSN_DEBUG_PLAN")) fprintf(stderr, "[ssn]   serial chain in round %d:", r);
+          for (int mi : members) {
+            const Inst& m = insts[(size_t)mi];
+            const Unit& mu = units[(size_t)m.unit];
+            if (mu.mop >= 0) {
+              chain_tab.push_back(mu.mop);
+              if (getenv("SSN_DEBUG_PLAN")) fprintf(stderr, " k%d/%lld(s%d)", mops[(size_t)mu.mop].kind, (long long)mops[(size_t)mu.mop].len, m.sub);
+            } else {
+              const Item& it = items[(size_t)mu.item];      // (a transform: solo_lat admits nothing else)
+              long long& ao = unit_arg[(size_t)m.unit];
+              if (ao < 0) ao = (long long)put(&it.dft, sizeof it.dft);
+              chain_tab.push_back(-(int)(ao / 16) - 1);
+              lds = std::max(lds, dft_lds(it));
+              if (getenv("SSN_DEBUG_PLAN")) fprintf(stderr, " dft%d(s%d)", it.dft.kind, m.sub);
+            }
+            chain_tab.push_back(m.sub);
+          }
+          if (getenv("SSN_DEBUG_PLAN")) fprintf(stderr, "\n");
+          entry(ssn::RK_SOLO, 1, 1, lds, 3, (size_t)ofs);
+        }
+        // glue: one entry for all chunked micro-operators of the round
         const size_t map_begin = glue_map.size();
         for (const Inst* in : by_round[(size_t)r]) {
           const Unit& u = units[(size_t)in->unit];
           phase = u.phase;
           if (u.mop < 0) continue;
+          if (in_chain(in) && in->solo) continue;
           const MOp& op = mops[(size_t)u.mop];
           if (op.kind == ssn::M_GATE || op.kind == ssn::M_ARGMAX_GATHER) continue;
           if (in_chain(in)) {
@@ -2269,6 +2392,7 @@ struct Sim final : ssn_sim {
         for (const Inst* in : by_round[(size_t)r]) {
           const Unit& u = units[(size_t)in->unit];
           part_lo = in->lo; part_cnt = in->cnt;
+          if (in_chain(in) && in->solo) continue;
           if (u.mop >= 0) {
             const MOp& op = mops[(size_t)u.mop];
             if (op.kind == ssn::M_GATE) entry(ssn::RK_GATE, 1, 1, 64, 2, (size_t)u.mop);
@@ -2326,12 +2450,7 @@ struct Sim final : ssn_sim {
               continue;
             }
             case IT_DFT: {
-              size_t lds = (size_t)(it.dft.M > 0 ? it.dft.M : it.dft.N) * (it.dft.N1 > 0 ? 4 * sizeof(float) : 3 * sizeof(float2));
-              if (it.dft.inplace) {                         // in place: M + M / 8 points + M / (smallest radix) twiddles
-                int rmin = 8;
-                for (int q = 0; q < it.dft.nr; ++q) rmin = std::min(rmin, it.dft.radix[q]);
-                lds = (size_t)(it.dft.M + it.dft.M / 8 + it.dft.M / rmin) * sizeof(float2);
-              }
+              const size_t lds = dft_lds(it);
               if (lds <= 64 * 1024 && it.dft.N1 == 0) {      // (the four-step engine is launched on its own: see dft_body<ROUND>)
                 if (ao < 0) ao = (long long)put(&it.dft, sizeof it.dft);
                 entry(ssn::RK_DFT, 1, 1, lds, 0, (size_t)ao);
@@ -2389,7 +2508,8 @@ struct Sim final : ssn_sim {
       if (in_phase1 && one.back().chain >= 0 && (size_t)chains_one[(size_t)one.back().chain][0] < phase1_from) {
         // joined a chain that started before the exchange: undo, take the first round of phase 1 instead
         chains_one[(size_t)one.back().chain].pop_back();
-        one.back().chain = -1; one.back().round = std::max(r, phase1_base);
+        const int r_own = r + (one.back().solo ? 1 : 0);        // (a serial member sat one round before its hard bound)
+        one.back().chain = -1; one.back().solo = false; one.back().round = std::max(r_own, phase1_base);
         r = one.back().round;
       }
       n_rounds = std::max(n_rounds, r + 1);
@@ -2515,11 +2635,12 @@ struct Sim final : ssn_sim {
     CHK(dmalloc(&d_chain, (int64_t)(chain_tab.size() + 1) * 4));
     round_bufs.push_back(d_chain);
     if (!chain_tab.empty()) HIPCHK(hipMemcpy(d_chain, chain_tab.data(), chain_tab.size() * 4, hipMemcpyHostToDevice));
-    for (RoundLaunch& rl : round_launches) rl.args.chain = d_chain;
+    for (RoundLaunch& rl : round_launches) { rl.args.chain = d_chain; rl.args.arena = (const unsigned char*)d_arena; }
     for (const Fix& f : fixes) {
       ssn::RoundEntry& e = round_launches[f.rl].args.e[f.entry];
       if (f.what == 0) e.args = (const unsigned char*)d_arena + f.off;
       else if (f.what == 1) e.args = d_map + f.off;
+      else if (f.what == 3) e.args = d_chain + f.off;
       else e.args = d_mops + f.off;
     }
     if (getenv("SSN_DEBUG_PLAN")) {

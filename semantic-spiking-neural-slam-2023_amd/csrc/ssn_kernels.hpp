@@ -620,7 +620,8 @@ __device__ inline void dft_pass_inplace_r(int r, float2* z, const float2* T, int
 }
 
 // One mixed-radix Stockham pass structure over L points held in LDS (x -> result returned; y is scratch)
-__device__ inline float2* dft_stockham(float2* x, float2* y, const float2* tw, int L, const int* radix, int nr, int tid, int nthr) {
+template <typename RP>      // (RP: pointer to the radix list - generic, or constant address space inside a serial chain of a round)
+__device__ inline float2* dft_stockham(float2* x, float2* y, const float2* tw, int L, RP radix, int nr, int tid, int nthr) {
   // Generic radix: four output points per thread at a time: a radix-r butterfly is r dependent LDS round trips (value +
   // twiddle), and one wave per SIMD has nothing else to hide them behind - four independent chains do (a 256-thread workgroup
   // then runs a 1015-point transform as fast as 1024 threads with one point each).
@@ -830,7 +831,8 @@ __device__ __forceinline__ void dft4_body(const DftArgs& a, unsigned char* ssn_d
 // (ROUND = true: the body inside k_round never runs the four-step engine - its MFMA accumulators would add 8 AGPRs to the
 //  round kernel and take every body of every round from 7 to 6 waves per SIMD; such transforms are launched on their own)
 // Bluestein's convolution with both transforms in place (DftArgs::inplace): one LDS array of M points.
-__device__ __forceinline__ void dft_bluestein_inplace(const DftArgs& a, unsigned char* ssn_dft_dyn) {
+template <typename A>
+__device__ __forceinline__ void dft_bluestein_inplace(const A& a, unsigned char* ssn_dft_dyn) {
   const int N = a.N, H = N / 2 + 1, M = a.M, tid = threadIdx.x, nthr = blockDim.x;
   float2* z = reinterpret_cast<float2*>(ssn_dft_dyn);           // M + M / 8 points (padded), then the first M / (smallest radix) twiddles W_M^i
   float2* T = z + M + M / 8;
@@ -893,8 +895,8 @@ __device__ __forceinline__ void dft_bluestein_inplace(const DftArgs& a, unsigned
   }
 }
 
-template <bool ROUND = false>
-__device__ __forceinline__ void dft_body(const DftArgs& a, unsigned char* ssn_dft_dyn) {
+template <bool ROUND = false, typename A = DftArgs>
+__device__ __forceinline__ void dft_body(const A& a, unsigned char* ssn_dft_dyn) {
   if constexpr (!ROUND) { if (a.N1 > 0) { dft4_body(a, ssn_dft_dyn); return; } }
   if (a.M > 0 && a.inplace) { dft_bluestein_inplace(a, ssn_dft_dyn); return; }
   const int N = a.N, H = N / 2 + 1, tid = threadIdx.x, nthr = blockDim.x;

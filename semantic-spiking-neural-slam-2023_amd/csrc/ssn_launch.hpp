@@ -255,7 +255,9 @@ enum RoundKind {
   RK_MATVEC_R1, RK_MATVEC_R4, RK_SPMV, RK_NEURONS, RK_DFT, RK_PES, RK_VOJA,
   RK_ENS_3_4_S, RK_ENS_3_5_S, RK_ENS_1_1_D,     // k_ensarray<din, dout, spike-sparse | dense decoders>
   RK_ENS_SMALL,                                 // arrays of many small 1-D ensembles: a wave per ensemble, 16 per block (ens_small_body)
-  RK_GRID_LHS, RK_GRID_DOT                      // clean-up over a sample grid from its factor tables (round 4): left operand; similarities
+  RK_GRID_LHS, RK_GRID_DOT,                     // clean-up over a sample grid from its factor tables (round 4): left operand; similarities
+  RK_SOLO                                       // a serial chain of single-workgroup units, one block: args -> {n, code_0, sub_0, ...} in RoundArgs::chain;
+                                                // code >= 0: micro-operator index, code < 0: DftArgs at RoundArgs::arena + 16 * (-code - 1)
 };
 // Clean-up similarities of a 2-D sample grid without the pass over its table (reference slam.py:209-215: 10^4 x d every timestep,
 // 40 MB at d = 1015): sims[a * nn + r] = sum_k A[a][k] * W[r][k] with A = Re / -Im of conj(X) * lhs[a] (grid_lhs_body) and W the
@@ -269,6 +271,7 @@ struct GlueBlock { int op; int chunk; };        // micro-operator index (into Ro
 // needs no barrier and no launch of its own when the same thread handles the same index in program order.
 struct RoundEntry { int kind; int first; int gx; int gy; const void* args; int lo; int cnt; };   // blocks [lo, lo + cnt) of the gx x gy grid
 constexpr int MAX_ROUND_ENTRIES = 96;
+constexpr int SOLO_MAX_MEMBERS = 24;         // members of a serial chain (their descriptors are staged in LDS)
 template <typename T>
 struct RoundArgs {
   int n;
@@ -282,6 +285,7 @@ struct RoundArgs {
   int pad;
   const MicroOp<T>* mops;
   const int* chain;
+  const unsigned char* arena;   // body arguments of the plan (serial chains address their transforms through it)
   T* sig;
   StepCtx* ctx;
   RoundEntry e[MAX_ROUND_ENTRIES];

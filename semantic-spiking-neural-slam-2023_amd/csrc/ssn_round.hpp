@@ -226,6 +226,60 @@ __device__ __forceinline__ void argmax_gather_body(const MicroOp<T>& op, T* __re
   for (long long i = tid; i < op.len; i += 256) d[i] = trow[i];
 }
 
+// A serial chain (RK_SOLO): single-workgroup units in program order, a workgroup barrier between them.  At most one transform
+// per chain, and it runs OUTSIDE the member loops (table: {n, code_0, sub_0, ...}; code < 0: the transform): inside a loop its
+// descriptor and addressing stay live around the back edge and cost every block of the round kernel ~20 VGPRs.
+template <typename T>
+__device__ __forceinline__ void solo_body(const RoundArgs<T>& ra, const int* __restrict__ ch, unsigned char* smem) {
+  // The chain table and the members' descriptors go to LDS first, all loads in flight together: read one at a time behind the
+  // barrier of the member before, each member would start with two dependent trips to memory (table entry -> descriptor)
+  // before the first load of its data - measured ~4 us per member instead of ~2.
+  __shared__ int s_tab[2 * SOLO_MAX_MEMBERS + 2];
+  __shared__ __align__(16) unsigned char s_ops[SOLO_MAX_MEMBERS * sizeof(MicroOp<T>)];
+  const int tid = threadIdx.x;
+  const int n = __builtin_amdgcn_readfirstlane(min(ch[0], SOLO_MAX_MEMBERS));
+  if (tid < 2 * n) s_tab[tid] = ch[1 + tid];
+  {
+    constexpr int DW = (int)(sizeof(MicroOp<T>) / 4);
+    static_assert(sizeof(MicroOp<T>) % 4 == 0, "descriptor copied by dwords");
+    for (int i = tid; i < n * DW; i += 256) {
+      const int q = i / DW, w = i - q * DW;
+      const int code = ch[1 + 2 * q];
+      if (code >= 0) reinterpret_cast<int*>(s_ops)[i] = reinterpret_cast<const int*>(ra.mops + code)[w];
+    }
+  }
+  __syncthreads();
+  auto members = [&](int q0, int q1) {
+#pragma unroll 1
+    for (int q = q0; q < q1; ++q) {
+      const int sub = __builtin_amdgcn_readfirstlane(s_tab[2 * q + 1]);
+      if (q) __syncthreads();
+      const MicroOp<T>& op = reinterpret_cast<const MicroOp<T>*>(s_ops)[q];
+      if (op.kind == M_GATE) gate_body<T>(op, ra.sig, smem);
+      else if (op.kind == M_ARGMAX_GATHER) argmax_gather_body<T>(op, ra.sig, smem);
+      else {
+        const bool rows = op.kind == M_MATVEC_INC || op.kind == M_MATVEC_SET || op.kind == M_ENS_FINISH || op.kind == M_REDUCE_SET || op.kind == M_REDUCE_INC;
+        const int chunks = (int)((op.len + (rows ? GLUE_ROWS : GLUE_CHUNK) - 1) / (rows ? GLUE_ROWS : GLUE_CHUNK));
+#pragma unroll 1
+        for (int c = 0; c < chunks; ++c) glue_body<T>(op, c, sub, ra.sig, ra.ctx);
+      }
+    }
+  };
+  int qd = n;                     // position of the transform (n: none)
+#pragma unroll 1
+  for (int q = 0; q < n; ++q) if (s_tab[2 * q] < 0) qd = q;
+  qd = __builtin_amdgcn_readfirstlane(qd);
+  members(0, qd);
+  if (qd < n) {
+    if (qd) __syncthreads();
+    // (the descriptor is read through the constant address space: behind the stores of the members before it the compiler
+    //  would otherwise fetch its uniform fields with vector loads and hold them in VGPRs)
+    typedef const __attribute__((address_space(4))) DftArgs DftArgsK;
+    if constexpr (sizeof(T) == 4) dft_body<true, DftArgsK>(*(DftArgsK*)(uintptr_t)(ra.arena + (size_t)(-s_tab[2 * qd] - 1) * 16), smem);
+    members(qd + 1, n);
+  }
+}
+
 // One virtual block of a round.
 template <typename T>
 __device__ __forceinline__ void round_block(const RoundArgs<T>& ra, int vb, unsigned char* smem) {
@@ -247,6 +301,7 @@ __device__ __forceinline__ void round_block(const RoundArgs<T>& ra, int vb, unsi
       }
       break;
     }
+    case RK_SOLO: solo_body<T>(ra, (const int*)e.args, smem); break;
     case RK_GATE: gate_body<T>(*(const MicroOp<T>*)e.args, ra.sig, smem); break;
     case RK_ARGMAX: argmax_gather_body<T>(*(const MicroOp<T>*)e.args, ra.sig, smem); break;
     case RK_MATVEC_R1: matvec_body<T, true, 1, 4>(*(const MatvecArgs<T>*)e.args, bx, smem); break;

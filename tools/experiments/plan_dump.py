@@ -13,7 +13,7 @@ print("ops by stage/kind:", collections.Counter((o["stage"], o["kind"]) for o in
 for o in bm.ops:
     if o["stage"] == 1:
         print({k: (v if not hasattr(v, "shape") else v.shape) for k, v in o.items() if k in ("kind", "level", "dst", "src", "len", "rows", "cols", "mode", "alpha", "a", "K", "n", "dout", "dft", "x", "j", "out", "err", "act", "spk", "key")})
-sim = Simulator(None, model=bm, dtype="f32")
+sim = Simulator(None, model=bm, dtype="f32", steps_per_graph=int(os.environ.get("SSN_SPG", "0")))
 sim.prepare(400)
 sim.run_steps(100, collect=False)
 sim.run_steps(100, profile=2, collect=False)
