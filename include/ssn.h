@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSN_ABI_VERSION 7
+#define SSN_ABI_VERSION 8
 
 enum ssn_status {
   SSN_OK = 0,
@@ -254,6 +254,13 @@ int ssn_write_buffer(ssn_sim* sim, int32_t buffer_id, const double* src, int64_t
  * sampling, step counter; phase 2 = phase 1 followed by phase 0 of the next timestep in one launch, for the inside of a
  * run: 0, x, 2, x, 2, ..., x, 1 with x the caller's exchange).  Blocking.  ssn_run_steps refuses such models. */
 int ssn_run_phase(ssn_sim* sim, int32_t phase);
+/* Pipelined over the exchange (ABI 8): C = ssn_cycle_steps() timesteps planned together as C + 1 launch segments, the exchange
+ * of timestep k between segments k and k + 1 - what does not hang on that exchange (the head of timestep k + 1) shares rounds
+ * with what does.  phase = 3 (ssn_run_phase and ssn_phase_async alike) runs the next segment; a cycle is
+ *   3, x, 3, x, ..., x, 3   (C + 1 segments, C exchanges x)
+ * it starts at a timestep boundary, and phases 0 / 1 / 2 are refused until its last segment has run (they serve the timesteps that
+ * do not fill a cycle).  0: the model has no such plan (not neuron-sharded, or planned with flag 8388608 / SSN_CYCLE_STEPS=0). */
+int64_t ssn_cycle_steps(ssn_sim* sim);
 /* Elements of the exchange (sum of the range lengths); copy them to / from one contiguous device buffer of the simulator's dtype. */
 int64_t ssn_exchange_size(ssn_sim* sim);
 int ssn_exchange_pack(ssn_sim* sim, void* dst_dev);
@@ -268,7 +275,8 @@ int ssn_exchange_unpack(ssn_sim* sim, const void* src_dev);
  * exchange_buf: device buffer of ssn_exchange_size() elements of the simulator's dtype, the same pointer throughout a run (it is
  * captured into the graphs); NULL when the caller does not exchange (a single rank).  A run is
  *   ssn_phase_async(0), [collective on hip_stream], ssn_phase_async(2), [collective], ..., ssn_phase_async(1), ssn_phase_sync.
- * phase = -1 only builds the graphs for exchange_buf (otherwise built by the first call of a run) and launches nothing. */
+ * phase = -1 only builds the graphs for exchange_buf (otherwise built by the first call of a run) and launches nothing;
+ * phase = 3: the next segment of a pipelined cycle (ssn_cycle_steps above), [unpack] / [pack] around it as for phases 2 / 0. */
 int ssn_phase_async(ssn_sim* sim, int32_t phase, void* exchange_buf, void* hip_stream);
 /* Waits for everything ssn_phase_async enqueued on that stream; checks the device step counter and the probe-overflow flag. */
 int ssn_phase_sync(ssn_sim* sim, void* hip_stream);

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSN_HIP_LIB") or os.path.join(_HERE, "libssn_hip.so")     # override: A/B builds of the library
 
-SSN_ABI_VERSION = 7
+SSN_ABI_VERSION = 8
 SSN_F32, SSN_F64 = 0, 1
 SSN_BUF_REAL, SSN_BUF_I32 = 0, 1
 NEURON_CODE = {"lif": 0, "lifrate": 1, "relu": 2}
@@ -81,6 +81,7 @@ EXPORTS = {
     "ssn_write_buffer": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "ssn_run_phase": (C.c_int, [C.c_void_p, C.c_int32]),
     "ssn_exchange_size": (C.c_int64, [C.c_void_p]),
+    "ssn_cycle_steps": (C.c_int64, [C.c_void_p]),
     "ssn_exchange_pack": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ssn_exchange_unpack": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ssn_phase_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

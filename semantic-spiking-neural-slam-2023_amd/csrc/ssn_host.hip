@@ -88,7 +88,9 @@ struct Buf {
 };
 
 enum ItemType { IT_PROGRAM = 0, IT_ENS, IT_MATVEC, IT_NEURONS, IT_PES, IT_VOJA, IT_MATVEC_ORDERED, IT_FINISH, IT_SPMV, IT_DFT, IT_VECOPS, IT_GRID_LHS, IT_GRID_GEMM, IT_ARGMAX_PART, IT_ROUND,
-                IT_GRID_DOT };      // (a body of the round grid only)
+                IT_GRID_DOT,        // (a body of the round grid only)
+                IT_MATVEC_NEURONS,  // (round plan) a dense population's encoder product with the neuron update in its epilogue
+                IT_NONE };          // (round plan) an operator that was folded into another one
 
 }  // namespace
 
@@ -103,6 +105,7 @@ struct ssn_sim {
   virtual int run_steps(int64_t n, int profile) = 0;
   virtual int run_phase(int phase) = 0;
   virtual int64_t exchange_size() = 0;
+  virtual int64_t cycle_len() = 0;
   virtual int exchange_copy(void* buf, bool pack) = 0;
   virtual int phase_async(int phase, void* buf, hipStream_t ext) = 0;
   virtual int phase_sync(hipStream_t ext) = 0;
@@ -136,6 +139,7 @@ struct Sim final : ssn_sim {
     ssn::NeuronParams<T> np;
     int* list = nullptr; int* count = nullptr;     // spike list (k_neurons_compact -> k_spmv_partial)
     int seg = 0;                                   // > 0: segmented spike list (k_neurons), segments per spmv chunk
+    int seg_len = 256;                             // neurons per list segment (16: written by a fused product + neuron update)
     int level = -1;                                // scheduling round of the operator (builder): equal level = independent
     int phase = -1;                                // neuron-sharded models: 0 before the per-timestep exchange, 1 after (set by plan())
     T* lp_dst = nullptr; const T* lp_src = nullptr; T lp_a = 0, lp_b = 0;      // IT_PES: folded filter of the row factors (build_rounds)
@@ -198,6 +202,12 @@ struct Sim final : ssn_sim {
   std::vector<RoundLaunch> round_launches;
   std::vector<Launch> launch_list;            // one timestep
   std::vector<Launch> graph_list;             // steps_per_graph timesteps, software-pipelined (empty: replay launch_list)
+  // neuron-sharded models, pipelined (round 4): cycle_steps timesteps as cycle_steps + 1 launch segments; the caller's exchange of
+  // timestep k sits between segments k and k + 1 (ssn_run_phase / ssn_phase_async with phase 3 = "the next segment")
+  std::vector<std::vector<Launch>> cycle_segs;
+  int cycle_steps = 0, next_seg = 0;
+  std::vector<hipGraph_t> cycle_graph;
+  std::vector<hipGraphExec_t> cycle_exec;
   std::vector<Launch> phase2_list;            // neuron-sharded models: the updates of timestep s and timestep s + 1 up to its exchange,
                                               // planned as ONE set of rounds (empty: the two halves one after the other)
   int graph_rounds = 0;
@@ -251,7 +261,7 @@ struct Sim final : ssn_sim {
   void* async_buf = nullptr;
   bool async_captured = false, async_active = false;
   hipStream_t async_stream = nullptr;         // the caller's stream a stream-ordered run is in flight on (while async_active)
-  static constexpr int N_ITEM_TYPES = 16;
+  static constexpr int N_ITEM_TYPES = 18;
   double type_ms[N_ITEM_TYPES] = {};             // profile = 2: device time per plan-item type
   int64_t type_launches[N_ITEM_TYPES] = {};
   std::vector<double> item_ms;                   // ... and per plan item (printed under SSN_DEBUG_PLAN)
@@ -269,6 +279,7 @@ struct Sim final : ssn_sim {
       if (async_exec[h]) hipGraphExecDestroy(async_exec[h]);
       if (async_graph[h]) hipGraphDestroy(async_graph[h]);
     }
+    drop_cycle_graphs();
     for (auto& b : bufs) if (b.d) hipFree(b.d);
     for (auto p : table_rows) if (p) hipFree(p);
     for (auto p : table_idx) if (p) hipFree(p);
@@ -1804,6 +1815,7 @@ struct Sim final : ssn_sim {
       case IT_VOJA: *us = 0.2 * it.rows * it.ld * sizeof(T) / per_us; break;
       case IT_SPMV: *us = 0.1 * (double)it.cols * it.ld * sizeof(T) / per_us; break;
       case IT_NEURONS: *us = (double)it.n * 5.0 * sizeof(T) / per_us; break;
+      case IT_MATVEC_NEURONS: *us = (double)it.rows * it.ld * sizeof(T) / per_us; *blocks = (it.rows + 15) / 16; break;
       case IT_DFT: *lat = 9.0; break;
       default: *us = 1.0; break;
     }
@@ -2003,7 +2015,7 @@ struct Sim final : ssn_sim {
     // workgroup that has read row r's factor advances it) takes one of them out.  Round 2 measured this fold slower because the
     // oscillators' own four-round recurrence kept the period at four; it pays together with the oscillator array completing
     // its previous timestep itself (below).  SSN_PES_FOLD=0: off.
-    if (!phased && !(getenv("SSN_PES_FOLD") && atoi(getenv("SSN_PES_FOLD")) == 0))
+    if ((!phased || (getenv("SSN_PHASED_PES_FOLD") && atoi(getenv("SSN_PHASED_PES_FOLD")) == 1)) && !(getenv("SSN_PES_FOLD") && atoi(getenv("SSN_PES_FOLD")) == 0))
       for (size_t i = 0; i < items.size(); ++i) {
         Item& pe = items[i];
         if (pe.type != IT_PES || pe.cols > 1024 || !(pe.aux0 >= sig && pe.aux0 < sig + n_sig)) continue;
@@ -2023,6 +2035,68 @@ struct Sim final : ssn_sim {
             }
         }
       }
+    // Round 4: the neuron update of a dense population in the epilogue of its encoder product.  A population hop is four
+    // dependent rounds - product (J += W x) -> neurons -> sparse decode over the spike list -> reduction (+ filter) - and a
+    // neuron-sharded timestep adds the exchange and the filter behind it: six rounds between two exchanges.  Where the product is
+    // the last writer of the current vector J before the neurons, nothing else ever reads J, and nothing between the two touches
+    // the product's operands, the workgroup that owns 16 rows steps their 16 neurons itself (matvec_neurons_body).  The fused
+    // operator takes the neurons' place in program order (whatever reads the previous timestep's spikes between the two still
+    // comes first).  SSN_FUSE_NEURONS=0: off.
+    if (!(getenv("SSN_FUSE_NEURONS") && atoi(getenv("SSN_FUSE_NEURONS")) == 0)) {
+      // accesses of every operator in program order: (item index, accesses)
+      std::vector<std::pair<int, std::vector<Rng>>> seq;
+      {
+        int pj = 0;
+        for (size_t i = 0; i < items.size(); ++i) {
+          if (items[i].type == IT_PROGRAM) {
+            for (const MOp& op : programs[(size_t)item_prog[(size_t)pj]]) { seq.push_back({(int)i, {}}); micro_access(seq.back().second, op, false); }
+            ++pj;
+          } else {
+            seq.push_back({(int)i, {}});
+            item_access(seq.back().second, items[i]);
+          }
+        }
+      }
+      for (size_t jn = 0; jn < items.size(); ++jn) {
+        Item& N = items[jn];
+        if (N.type != IT_NEURONS || !(N.src >= sig && N.src < sig + n_sig)) continue;
+        const int64_t j0 = N.src - sig, j1 = j0 + N.n;
+        int jm = -1;
+        for (size_t j = 0; j < jn; ++j)
+          if (items[j].type == IT_MATVEC && items[j].dst == N.src && items[j].rows == N.n) jm = (int)j;
+        if (jm < 0) continue;
+        const Item& M = items[(size_t)jm];
+        if ((size_t)M.cols * sizeof(T) > 48 * 1024 || M.rows <= 4096 || M.phase != N.phase) continue;
+        std::vector<Rng> accM;
+        item_access(accM, M);
+        bool ok = true;
+        for (const auto& e : seq) {
+          if (e.first == jm || e.first == (int)jn) continue;
+          for (const Rng& r : e.second) {
+            if (r.space != (const void*)sig || r.lo >= j1 || j0 >= r.hi) continue;
+            if (!r.w) ok = false;                                        // another reader of J
+            else if (e.first > jm && e.first < (int)jn) ok = false;      // another writer between the product and the neurons
+            else if (e.first > (int)jn) ok = false;                      // (a writer behind the neurons: not the pattern)
+          }
+          if (e.first > jm && e.first < (int)jn && hazard(e.second, accM)) ok = false;      // the product's operands change on the way
+          if (!ok) break;
+        }
+        if (!ok) continue;
+        if (N.list) {                        // spike list in 16-neuron segments: counts per small segment, the spans of the products stay
+          int* cnt = nullptr;
+          const int n_small = (N.n + 15) / 16;
+          CHK(dmalloc(&cnt, (int64_t)n_small * 4 + 64));
+          HIPCHK(hipMemset(cnt, 0, (size_t)n_small * 4 + 64));
+          scratch_bufs.push_back(cnt);
+          for (Item& sp : items) if (sp.type == IT_SPMV && sp.list == N.list) { sp.count = cnt; sp.seg_len = 16; }
+          N.count = cnt;
+        }
+        N.type = IT_MATVEC_NEURONS;
+        N.Wm = M.Wm; N.aux0 = M.src; N.rows = M.rows; N.cols = M.cols; N.ld = M.ld; N.set = M.set;
+        items[(size_t)jm].type = IT_NONE;
+        if (getenv("SSN_DEBUG_PLAN")) fprintf(stderr, "[ssn] encoder product %d x %d and the update of its %d neurons fused (items %d, %zu)\n", N.rows, N.cols, N.n, jm, jn);
+      }
+    }
     // Element-wise micro-operators are cut at every range endpoint of the other operators.  The builder merges
     // neighbouring resets / hand-offs into one long operator (one fill over all accumulators of a network); as a unit
     // it would inherit the hazards of every signal it spans - the reset of an accumulator that is read in the last
@@ -2096,7 +2170,7 @@ struct Sim final : ssn_sim {
           units.push_back(std::move(u));
         }
         ++prog_i;
-      } else {
+      } else if (it.type != IT_NONE) {
         Unit u; u.item = (int)i; u.phase = std::max(0, it.phase);
         item_access(u.acc, it);
         units.push_back(std::move(u));
@@ -2154,7 +2228,7 @@ struct Sim final : ssn_sim {
       }
       return lds;
     };
-    const bool solo_on = !phased && !(flags & 134217728) && !(getenv("SSN_SOLO_CHAINS") && atoi(getenv("SSN_SOLO_CHAINS")) == 0);
+    const bool solo_on = (!phased || (getenv("SSN_PHASED_SOLO") && atoi(getenv("SSN_PHASED_SOLO")) == 1)) && !(flags & 134217728) && !(getenv("SSN_SOLO_CHAINS") && atoi(getenv("SSN_SOLO_CHAINS")) == 0);
     const double solo_cap = getenv("SSN_SOLO_CAP_US") ? atof(getenv("SSN_SOLO_CAP_US")) : 16.0;
     const bool solo_dft = getenv("SSN_SOLO_DFT") && atoi(getenv("SSN_SOLO_DFT")) == 1;      // transforms as chain members: measured slower (below)
     const long long solo_max_len = getenv("SSN_SOLO_MAX_LEN") ? atoll(getenv("SSN_SOLO_MAX_LEN")) : 2048;
@@ -2176,6 +2250,7 @@ struct Sim final : ssn_sim {
           default: return -1.0;
         }
       }
+      if (u.item < 0) return -1.0;            // (the exchange of a sharded cycle plan)
       const Item& it = items[(size_t)u.item];
       if (solo_dft && it.type == IT_DFT && it.dft.N1 == 0 && sizeof(T) == 4 && dft_lds(it) <= 60 * 1024) return 9.5;
       return -1.0;
@@ -2330,6 +2405,9 @@ struct Sim final : ssn_sim {
           }
           pending.clear();
         };
+        // the exchange of a neuron-sharded cycle plan (a unit without operator): the caller's all-reduce comes before this round
+        for (const Inst* in : by_round[(size_t)r])
+          if (units[(size_t)in->unit].mop < 0 && units[(size_t)in->unit].item < 0) { Launch x; x.phase = -2; out.push_back(x); }
         // serial chains: one block each, members in program order behind workgroup barriers (RK_SOLO; see solo_lat)
         part_lo = 0; part_cnt = -1;
         for (const Inst* in : by_round[(size_t)r]) {
@@ -2393,6 +2471,7 @@ struct Sim final : ssn_sim {
           const Unit& u = units[(size_t)in->unit];
           part_lo = in->lo; part_cnt = in->cnt;
           if (in_chain(in) && in->solo) continue;
+          if (u.mop < 0 && u.item < 0) continue;        // (the exchange marker)
           if (u.mop >= 0) {
             const MOp& op = mops[(size_t)u.mop];
             if (op.kind == ssn::M_GATE) entry(ssn::RK_GATE, 1, 1, 64, 2, (size_t)u.mop);
@@ -2405,10 +2484,16 @@ struct Sim final : ssn_sim {
           switch (it.type) {
             case IT_MATVEC:
               if (xb <= 48 * 1024) {
-                ssn::MatvecArgs<T> a{it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set};
-                if (ao < 0) ao = (long long)put(&a, sizeof a);
                 const bool r1 = it.rows <= 4096;
-                entry(r1 ? ssn::RK_MATVEC_R1 : ssn::RK_MATVEC_R4, r1 ? (it.rows + 3) / 4 : (it.rows + 15) / 16, 1, xb, 0, (size_t)ao);
+                if (r1) {
+                  ssn::MatvecArgs<T> a{it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set};
+                  if (ao < 0) ao = (long long)put(&a, sizeof a);
+                } else {                 // (the 16-rows-per-workgroup body is matvec_neurons_body's: no population behind this product)
+                  ssn::MatvecNeuronsArgs<T> a{};
+                  a.mv = ssn::MatvecArgs<T>{it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set};
+                  if (ao < 0) ao = (long long)put(&a, sizeof a);
+                }
+                entry(r1 ? ssn::RK_MATVEC_R1 : ssn::RK_MATVEC_R4, r1 ? (it.rows + 3) / 4 : (it.rows + 15) / 16, 1, (xb + 15) / 16 * 16 + 64, 0, (size_t)ao);
                 continue;
               }
               break;
@@ -2434,7 +2519,7 @@ struct Sim final : ssn_sim {
               break;
             }
             case IT_SPMV: {
-              ssn::SpmvArgs<T> a{it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count, it.seg};
+              ssn::SpmvArgs<T> a{it.Wm, it.ld, it.src, it.cols, it.rows, it.dst, it.ld, it.n, it.list, it.count, it.seg, it.seg_len};
               const size_t lds = 272 * sizeof(int) + (it.list ? 0 : (size_t)it.cols * sizeof(int));
               if (lds <= 60 * 1024) {
                 if (ao < 0) ao = (long long)put(&a, sizeof a);
@@ -2447,6 +2532,13 @@ struct Sim final : ssn_sim {
               ssn::NeuronsArgs<T> a{it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count};
               if (ao < 0) ao = (long long)put(&a, sizeof a);
               entry(ssn::RK_NEURONS, (it.n + 255) / 256, 1, 64, 0, (size_t)ao);
+              continue;
+            }
+            case IT_MATVEC_NEURONS: {
+              ssn::MatvecNeuronsArgs<T> a{ssn::MatvecArgs<T>{it.Wm, it.aux0, nullptr, it.rows, it.cols, it.ld, it.set},
+                                          ssn::NeuronsArgs<T>{it.np, it.src, it.dst, it.V, it.R, it.n, it.scalar, it.list, it.count}};
+              if (ao < 0) ao = (long long)put(&a, sizeof a);
+              entry(ssn::RK_MATVEC_NEURONS, (it.rows + 15) / 16, 1, (xb + 15) / 16 * 16 + 64, 0, (size_t)ao);
               continue;
             }
             case IT_DFT: {
@@ -2490,6 +2582,27 @@ struct Sim final : ssn_sim {
         for (const Launch& l : plain) out.push_back(l);      // the plain launches first (ensemble arrays: the long ones), then the round's grid
         flush_entries();
         close();
+      }
+    };
+
+    // (diagnostic) the chain of binding hazards behind the last instance of a pipelined plan: what its period is made of
+    auto print_critical_chain = [&](const std::vector<Inst>& all, const std::vector<std::vector<Rng>>& accs) {
+      size_t cur = 0;
+      for (size_t i = 0; i < all.size(); ++i) if (all[i].round >= all[cur].round) cur = i;
+      fprintf(stderr, "[ssn] critical chain (backwards from the last round):\n");
+      for (int hop = 0; hop < 70 && all[cur].round > 0; ++hop) {
+        const Unit& u = units[(size_t)all[cur].unit];
+        if (u.mop >= 0) fprintf(stderr, "[ssn]   round %3d step %2d micro %d/%lld dst %lld\n", all[cur].round, all[cur].sub, mops[(size_t)u.mop].kind, (long long)mops[(size_t)u.mop].len, (long long)mops[(size_t)u.mop].dst);
+        else if (u.item < 0) fprintf(stderr, "[ssn]   round %3d step %2d EXCHANGE\n", all[cur].round, all[cur].sub);
+        else fprintf(stderr, "[ssn]   round %3d step %2d item %d type %d rows %d cols %d\n", all[cur].round, all[cur].sub, u.item, items[(size_t)u.item].type, items[(size_t)u.item].rows, items[(size_t)u.item].cols);
+        size_t prev = cur;
+        for (size_t v = cur; v-- > 0;)
+          if (all[v].round == all[cur].round - 1 && hazard(accs[(size_t)all[cur].unit], accs[(size_t)all[v].unit])) { prev = v; break; }
+        if (prev == cur)          // a chain member: its predecessor sits in the same round, in the same block
+          for (size_t v = cur; v-- > 0;)
+            if (all[v].round == all[cur].round && all[v].chain >= 0 && all[v].chain == all[cur].chain) { prev = v; break; }
+        if (prev == cur) break;
+        cur = prev;
       }
     };
 
@@ -2549,25 +2662,7 @@ struct Sim final : ssn_sim {
           all.back().sub = st;
           nr = std::max(nr, r + 1);
         }
-      if (getenv("SSN_DEBUG_PLAN")) {
-        // the chain of binding hazards behind the last instance: what the steady-state period is made of
-        size_t cur = 0;
-        for (size_t i = 0; i < all.size(); ++i) if (all[i].round >= all[cur].round) cur = i;
-        fprintf(stderr, "[ssn] critical chain (backwards from the last round):\n");
-        for (int hop = 0; hop < 70 && all[cur].round > 0; ++hop) {
-          const Unit& u = units[(size_t)all[cur].unit];
-          if (u.mop >= 0) fprintf(stderr, "[ssn]   round %3d step %2d micro %d/%lld dst %lld\n", all[cur].round, all[cur].sub, mops[(size_t)u.mop].kind, (long long)mops[(size_t)u.mop].len, (long long)mops[(size_t)u.mop].dst);
-          else fprintf(stderr, "[ssn]   round %3d step %2d item %d type %d rows %d cols %d\n", all[cur].round, all[cur].sub, u.item, items[(size_t)u.item].type, items[(size_t)u.item].rows, items[(size_t)u.item].cols);
-          size_t prev = cur;
-          for (size_t v = cur; v-- > 0;)
-            if (all[v].round == all[cur].round - 1 && hazard(acc_nc[(size_t)all[cur].unit], acc_nc[(size_t)all[v].unit])) { prev = v; break; }
-          if (prev == cur)          // a chain member: its predecessor sits in the same round, in the same block
-            for (size_t v = cur; v-- > 0;)
-              if (all[v].round == all[cur].round && all[v].chain >= 0 && all[v].chain == all[cur].chain) { prev = v; break; }
-          if (prev == cur) break;
-          cur = prev;
-        }
-      }
+      if (getenv("SSN_DEBUG_PLAN")) print_critical_chain(all, acc_nc);
       if (getenv("SSN_DEBUG_DEPS")) {
         // what every instance of the steady-state rounds waits for in the round before it (diagnostic for in-launch dependencies)
         auto name = [&](const Inst& in) {
@@ -2622,6 +2717,79 @@ struct Sim final : ssn_sim {
       emit(comb, nr, phase2_list, chains_comb);
       if (getenv("SSN_DEBUG_PLAN")) fprintf(stderr, "[ssn] phased plan: %zu launches per timestep apart (phase 0 + phase 1), %zu with the updates of s and the head of s + 1 planned together\n", launch_list.size(), phase2_list.size());
       launches_per_step = (int)phase2_list.size();
+    }
+
+    // ---- neuron-sharded models, pipelined over the exchange (round 4).  The plan above still starts every
+    // timestep from an empty chip behind its exchange: ten rounds per timestep, none of them shared with another timestep.  Here
+    // the exchange of timestep s is a unit of the plan like any other - it reads and writes the exchanged signal ranges, so the
+    // operators that complete the partial sums come before it and their consumers (synapse filters, probes) behind it - and C
+    // timesteps are placed together as in the unsharded step graph: what does not hang on the exchange of s (the head of
+    // s + 1: tabulated inputs, encoder products, neuron updates of populations whose input is ready) shares rounds with the
+    // tail of s.  The launch sequence is cut at the exchanges into C + 1 segments; the caller runs segment, all-reduce,
+    // segment, ... (phase 3), the clock advances by C behind the last one.  SSN_CYCLE_STEPS: C (default 16; 0: off).
+    cycle_segs.clear();
+    cycle_steps = 0;
+    {
+      const int C = getenv("SSN_CYCLE_STEPS") ? atoi(getenv("SSN_CYCLE_STEPS")) : 16;
+      if (phased && C > 1 && C <= 64 && !(flags & 8388608) && (units.size() + 1) * (size_t)C <= 40000) {
+        const int xu = (int)units.size();
+        {
+          Unit x; x.phase = 0; x.writes = true;
+          for (auto& r : exchange) x.acc.push_back(Rng{(const void*)sig, (int64_t)r.lo, (int64_t)r.hi, true});
+          units.push_back(std::move(x));
+          unit_arg.push_back(-1);
+        }
+        std::vector<std::vector<Rng>> acc_c(units.size());
+        std::vector<int> order;              // program order of one timestep with the exchange between its phases
+        bool seen1 = false;
+        for (int u = 0; u < xu; ++u) {
+          if (units[(size_t)u].mop >= 0) micro_access(acc_c[(size_t)u], mops[(size_t)units[(size_t)u].mop], false); else acc_c[(size_t)u] = units[(size_t)u].acc;
+          if (units[(size_t)u].mop >= 0 && mops[(size_t)units[(size_t)u].mop].kind == ssn::M_STEP_END) continue;
+          if (units[(size_t)u].phase == 1 && !seen1) { seen1 = true; order.push_back(xu); }
+          order.push_back(u);
+        }
+        acc_c[(size_t)xu] = units[(size_t)xu].acc;
+        if (seen1) {
+          std::vector<Inst> all;
+          std::vector<std::vector<int>> chains_c;
+          int nr = 0;
+          const size_t per = order.size();
+          for (int st = 0; st < C; ++st)
+            for (size_t q = 0; q < per; ++q) {
+              const size_t lo = st > 0 ? (size_t)(st - 1) * per : 0;
+              const int r = place(all, lo, order[q], acc_c, 0, chains_c);
+              all.back().sub = st;
+              nr = std::max(nr, r + 1);
+            }
+          if (!(flags & 16777216))
+            balance_rounds(all, nr, per, [&](int a, int b) { return hazard(acc_c[(size_t)a], acc_c[(size_t)b]); },
+                           [&](int u, double* us, double* lat, int* blocks) {
+                             if (u == xu) { *us = 0.0; *lat = 0.0; *blocks = 0; return; }
+                             unit_cost(units[(size_t)u].mop, units[(size_t)u].item, us, lat, blocks);
+                           });
+          if (getenv("SSN_DEBUG_PLAN")) print_critical_chain(all, acc_c);
+          std::vector<Launch> seq;
+          emit(all, nr, seq, chains_c);
+          cycle_segs.emplace_back();
+          for (const Launch& l : seq) {
+            if (l.phase == -2) { cycle_segs.emplace_back(); continue; }
+            cycle_segs.back().push_back(l);
+          }
+          if ((int)cycle_segs.size() == C + 1) {
+            cycle_steps = C;
+            launches_per_step = ((int)(seq.size() - (size_t)C) + C - 1) / C;       // (average over the cycle)
+            if (getenv("SSN_DEBUG_PLAN")) {
+              fprintf(stderr, "[ssn] sharded plan pipelined over the exchange: %d timesteps in %d rounds, %zu launches, segments:", C, nr, seq.size() - (size_t)C);
+              for (auto& sg : cycle_segs) fprintf(stderr, " %zu", sg.size());
+              fprintf(stderr, "\n");
+            }
+          } else {
+            cycle_segs.clear();
+          }
+        }
+        units.pop_back();
+        unit_arg.pop_back();
+      }
     }
 
     T* d_arena = nullptr; ssn::GlueBlock* d_map = nullptr;
@@ -2770,6 +2938,12 @@ struct Sim final : ssn_sim {
         break;
       case IT_NEURONS:
         acc_sig(a, it.src - sig, it.n, false); acc_sig(a, it.dst - sig, it.n, true); acc_ptr(a, it.V, true); acc_ptr(a, it.R, true);
+        acc_ptr(a, it.list, true); acc_ptr(a, it.count, true);
+        break;
+      case IT_MATVEC_NEURONS:     // src: the current vector J (read unless the product sets), aux0: the product's input
+        acc_sig(a, it.aux0 - sig, it.cols, false); acc_ptr(a, it.Wm, false);
+        if (!it.set) acc_sig(a, it.src - sig, it.n, false);
+        acc_sig(a, it.dst - sig, it.n, true); acc_ptr(a, it.V, true); acc_ptr(a, it.R, true);
         acc_ptr(a, it.list, true); acc_ptr(a, it.count, true);
         break;
       case IT_PES:
@@ -3032,7 +3206,7 @@ struct Sim final : ssn_sim {
       case IT_SPMV: {
         ssn::SpmvBatch<T> b{};
         for (int q = 0; q < it.batch; ++q)
-          b.a[q] = ssn::SpmvArgs<T>{g[q].Wm, g[q].ld, g[q].src, g[q].cols, g[q].rows, g[q].dst, g[q].ld, g[q].n, g[q].list, g[q].count, g[q].seg};
+          b.a[q] = ssn::SpmvArgs<T>{g[q].Wm, g[q].ld, g[q].src, g[q].cols, g[q].rows, g[q].dst, g[q].ld, g[q].n, g[q].list, g[q].count, g[q].seg, g[q].seg_len};
         return ssn::launch_spmv_partial<T>(stream, b, it.batch);
       }
       case IT_NEURONS: {
@@ -3081,6 +3255,21 @@ struct Sim final : ssn_sim {
           e = launch_item(it, nullptr, nullptr);
         if (e != hipSuccess) return e;
       }
+    }
+    return hipSuccess;
+  }
+
+  void drop_cycle_graphs() {
+    for (auto e : cycle_exec) if (e) hipGraphExecDestroy(e);
+    for (auto g : cycle_graph) if (g) hipGraphDestroy(g);
+    cycle_exec.clear(); cycle_graph.clear();
+  }
+  // segment k of the pipelined sharded cycle (k = 0 .. cycle_steps); the clock advances behind the last one
+  hipError_t launch_segment(int k) {
+    for (const Launch& l : cycle_segs[(size_t)k]) { hipError_t e = launch_one(l); if (e != hipSuccess) return e; }
+    if (k == cycle_steps) {
+      hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, stream, d_ctx, (long long)cycle_steps);
+      return hipGetLastError();
     }
     return hipSuccess;
   }
@@ -3137,6 +3326,22 @@ struct Sim final : ssn_sim {
   int run_phase(int phase) override {
     HIPCHK(hipSetDevice(device));
     if (!phased) return fail(SSN_EINVAL, "ssn_run_phase: the model has no exchange ranges (use ssn_run_steps)");
+    if (phase == 3) {            // the next segment of a pipelined cycle (eager launches; the caller exchanges between two segments)
+      if (!cycle_steps || !round_mode) return fail(SSN_EINVAL, "ssn_run_phase(3): this model has no pipelined cycle plan (ssn_cycle_steps() == 0)");
+      if (next_seg == 0 && next_phase != 0) return fail(SSN_EINVAL, "ssn_run_phase(3): a cycle starts at a timestep boundary (phase %d is due)", next_phase);
+      HIPCHK(launch_segment(next_seg));
+      HIPCHK(hipStreamSynchronize(stream));
+      if (++next_seg > cycle_steps) {
+        next_seg = 0;
+        steps_done += cycle_steps;
+        ssn::StepCtx ctx;
+        HIPCHK(hipMemcpy(&ctx, d_ctx, sizeof ctx, hipMemcpyDeviceToHost));
+        if (ctx.step != steps_done) return fail(SSN_EHIP, "device step counter %lld != host %lld", (long long)ctx.step, (long long)steps_done);
+        if (ctx.probe_overflow) return fail(SSN_EINVAL, "probe storage overflow: call ssn_reserve_probes before stepping");
+      }
+      return SSN_OK;
+    }
+    if (next_seg != 0) return fail(SSN_EINVAL, "ssn_run_phase(%d): a pipelined cycle is under way (segment %d of %d is due)", phase, next_seg, cycle_steps + 1);
     if (phase < 0 || phase > 2) return fail(SSN_EINVAL, "ssn_run_phase(%d): 0, 1 or 2 (= 1 followed by the next timestep's 0)", phase);
     if ((phase == 2 ? 1 : phase) != next_phase) return fail(SSN_EINVAL, "ssn_run_phase(%d): phase %d is due", phase, next_phase);
     HIPCHK(hipGraphLaunch(phase_exec[phase], stream));
@@ -3153,6 +3358,8 @@ struct Sim final : ssn_sim {
     }
     return SSN_OK;
   }
+
+  int64_t cycle_len() override { return round_mode ? cycle_steps : 0; }
 
   int64_t exchange_size() override {
     int64_t n = 0;
@@ -3203,6 +3410,22 @@ struct Sim final : ssn_sim {
       HIPCHK(e2);
       HIPCHK(hipGraphInstantiate(&async_exec[h], async_graph[h], nullptr, nullptr, 0));
     }
+    drop_cycle_graphs();
+    if (cycle_steps && round_mode) {          // segment k: [unpack the sums of timestep k - 1] -> rounds -> [pack the partial sums of timestep k]
+      cycle_graph.assign((size_t)cycle_steps + 1, nullptr);
+      cycle_exec.assign((size_t)cycle_steps + 1, nullptr);
+      for (int k = 0; k <= cycle_steps; ++k) {
+        HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e = hipSuccess;
+        if (k >= 1 && buf) e = exchange_copy_async(buf, false, stream);
+        if (e == hipSuccess) e = launch_segment(k);
+        if (k < cycle_steps && buf && e == hipSuccess) e = exchange_copy_async(buf, true, stream);
+        hipError_t e2 = hipStreamEndCapture(stream, &cycle_graph[(size_t)k]);
+        HIPCHK(e);
+        HIPCHK(e2);
+        HIPCHK(hipGraphInstantiate(&cycle_exec[(size_t)k], cycle_graph[(size_t)k], nullptr, nullptr, 0));
+      }
+    }
     async_buf = buf;
     async_captured = true;
     return SSN_OK;
@@ -3217,8 +3440,14 @@ struct Sim final : ssn_sim {
       if (!async_captured || buf != async_buf) CHK(capture_async(buf));
       return SSN_OK;
     }
-    if (phase < 0 || phase > 2) return fail(SSN_EINVAL, "ssn_phase_async(%d): 0, 1 or 2 (= 1 followed by the next timestep's 0)", phase);
-    if ((phase == 2 ? 1 : phase) != next_phase) return fail(SSN_EINVAL, "ssn_phase_async(%d): phase %d is due", phase, next_phase);
+    if (phase == 3) {
+      if (!cycle_steps || !round_mode) return fail(SSN_EINVAL, "ssn_phase_async(3): this model has no pipelined cycle plan (ssn_cycle_steps() == 0)");
+      if (next_seg == 0 && next_phase != 0) return fail(SSN_EINVAL, "ssn_phase_async(3): a cycle starts at a timestep boundary (phase %d is due)", next_phase);
+    } else {
+      if (next_seg != 0) return fail(SSN_EINVAL, "ssn_phase_async(%d): a pipelined cycle is under way (segment %d of %d is due)", phase, next_seg, cycle_steps + 1);
+      if (phase < 0 || phase > 2) return fail(SSN_EINVAL, "ssn_phase_async(%d): 0, 1, 2 (= 1 followed by the next timestep's 0) or 3 (next segment of a pipelined cycle)", phase);
+      if ((phase == 2 ? 1 : phase) != next_phase) return fail(SSN_EINVAL, "ssn_phase_async(%d): phase %d is due", phase, next_phase);
+    }
     if (!async_active) {
       HIPCHK(hipStreamSynchronize(stream));          // uploads / table updates issued on the simulator's own stream come first
       if (!async_captured || buf != async_buf) CHK(capture_async(buf));
@@ -3226,8 +3455,13 @@ struct Sim final : ssn_sim {
     } else if (buf != async_buf) {
       return fail(SSN_EINVAL, "ssn_phase_async: the exchange buffer changed inside a run (call ssn_phase_sync first)");
     }
-    HIPCHK(hipGraphLaunch(async_exec[phase], ext ? ext : stream));
     async_stream = ext ? ext : stream;
+    if (phase == 3) {
+      HIPCHK(hipGraphLaunch(cycle_exec[(size_t)next_seg], ext ? ext : stream));
+      if (++next_seg > cycle_steps) { next_seg = 0; steps_done += cycle_steps; }
+      return SSN_OK;
+    }
+    HIPCHK(hipGraphLaunch(async_exec[phase], ext ? ext : stream));
     next_phase = phase == 0 ? 1 : (phase == 1 ? 0 : 1);
     if (phase >= 1) steps_done += 1;
     return SSN_OK;
@@ -3238,6 +3472,7 @@ struct Sim final : ssn_sim {
     if (!phased) return fail(SSN_EINVAL, "ssn_phase_sync: the model has no exchange ranges");
     HIPCHK(hipStreamSynchronize(ext ? ext : stream));
     async_active = false;
+    if (next_seg != 0) { const int due = next_seg; next_seg = 0; return fail(SSN_EINVAL, "ssn_phase_sync inside a pipelined cycle (segment %d of %d was due): the simulator's state is part-way through %d timesteps - reset it", due, cycle_steps + 1, cycle_steps); }
     ssn::StepCtx ctx;
     HIPCHK(hipMemcpy(&ctx, d_ctx, sizeof ctx, hipMemcpyDeviceToHost));
     if (ctx.step != steps_done) return fail(SSN_EHIP, "device step counter %lld != host %lld", (long long)ctx.step, (long long)steps_done);
@@ -3432,6 +3667,7 @@ struct Sim final : ssn_sim {
     CHK(init_bsig());
     steps_done = 0;
     next_phase = 0;
+    next_seg = 0;
     reserve_first = reserve_n = 0;
     for (auto& s : pslots) { s.base_slot = 0; s.capacity = 0; }
     if (!pslots.empty()) HIPCHK(hipMemcpy(d_pslots, pslots.data(), pslots.size() * sizeof(ssn::ProbeSlot), hipMemcpyHostToDevice));
@@ -3635,7 +3871,7 @@ struct Sim final : ssn_sim {
   int kernel_times(ssn_kernel_time* out, int capacity) override {
     static const char* names[N_ITEM_TYPES] = {"k_program", "k_ensarray", "k_matvec", "k_neurons", "k_pes", "k_voja", "k_matvec_ordered",
                                               "k_ens_finish", "k_spmv_partial", "k_dft", "k_vecops", "k_grid_lhs", "k_gemm_nt_mfma_f32",
-                                              "k_argmax_partial", "k_round", ""};
+                                              "k_argmax_partial", "k_round", "", "", ""};
     int n = 0;
     for (int t = 0; t < N_ITEM_TYPES; ++t) {
       if (!type_launches[t]) continue;
@@ -3731,6 +3967,7 @@ int ssn_get_counters(ssn_sim* sim, ssn_counters* out) {
 }
 int ssn_run_phase(ssn_sim* sim, int32_t phase) { return sim ? sim->run_phase(phase) : fail(SSN_EINVAL, "null simulator"); }
 int64_t ssn_exchange_size(ssn_sim* sim) { return sim ? sim->exchange_size() : -1; }
+int64_t ssn_cycle_steps(ssn_sim* sim) { return sim ? sim->cycle_len() : -1; }
 int ssn_exchange_pack(ssn_sim* sim, void* dst_dev) {
   if (!sim || !dst_dev) return fail(SSN_EINVAL, "null argument");
   return sim->exchange_copy(dst_dev, true);
@@ -3753,6 +3990,6 @@ int ssn_device_count(void) {
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 const char* ssn_last_error(void) { return g_err.c_str(); }
-const char* ssn_version(void) { return "libssn_hip 0.8 (gfx950, ABI 7)"; }
+const char* ssn_version(void) { return "libssn_hip 0.9 (gfx950, ABI 8)"; }
 
 }  // extern "C"

@@ -1381,6 +1381,105 @@ __global__ __launch_bounds__(256) void k_matvec(MatvecBatch<T> batch) {
   matvec_body<T, XLDS, RW, CUV>(batch.a[blockIdx.y], (int)blockIdx.x, ssn_mv_smem);
 }
 
+// Encoder product of a dense population with its neuron update in the epilogue (a body of the round grid; round 4; with
+// nr.V == nullptr the plain product of the round grid's 16-rows-per-workgroup variant - one copy of the code for both).  The
+// product is matvec_body<T, true, 4>'s - the same loads, the same accumulation order per row - and instead of adding its 16 sums to
+// the current vector J it steps the 16 neurons of those rows: lanes 0 - 3 of each wave take one neuron each (J = J[i] + sum, or
+// the sum alone for a product that sets), write state and output, and the workgroup leaves the spikes as segment bx of a spike
+// list in 16-neuron segments (ascending index; spmv_body, seg_len = 16).  One dependent round of a population hop - product ->
+// neurons -> sparse decode -> reduction - less; the current vector is never written.
+template <typename T>
+__device__ __forceinline__ void matvec_neurons_body(const MatvecNeuronsArgs<T>& a, const int bx, unsigned char* ssn_mv_dyn) {
+  const MatvecArgs<T>& ma = a.mv;
+  const T* __restrict__ Wm = ma.Wm;
+  const T* __restrict__ sig_src = ma.src;
+  const int rows = ma.rows, cols = ma.cols, ld = ma.ld, set = ma.set;
+  if (bx * 16 >= rows) return;
+  using vec = typename VecT<T>::type;
+  constexpr int W = VecT<T>::W;
+  constexpr int RW = 4;
+  T* xs = reinterpret_cast<T*>(ssn_mv_dyn);
+  int* wmask = reinterpret_cast<int*>(ssn_mv_dyn + (((size_t)cols * sizeof(T) + 15) / 16) * 16);      // [4]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = (bx * 4 + wave) * RW;
+  const bool active = r0 < rows;
+  const T* wr[RW];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) wr[q] = Wm + (size_t)min(r0 + q, rows - 1) * ld;
+  T s[RW];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) s[q] = T(0);
+  const int n_vec = cols / W;
+  T w0[RW][W];
+  const bool have0 = active && lane < n_vec;
+  if (have0) {
+#pragma unroll
+    for (int q = 0; q < RW; ++q) *(vec*)w0[q] = *(const vec*)(wr[q] + (size_t)lane * W);
+  }
+  int nz = 0;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const T v = sig_src[c];
+    xs[c] = v;
+    nz |= (v != T(0));
+  }
+  nz = __syncthreads_or(nz);
+  if (nz && active) {                            // (an all-zero input adds nothing: the matrix is not read)
+    if (have0) {
+      T xv[W];
+      *(vec*)xv = *(const vec*)(xs + (size_t)lane * W);
+#pragma unroll
+      for (int q = 0; q < RW; ++q)
+#pragma unroll
+        for (int j = 0; j < W; ++j) s[q] += w0[q][j] * xv[j];
+    }
+    for (int v = lane + 64; v < n_vec; v += 64) {
+      T w[RW][W], xv[W];
+#pragma unroll
+      for (int q = 0; q < RW; ++q) *(vec*)w[q] = *(const vec*)(wr[q] + (size_t)v * W);
+      *(vec*)xv = *(const vec*)(xs + (size_t)v * W);
+#pragma unroll
+      for (int q = 0; q < RW; ++q)
+#pragma unroll
+        for (int j = 0; j < W; ++j) s[q] += w[q][j] * xv[j];
+    }
+    for (int c = n_vec * W + lane; c < cols; c += 64)
+#pragma unroll
+      for (int q = 0; q < RW; ++q) s[q] += wr[q][c] * xs[c];
+  }
+  T t[RW];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) t[q] = __shfl(wave_sum(s[q]), 0, 64);       // (lane 0 holds the sum: to every lane)
+  const NeuronsArgs<T>& na = a.nr;
+  if (!na.V) {                                   // a plain product (no population behind it): y (+)= W x, as matvec_body<T, true, 4>
+    if (active && lane < RW && r0 + lane < rows && (set || nz)) {
+      const T sum = lane == 0 ? t[0] : (lane == 1 ? t[1] : (lane == 2 ? t[2] : t[3]));
+      T* const d = ma.dst + r0 + lane;
+      if (set) *d = sum; else *d += sum;
+    }
+    return;
+  }
+  // the neurons of this wave's rows: lane q < 4 takes row r0 + q
+  const int i = r0 + lane;
+  T act = T(0);
+  if (active && lane < RW && i < rows) {
+    const T sum = lane == 0 ? t[0] : (lane == 1 ? t[1] : (lane == 2 ? t[2] : t[3]));
+    const T J = set ? sum : na.J[i] + sum;
+    T v = na.V[i], r = na.R[i];
+    act = neuron_step(na.np, J, v, r);
+    na.V[i] = v; na.R[i] = r;
+    na.out[i] = na.amp * act;
+  }
+  if (na.seg_list) {
+    const unsigned long long mask = __ballot(act != T(0));      // (bits 0 - 3 at most)
+    if (lane == 0) wmask[wave] = (int)(mask & 15ull);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += __popc(wmask[w]);
+    if (act != T(0)) na.seg_list[bx * 16 + base + __popc((int)(mask & ((1ull << lane) - 1ull)))] = i;
+    if (threadIdx.x == 0) na.seg_cnt[bx] = __popc(wmask[0]) + __popc(wmask[1]) + __popc(wmask[2]) + __popc(wmask[3]);
+  }
+}
+
 template <typename T>
 hipError_t launch_matvec(hipStream_t s, const MatvecBatch<T>& b, int count) {
   int rows = 0, cols = 0;
@@ -1448,25 +1547,52 @@ __device__ __forceinline__ void spmv_body(const SpmvArgs<T>& sa, const int bx, c
   const int c = by;
   const int r = bx * 256 + tid;
   if (seg > 0) {
-    // segmented spike list from k_neurons (256 neurons per segment): chunk c takes segments [c*seg, (c+1)*seg)
+    // Segmented spike list: chunk c takes the 256-neuron spans [c * seg, (c + 1) * seg).  A span's spikes (ascending neuron index)
+    // are copied to a compact LDS list - one trip for the count(s), one for the entries - and every thread walks that list with
+    // eight row reads in flight.
+    //   seg_len 256 (k_neurons: one segment per span): thread t copies entry t of the segment;
+    //   seg_len 16 (matvec_neurons_body: 16 small segments per span): thread t looks at slot t % 16 of small segment t / 16;
+    //     the 16 counts sit in lanes 0 - 15 of every wave and are scanned with shuffles (as uniform loads they would take 16
+    //     scalar registers of a kernel - k_round - that has none to spare).
     T acc = T(0);
-    const int n_seg = (n + 255) / 256;
-    if (r < rows)
-      for (int sgm = c * seg; sgm < min(n_seg, (c + 1) * seg); ++sgm) {
-        const int* sl = glist + sgm * 256;
-        const int e = gcount[sgm];
+    int* llist = counts;                                // [256] (the scan counters of the list-less path: unused here)
+    const int n_small = (n + 15) / 16;
+    const int n_span = (n + 255) / 256;
+    for (int span = c * seg; span < min(n_span, (c + 1) * seg); ++span) {
+      int total, src = -1, at = 0;
+      if (sa.seg_len == 16) {
+        const int q = tid >> 4, pos = tid & 15, ln = tid & 63;
+        int e = 0;
+        if (ln < 16) { const int sgm = span * 16 + ln; e = sgm < n_small ? gcount[sgm] : 0; }
+        int inc = e;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { const int v = __shfl_up(inc, off, 64); if (ln >= off) inc += v; }
+        total = __shfl(inc, 15, 64);
+        const int mine = __shfl(e, q, 64);
+        at = __shfl(inc, q, 64) - mine + pos;
+        if (pos < mine) src = (span * 16 + q) * 16 + pos;
+      } else {
+        total = gcount[span];
+        at = tid;
+        if (tid < total) src = span * 256 + tid;
+      }
+      __syncthreads();                                     // (the list of the span before is no longer read)
+      if (src >= 0) llist[at] = glist[src];
+      __syncthreads();
+      if (r < rows) {
         int i = 0;
-        for (; i + 8 <= e; i += 8) {           // eight independent row reads in flight per lane
+        for (; i + 8 <= total; i += 8) {
           int j[8]; T w[8], sv[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) j[q] = sl[i + q];
+          for (int u = 0; u < 8; ++u) j[u] = llist[i + u];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) { w[q] = Wt[(size_t)j[q] * ldt + r]; sv[q] = spikes[j[q]]; }
+          for (int u = 0; u < 8; ++u) { w[u] = Wt[(size_t)j[u] * ldt + r]; sv[u] = spikes[j[u]]; }
 #pragma unroll
-          for (int q = 0; q < 8; ++q) acc += sv[q] * w[q];
+          for (int u = 0; u < 8; ++u) acc += sv[u] * w[u];
         }
-        for (; i < e; ++i) { const int j = sl[i]; acc += spikes[j] * Wt[(size_t)j * ldt + r]; }
+        for (; i < total; ++i) { const int j = llist[i]; acc += spikes[j] * Wt[(size_t)j * ldt + r]; }
       }
+    }
     if (r < rows) partial[(size_t)c * rows_pad + r] = acc;
     return;
   }

@@ -172,9 +172,13 @@ template <typename T> struct MatvecArgs { const T* Wm; const T* src; T* dst; int
 template <typename T> struct MatvecBatch { MatvecArgs<T> a[MAX_BATCH]; };
 template <typename T> struct NeuronsArgs { NeuronParams<T> np; const T* J; T* out; T* V; T* R; int n; T amp; int* seg_list; int* seg_cnt; };
 template <typename T> struct NeuronsBatch { NeuronsArgs<T> a[MAX_BATCH]; };
+// A dense population's encoder product with its neuron update in the epilogue (matvec_neurons_body): the workgroup that owns 16
+// rows of W steps those 16 neurons - J = (set ? 0 : J[i]) + W[i] . x never goes back to memory - and leaves their spikes as
+// segment bx of a spike list in 16-neuron segments (SpmvArgs::seg_len = 16).
+template <typename T> struct MatvecNeuronsArgs { MatvecArgs<T> mv; NeuronsArgs<T> nr; };
 struct DftBatch { DftArgs a[MAX_BATCH]; };
 template <typename T> struct SpmvArgs { const T* Wt; int ldt; const T* spikes; int n, rows; T* partial; int rows_pad, chunks; const int* list; const int* count;
-                                       int seg; };
+                                       int seg; int seg_len; };      // seg_len: neurons per list segment (256: k_neurons; 16: matvec_neurons_body)
 template <typename T> struct SpmvBatch { SpmvArgs<T> a[MAX_BATCH]; };
 constexpr int MAX_ENS_BATCH = 2;
 template <typename T> struct EnsBatch { EnsArgs<T> a[MAX_ENS_BATCH]; };
@@ -256,6 +260,7 @@ enum RoundKind {
   RK_ENS_3_4_S, RK_ENS_3_5_S, RK_ENS_1_1_D,     // k_ensarray<din, dout, spike-sparse | dense decoders>
   RK_ENS_SMALL,                                 // arrays of many small 1-D ensembles: a wave per ensemble, 16 per block (ens_small_body)
   RK_GRID_LHS, RK_GRID_DOT,                     // clean-up over a sample grid from its factor tables (round 4): left operand; similarities
+  RK_MATVEC_NEURONS,                            // encoder product + neuron update of a dense population (MatvecNeuronsArgs)
   RK_SOLO                                       // a serial chain of single-workgroup units, one block: args -> {n, code_0, sub_0, ...} in RoundArgs::chain;
                                                 // code >= 0: micro-operator index, code < 0: DftArgs at RoundArgs::arena + 16 * (-code - 1)
 };

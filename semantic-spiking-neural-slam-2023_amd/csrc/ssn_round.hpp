@@ -305,7 +305,8 @@ __device__ __forceinline__ void round_block(const RoundArgs<T>& ra, int vb, unsi
     case RK_GATE: gate_body<T>(*(const MicroOp<T>*)e.args, ra.sig, smem); break;
     case RK_ARGMAX: argmax_gather_body<T>(*(const MicroOp<T>*)e.args, ra.sig, smem); break;
     case RK_MATVEC_R1: matvec_body<T, true, 1, 4>(*(const MatvecArgs<T>*)e.args, bx, smem); break;
-    case RK_MATVEC_R4: matvec_body<T, true, 4>(*(const MatvecArgs<T>*)e.args, bx, smem); break;
+    // (one copy of the 16-rows-per-workgroup product for both: a plain product's descriptor has nr.V == nullptr)
+    case RK_MATVEC_R4: case RK_MATVEC_NEURONS: matvec_neurons_body<T>(*(const MatvecNeuronsArgs<T>*)e.args, bx, smem); break;
     case RK_SPMV: spmv_body<T>(*(const SpmvArgs<T>*)e.args, bx, by, smem); break;
     case RK_NEURONS: neurons_body<T>(*(const NeuronsArgs<T>*)e.args, bx, smem); break;
     case RK_DFT:

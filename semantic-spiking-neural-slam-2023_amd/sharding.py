@@ -423,13 +423,14 @@ class ShardedSLAM:
     ``sim_factory(model)`` is injectable: the tests run the orchestration on the NumPy oracle."""
 
     def __init__(self, sm, rank, world, dt=0.001, dtype="f32", device=0, n_eval_points=None, sim_factory=None, dist=None,
-                 replicate=None, host_loop=False, flags=0):
+                 replicate=None, host_loop=False, flags=0, cycles=True):
         """``host_loop=True`` keeps round 2's loop (one blocking ssn_run_phase and one blocking exchange per timestep) for A/B
-        measurements; the default enqueues the whole run (``run_steps``)."""
+        measurements; the default enqueues the whole run (``run_steps``).  ``cycles=False`` steps one timestep at a time
+        (phases 0 / 2 / 1) instead of through the plan pipelined over the exchange (``ssn_cycle_steps``)."""
         if dist is None:
             import torch.distributed as dist
         self.dist, self.rank, self.world, self.dt, self.dtype = dist, rank, world, dt, dtype
-        self.sm, self.host_loop = sm, bool(host_loop)
+        self.sm, self.host_loop, self.cycles = sm, bool(host_loop), bool(cycles)
         if replicate is None:
             replicate = [sm.slam.ovc_ens]
         self.model = build(sm.model, dt=dt, n_eval_points=n_eval_points, neuron_shard=(rank, world), replicate=replicate)
@@ -493,6 +494,12 @@ class ShardedSLAM:
         if self.world == 1:
             return True
         return self.dist.is_initialized() and self.dist.get_backend() == "nccl"
+
+    def _cycle_steps(self):
+        """Timesteps per cycle of the plan pipelined over the exchange (0: not offered, or switched off with ``cycles=False``)."""
+        if not self.cycles or not hasattr(self.sim, "cycle_steps"):
+            return 0
+        return int(self.sim.cycle_steps())
 
     def _exchange_buffer(self):
         """Device buffer of the per-timestep exchange (None for a single rank: its sums are complete)."""
@@ -565,11 +572,22 @@ class ShardedSLAM:
                 # set_table synchronise the simulator's own stream only and must not race with graphs still queued here.
                 enqueue_error = None
                 try:
-                    self.sim.phase_async(0, buf, stream)
-                    for i in range(n):
-                        if self.world > 1:
-                            self.dist.all_reduce(self._buf)
-                        self.sim.phase_async(2 if i + 1 < n else 1, buf, stream)
+                    # whole cycles of the plan pipelined over the exchange first (segment, all-reduce, segment, ...), then
+                    # what is left one timestep at a time (0, x, 2, x, ..., 1)
+                    cyc = self._cycle_steps()
+                    done = 0
+                    while cyc and n - done >= cyc:
+                        for k in range(cyc + 1):
+                            self.sim.phase_async(3, buf, stream)
+                            if k < cyc and self.world > 1:
+                                self.dist.all_reduce(self._buf)
+                        done += cyc
+                    if done < n:
+                        self.sim.phase_async(0, buf, stream)
+                        for i in range(done, n):
+                            if self.world > 1:
+                                self.dist.all_reduce(self._buf)
+                            self.sim.phase_async(2 if i + 1 < n else 1, buf, stream)
                 except BaseException as e:           # noqa: BLE001 - re-raised below, after the stream has been drained
                     enqueue_error = e
                 try:
@@ -582,11 +600,20 @@ class ShardedSLAM:
             torch.cuda.current_stream().wait_stream(self._stream)
         else:
             self._agree(err)
-            self.sim.run_phase(0)
-            for i in range(n):
-                self._exchange()
-                # the updates of this timestep and the next one up to its exchange share a launch (one host round trip)
-                self.sim.run_phase(2 if i + 1 < n else 1)
+            cyc = self._cycle_steps()
+            done = 0
+            while cyc and n - done >= cyc:
+                for k in range(cyc + 1):
+                    self.sim.run_phase(3)
+                    if k < cyc:
+                        self._exchange()
+                done += cyc
+            if done < n:
+                self.sim.run_phase(0)
+                for i in range(done, n):
+                    self._exchange()
+                    # the updates of this timestep and the next one up to its exchange share a launch (one host round trip)
+                    self.sim.run_phase(2 if i + 1 < n else 1)
         self.n_steps += n
 
     # -- results ----------------------------------------------------------------------------------------------------

@@ -665,8 +665,11 @@ class Simulator:
     def run_phase(self, phase):
         """0: up to the exchange; 1: the updates; 2: the updates followed by the next timestep up to its exchange.
         (The graphs of the stream-ordered path are built through ``phase_async(-1, buffer, None)``.)"""
+        if phase == 3:
+            self._cycle_segment(lambda: self._lib.ssn_run_phase(self._h, 3))
+            return
         if phase not in (0, 1, 2):
-            raise fe.SimulationError(f"run_phase({phase}): 0, 1 or 2")
+            raise fe.SimulationError(f"run_phase({phase}): 0, 1, 2 or 3")
         if phase in (0, 2) and self._prepared_until < self.n_steps + (1 if phase == 0 else 2):
             raise fe.SimulationError("neuron-sharded model: call prepare(n_steps) before stepping")
         self._check(self._lib.ssn_run_phase(self._h, int(phase)))
@@ -674,11 +677,32 @@ class Simulator:
             self.n_steps += 1
             self._uncollected = True
 
+    def cycle_steps(self):
+        """Timesteps of the plan pipelined over the exchange (0: the model has none): ``cycle_steps() + 1`` calls of
+        ``run_phase(3)`` / ``phase_async(3, ...)`` with the caller's exchange between consecutive ones advance that many."""
+        return int(self._lib.ssn_cycle_steps(self._h))
+
+    def _cycle_segment(self, call):
+        c = self.cycle_steps()
+        seg = getattr(self, "_cycle_seg", 0)
+        if seg == 0 and self._prepared_until < self.n_steps + c:
+            raise fe.SimulationError("neuron-sharded model: call prepare(n_steps) before stepping")
+        self._check(call())
+        seg += 1
+        if seg > c:
+            seg = 0
+            self.n_steps += c
+            self._uncollected = True
+        self._cycle_seg = seg
+
     def phase_async(self, phase, exchange_buf_ptr, stream_ptr):
         """Stream-ordered variant of ``run_phase``: enqueues [unpack] -> the phase -> [pack] as one graph launch on the
         caller's HIP stream and returns; ``phase_sync`` waits and checks.  No host synchronisation per timestep."""
         if phase == -1:                  # only build the graphs for this exchange buffer (no launch, nothing to prepare)
             self._check(self._lib.ssn_phase_async(self._h, -1, C.c_void_p(exchange_buf_ptr or None), C.c_void_p(None)))
+            return
+        if phase == 3:
+            self._cycle_segment(lambda: self._lib.ssn_phase_async(self._h, 3, C.c_void_p(exchange_buf_ptr or None), C.c_void_p(stream_ptr or None)))
             return
         if phase in (0, 2) and self._prepared_until < self.n_steps + (1 if phase == 0 else 2):
             raise fe.SimulationError("neuron-sharded model: call prepare(n_steps) before stepping")
@@ -720,6 +744,7 @@ class Simulator:
     def reset(self, seed=None):
         self._check(self._lib.ssn_reset(self._h))
         self.n_steps = 0
+        self._cycle_seg = 0
         self._prepared_until = 0
         for k in self._chunks:
             self._chunks[k] = []

@@ -1431,19 +1431,29 @@ def test_sharded_slam_stream_ordered_run_equals_the_host_loop(Simulator):
     ref = OracleSimulator(model)
     ref.run_steps(steps)
     outs = []
-    for host_loop in (False, True):
+    for host_loop, cycles in ((False, True), (True, True), (False, False), (True, False)):
         sm = _small_slam(weights_every=None)
-        r = ShardedSLAM(sm, 0, 1, dtype="f64", host_loop=host_loop)
+        r = ShardedSLAM(sm, 0, 1, dtype="f64", host_loop=host_loop, cycles=cycles)
         assert r._stream_ordered() == (not host_loop)
+        # the plan pipelined over the exchange (ssn_cycle_steps timesteps as segments around the exchanges, phase 3) serves whole
+        # cycles, the per-timestep phases 0 / 2 / 1 the rest: 70 = 4 cycles of 16 + 6, 50 = 3 cycles + 2
+        assert r._cycle_steps() == (16 if cycles else 0)
         r.prepare(steps)
         r.run_steps(70)
-        r.run_steps(steps - 70)                    # two runs: the sequence 0, 2, ..., 1 restarts cleanly
+        r.run_steps(steps - 70)                    # two runs: the sequence restarts cleanly
         outs.append((r.probe_data(), r.learned_decoders(sm.slam.assomemory.conn_out)))
         with pytest.raises(nengo.SimulationError, match="prepare"):
             r.run_steps(5)                          # past the prepared window: refused before anything is enqueued
+        if cycles and host_loop:                    # inside a cycle the per-timestep phases are refused
+            r.sim.reset()
+            r.prepare(40)
+            r.sim.run_phase(3)
+            with pytest.raises(nengo.SimulationError, match="cycle is under way"):
+                r.sim.run_phase(0)
         r.close()
-    np.testing.assert_array_equal(outs[0][0], outs[1][0])
-    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0][0], o[0])
+        np.testing.assert_array_equal(outs[0][1], o[1])
     np.testing.assert_allclose(outs[0][0], ref.probe_data(0), atol=1e-9, rtol=0)
 
 
