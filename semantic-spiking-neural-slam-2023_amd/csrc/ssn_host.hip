@@ -2215,7 +2215,9 @@ struct Sim final : ssn_sim {
     //   * with the transforms as members (SSN_SOLO_DFT=1) the plan drops from 3.78 to 3.0 - 3.3 rounds per timestep and gets
     //     SLOWER - 110.8 us at a cap of 12 us, 114.8 at 16, 129 at 22, 139 at 26: a round now lasts as long as its longest
     //     chain (transform + members: 20 - 45 us) and the bandwidth-bound work does not fill the time under it;
-    //   * neuron-sharded plans (not pipelined over timesteps): no launch fewer, 157.8 vs 155.3 us - left off there.
+    //   * neuron-sharded plans: nothing for the per-timestep phases (157.8 vs 155.3 us, ten launches either way); with the
+    //     plan pipelined over the exchange 123.0 vs 125.6 us at world 1 (72 vs 76 launches per 16 timesteps) - on there too
+    //     (SSN_PHASED_SOLO=0: off for sharded plans only).
     // SSN_SOLO_CHAINS=0: off; SSN_SOLO_CAP_US: longest serial chain in estimated microseconds (default 16); SSN_SOLO_MAX_LEN:
     // longest glue operator a single workgroup takes (default 2048 elements).
     // LDS bytes of a transform as a round body
@@ -2228,7 +2230,7 @@ struct Sim final : ssn_sim {
       }
       return lds;
     };
-    const bool solo_on = (!phased || (getenv("SSN_PHASED_SOLO") && atoi(getenv("SSN_PHASED_SOLO")) == 1)) && !(flags & 134217728) && !(getenv("SSN_SOLO_CHAINS") && atoi(getenv("SSN_SOLO_CHAINS")) == 0);
+    const bool solo_on = !(phased && getenv("SSN_PHASED_SOLO") && atoi(getenv("SSN_PHASED_SOLO")) == 0) && !(flags & 134217728) && !(getenv("SSN_SOLO_CHAINS") && atoi(getenv("SSN_SOLO_CHAINS")) == 0);
     const double solo_cap = getenv("SSN_SOLO_CAP_US") ? atof(getenv("SSN_SOLO_CAP_US")) : 16.0;
     const bool solo_dft = getenv("SSN_SOLO_DFT") && atoi(getenv("SSN_SOLO_DFT")) == 1;      // transforms as chain members: measured slower (below)
     const long long solo_max_len = getenv("SSN_SOLO_MAX_LEN") ? atoll(getenv("SSN_SOLO_MAX_LEN")) : 2048;
@@ -2280,7 +2282,9 @@ struct Sim final : ssn_sim {
         const bool both = can && chainable(vv) && (long long)mops[(size_t)vv.mop].len == len;
         const int k = both ? conflict_kind(accs[(size_t)unit], accs[(size_t)placed[v].unit])
                            : (hazard(accs[(size_t)unit], accs[(size_t)placed[v].unit]) ? 2 : 0);
-        if (k == 2) { r_hard = std::max(r_hard, placed[v].round + 1); hard.push_back(v); }
+        // (the exchange of a sharded cycle plan is no kernel: it happens in front of its round's launch, so what waits for it may
+        //  run in that very round)
+        if (k == 2) { r_hard = std::max(r_hard, placed[v].round + ((vv.mop < 0 && vv.item < 0) ? 0 : 1)); hard.push_back(v); }
         else if (k == 1) { r_soft = std::max(r_soft, placed[v].round); soft.push_back(v); }
       }
       // serial chain: every hard predecessor in round r_hard - 1 is a single-workgroup unit of ONE chain (or one such unit alone)
@@ -2372,6 +2376,7 @@ struct Sim final : ssn_sim {
             }
           }
           Launch l; l.rl = (int)round_launches.size(); l.phase = phase;
+          rl.args.pad = l.rl;                    // (launch id: read by the diagnostic stamps of k_round, SSN_ROUND_STAMPS)
           round_launches.push_back(rl);
           out.push_back(l);
           rl.args.n = 0; rl.n_blocks = 0; rl.lds = 0;

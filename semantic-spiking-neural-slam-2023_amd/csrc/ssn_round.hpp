@@ -329,6 +329,22 @@ __device__ __forceinline__ void round_block(const RoundArgs<T>& ra, int vb, unsi
   }
 }
 
+#ifdef SSN_ROUND_STAMPS
+// diagnostic build only (make F32_EXTRA=-DSSN_ROUND_STAMPS, tools/round_stamps.py): every block of every k_round launch leaves
+// {launch id (RoundArgs::pad) << 32 | body kind << 24 | block index, s_memrealtime at its start, at its end} (100 MHz ticks)
+constexpr unsigned int ROUND_STAMP_CAP = 1u << 20;
+__device__ unsigned long long g_round_stamps[ROUND_STAMP_CAP][3];
+__device__ unsigned int g_round_stamp_n;
+inline long long read_round_stamps(unsigned long long* out, long long cap, int reset) {
+  unsigned int n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_round_stamp_n), sizeof n) != hipSuccess) return -1;
+  const long long m = std::min<long long>(std::min<long long>(n, ROUND_STAMP_CAP), cap);
+  if (out && m > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_stamps), (size_t)m * 24) != hipSuccess) return -1;
+  if (reset) { n = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_round_stamp_n), &n, sizeof n) != hipSuccess) return -1; }
+  return m;
+}
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_round(RoundArgs<T> ra) {
   extern __shared__ __align__(16) unsigned char ssn_round_smem[];
@@ -337,7 +353,27 @@ __global__ __launch_bounds__(256) void k_round(RoundArgs<T> ra) {
     const unsigned int m = gridDim.x - (unsigned int)ra.head;
     vb = ra.head + (int)(((unsigned long long)(unsigned int)(vb - ra.head) * ra.stride) % m);
   }
+#ifdef SSN_ROUND_STAMPS
+  unsigned long long st0, st1;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st0) :: "memory");
+#endif
   round_block<T>(ra, vb, ssn_round_smem);
+#ifdef SSN_ROUND_STAMPS
+  if constexpr (sizeof(T) == 4) {
+    __syncthreads();
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st1) :: "memory");
+    if (threadIdx.x == 0) {
+      int ei = 0;
+      for (int q = 1; q < ra.n; ++q) if (vb >= ra.e[q].first) ei = q;
+      const unsigned int i = atomicAdd(&g_round_stamp_n, 1u);
+      if (i < ROUND_STAMP_CAP) {
+        g_round_stamps[i][0] = ((unsigned long long)(unsigned int)ra.pad << 32) | ((unsigned long long)(ra.e[ei].kind & 255) << 24) | (unsigned long long)(blockIdx.x & 0xffffff);
+        g_round_stamps[i][1] = st0;
+        g_round_stamps[i][2] = st1;
+      }
+    }
+  }
+#endif
 }
 
 // (A persistent variant - all rounds of a step graph in one resident grid with grid barriers - was built, tested and
