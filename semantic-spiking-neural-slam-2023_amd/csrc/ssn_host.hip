@@ -2344,6 +2344,7 @@ struct Sim final : ssn_sim {
     };
     // Launch sequence of a set of instances grouped by round (instances of one round are mutually independent).
     const bool no_interleave = getenv("SSN_ROUND_INTERLEAVE") && atoi(getenv("SSN_ROUND_INTERLEAVE")) == 0;      // A/B knob
+    const bool head_prio = !(getenv("SSN_HEAD_PRIO") && atoi(getenv("SSN_HEAD_PRIO")) == 0);                       // A/B knob (ssn_round.hpp, k_round)
     std::vector<int> chain_tab;
     auto emit = [&](const std::vector<Inst>& insts, int n_rounds, std::vector<Launch>& out, const std::vector<std::vector<int>>& chains) {
       std::vector<std::vector<const Inst*>> by_round((size_t)n_rounds);
@@ -2360,13 +2361,14 @@ struct Sim final : ssn_sim {
           if (rl.args.n == 0) return;
           // interleaved dispatch of the big grids behind the latency-bound head (RoundArgs::stride)
           rl.args.head = 0; rl.args.stride = 0;
+          int head = 0;
+          for (int q = 0; q < rl.args.n; ++q) {
+            const int k = rl.args.e[q].kind;
+            if (k == ssn::RK_DFT || k == ssn::RK_SOLO || k == ssn::RK_GATE || k == ssn::RK_ARGMAX || k == ssn::RK_GLUE) head = rl.args.e[q].first + rl.args.e[q].cnt;
+            else break;
+          }
+          rl.args.prio = (head_prio && head < rl.n_blocks) ? head : 0;      // (blocks [0, prio) raise their waves' issue priority)
           if (!no_interleave) {
-            int head = 0;
-            for (int q = 0; q < rl.args.n; ++q) {
-              const int k = rl.args.e[q].kind;
-              if (k == ssn::RK_DFT || k == ssn::RK_SOLO || k == ssn::RK_GATE || k == ssn::RK_ARGMAX || k == ssn::RK_GLUE) head = rl.args.e[q].first + rl.args.e[q].cnt;
-              else break;
-            }
             const long long m = (long long)rl.n_blocks - head;
             if (m >= 64) {
               long long st = (long long)(0.6180339887 * (double)m);

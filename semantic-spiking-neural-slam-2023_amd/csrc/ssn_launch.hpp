@@ -287,7 +287,9 @@ struct RoundArgs {
   // then the Voja rows, then 8 000 latency-bound product-ensemble blocks ...: 70 us = the sum of the bodies' stand-alone times);
   // the stride deals every entry's blocks evenly over the whole launch, so bandwidth-bound and latency-bound bodies share the CUs.
   unsigned int stride;      // 0 / 1: identity
-  int pad;
+  int pad;                  // launch id (diagnostic stamps)
+  int prio;                 // blocks [0, prio) - the latency-bound head of the grid - raise their waves' issue priority (s_setprio 3)
+  int pad2;
   const MicroOp<T>* mops;
   const int* chain;
   const unsigned char* arena;   // body arguments of the plan (serial chains address their transforms through it)

@@ -357,6 +357,10 @@ __global__ __launch_bounds__(256) void k_round(RoundArgs<T> ra) {
   unsigned long long st0, st1;
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st0) :: "memory");
 #endif
+  // The latency-bound bodies at the head of the grid (transforms, serial chains, gate, argmax, glue: one workgroup each, and the
+  // round lasts as long as the slowest of them) share their SIMDs with up to six waves of bandwidth-bound blocks: per-block
+  // stamps (tools/round_stamps.py) show a transform that takes 9.5 us alone taking 25 - 50 us there.  Their waves issue first.
+  if (vb < ra.prio) __builtin_amdgcn_s_setprio(3);
   round_block<T>(ra, vb, ssn_round_smem);
 #ifdef SSN_ROUND_STAMPS
   if constexpr (sizeof(T) == 4) {
