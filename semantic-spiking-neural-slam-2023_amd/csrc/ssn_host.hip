@@ -1792,12 +1792,16 @@ struct Sim final : ssn_sim {
 
   // Cost model of the round balancer: device time a unit needs when bandwidth-bound (us at ~5 TB/s), the latency of a
   // single-workgroup unit (us), and the number of blocks of its grid (0: not splittable).
+  // latency of the single-workgroup bodies as the balancer prices them (us): alone a transform takes 9.5 us and the argmax ~3; inside a
+  // round that also streams they take 25 - 30 and ~13 (tools/round_stamps.py) - SSN_LAT_DFT / SSN_LAT_SOLO for A/B runs
+  double lat_dft = getenv("SSN_LAT_DFT") ? atof(getenv("SSN_LAT_DFT")) : 9.0;
+  double lat_solo = getenv("SSN_LAT_SOLO") ? atof(getenv("SSN_LAT_SOLO")) : 3.0;
   void unit_cost(int mop, int item, double* us, double* lat, int* blocks) const {
     *us = 0.0; *lat = 0.0; *blocks = 0;
     const double per_us = 5.0e6;      // bytes per microsecond
     if (mop >= 0) {
       const MOp& op = mops[(size_t)mop];
-      if (op.kind == ssn::M_GATE || op.kind == ssn::M_ARGMAX_GATHER) *lat = 3.0;
+      if (op.kind == ssn::M_GATE || op.kind == ssn::M_ARGMAX_GATHER) *lat = lat_solo;
       else *us = (double)op.len * 3.0 * sizeof(T) / per_us;
       return;
     }
@@ -1816,7 +1820,7 @@ struct Sim final : ssn_sim {
       case IT_SPMV: *us = 0.1 * (double)it.cols * it.ld * sizeof(T) / per_us; break;
       case IT_NEURONS: *us = (double)it.n * 5.0 * sizeof(T) / per_us; break;
       case IT_MATVEC_NEURONS: *us = (double)it.rows * it.ld * sizeof(T) / per_us; *blocks = (it.rows + 15) / 16; break;
-      case IT_DFT: *lat = 9.0; break;
+      case IT_DFT: *lat = lat_dft; break;
       default: *us = 1.0; break;
     }
   }
