@@ -196,6 +196,9 @@ typedef struct ssn_counters {
    * prices the two paths with these) */
   int64_t block_slots;
   int64_t block_slots_silent;
+  /* round plan (ABI 8) */
+  int32_t fused_populations;        /* dense populations whose neuron update runs in the epilogue of their encoder product      */
+  int32_t serial_chains;            /* serial chains of single-workgroup operators in one timestep's rounds (the eager plan)    */
 } ssn_counters;
 
 /* Per-kernel device time of the generic (one launch per operator) plan, collected by ssn_run_steps(profile = 2):

@@ -55,7 +55,8 @@ class Counters(C.Structure):
                 ("block_tpb", C.c_int32), ("block_npt", C.c_int32), ("block_enc_lds", C.c_int32),
                 ("block_threads", C.c_int32), ("fft_transforms", C.c_int32), ("fft_bluestein", C.c_int32),
                 ("block_members", C.c_int32), ("batch_products_skipped", C.c_int32),
-                ("block_slots", C.c_int64), ("block_slots_silent", C.c_int64)]
+                ("block_slots", C.c_int64), ("block_slots_silent", C.c_int64),
+                ("fused_populations", C.c_int32), ("serial_chains", C.c_int32)]
 
 
 class KernelTime(C.Structure):

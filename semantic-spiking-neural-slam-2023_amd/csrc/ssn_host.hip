@@ -206,6 +206,7 @@ struct Sim final : ssn_sim {
   // timestep k sits between segments k and k + 1 (ssn_run_phase / ssn_phase_async with phase 3 = "the next segment")
   std::vector<std::vector<Launch>> cycle_segs;
   int cycle_steps = 0, next_seg = 0;
+  int n_fused_populations = 0, n_serial_chains = 0;      // (counters of the round plan)
   std::vector<hipGraph_t> cycle_graph;
   std::vector<hipGraphExec_t> cycle_exec;
   std::vector<Launch> phase2_list;            // neuron-sharded models: the updates of timestep s and timestep s + 1 up to its exchange,
@@ -2070,7 +2071,9 @@ struct Sim final : ssn_sim {
           if (items[j].type == IT_MATVEC && items[j].dst == N.src && items[j].rows == N.n) jm = (int)j;
         if (jm < 0) continue;
         const Item& M = items[(size_t)jm];
-        if ((size_t)M.cols * sizeof(T) > 48 * 1024 || M.rows <= 4096 || M.phase != N.phase) continue;
+        // (smaller populations keep the four-rows-per-workgroup product, which fills more of the chip; SSN_FUSE_MIN_ROWS for tests)
+        const int fuse_min_rows = getenv("SSN_FUSE_MIN_ROWS") ? atoi(getenv("SSN_FUSE_MIN_ROWS")) : 4097;
+        if ((size_t)M.cols * sizeof(T) > 48 * 1024 || M.rows < fuse_min_rows || M.phase != N.phase) continue;
         std::vector<Rng> accM;
         item_access(accM, M);
         bool ok = true;
@@ -2098,6 +2101,7 @@ struct Sim final : ssn_sim {
         N.type = IT_MATVEC_NEURONS;
         N.Wm = M.Wm; N.aux0 = M.src; N.rows = M.rows; N.cols = M.cols; N.ld = M.ld; N.set = M.set;
         items[(size_t)jm].type = IT_NONE;
+        n_fused_populations += 1;
         if (getenv("SSN_DEBUG_PLAN")) fprintf(stderr, "[ssn] encoder product %d x %d and the update of its %d neurons fused (items %d, %zu)\n", N.rows, N.cols, N.n, jm, jn);
       }
     }
@@ -2640,6 +2644,8 @@ struct Sim final : ssn_sim {
     }
     launch_list.clear();
     emit(one, n_rounds, launch_list, chains_one);
+    n_serial_chains = 0;
+    for (size_t c = 0; c < chains_one.size(); ++c) if (chains_one[c].size() >= 2 && one[(size_t)chains_one[c][0]].solo) n_serial_chains += 1;
     launches_per_step = (int)launch_list.size();
     const int launches_unpipelined = launches_per_step;
 
@@ -3869,6 +3875,7 @@ struct Sim final : ssn_sim {
     out->block_members = fused_block ? std::max(1, blk.P) : 0;
     out->batch_products_skipped = batch_skipped;
     out->block_slots = 0; out->block_slots_silent = 0;
+    out->fused_populations = n_fused_populations; out->serial_chains = n_serial_chains;
     if (fused_block && blk.slot_stats) {
       unsigned long long ss[2] = {0, 0};
       hipSetDevice(device);

@@ -160,6 +160,19 @@ def stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=Tru
                             return stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=False, collapse=collapse)
                         stage[j] = stage[i]
                         changed = True
+                        # ... and whatever else j reads must then be written no later than j's new stage (stage[i] <= stage[j] on
+                        # every edge): a merged hand-off that copies the states of a core filter AND of a read-out filter into
+                        # node inputs would otherwise run per timestep on a state the post stage only updates after the block
+                        # (round 4: a second decoded connection of a dense population read zeros)
+                        todo = [j]
+                        while todo:
+                            v = todo.pop()
+                            for q in pred[v]:
+                                if stage[q] > stage[v]:
+                                    if ops[q]["kind"] in CORE_KINDS:
+                                        return stage_ops(ops, model, r_allocs, schedule_ops, op_access, overlap, enable=False, collapse=collapse)
+                                    stage[q] = stage[v]
+                                    todo.append(q)
 
     if enable and any(st != CORE for st in stage):
         ops, stage = _split_elementwise(list(ops), list(stage))

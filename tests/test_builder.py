@@ -94,6 +94,43 @@ def test_stage_partition_of_pathintegration(pi_model):
     np.testing.assert_allclose(a.probe_data(0), b.probe_data(0), atol=1e-13)
 
 
+def _stage_order_holds(m):
+    """Every writer of a signal runs in a stage no later than every reader of it (any lag): the core stage steps per timestep,
+    the post stage once per block behind it - a core reader of a state that the post stage updates would see a stale value."""
+    acc = [op_access(o, m) for o in m.ops]
+    for i, a in enumerate(acc):
+        w = [r for cls in (0, 1, 3) for r in a[cls]]
+        for j, b in enumerate(acc):
+            if i != j and any(_overlap(x, y) for x in w for y in b[2]):
+                assert m.ops[i]["stage"] <= m.ops[j]["stage"], (m.ops[i], m.ops[j])
+
+
+def test_stage_order_when_one_hand_off_reads_core_and_read_out_filters(pi_model):
+    """A dense population with two decoded connections, one of them only ever read by a probe: the builder merges the copies
+    of both filters' states into the node inputs into one operator; the synapse rule moves that operator into the core stage
+    (it reads a core filter's state before the update), and the read-out filter it also reads - with the decode that feeds it -
+    has to follow (round 4: left in the post stage, the second connection read zeros on the device)."""
+    d = 19
+    with nengo.Network(seed=4) as net:
+        u = nengo.Node(lambda t: np.sin(8 * t + np.arange(d)) * 0.8)
+        a = nengo.Ensemble(200, d)
+        e = nengo.Ensemble(300, d)
+        o = nengo.Node(size_in=2)
+        o2 = nengo.Node(size_in=1)
+        nengo.Connection(u, a, synapse=None)
+        nengo.Connection(a, e, synapse=0.01)
+        nengo.Connection(e, o, synapse=0.01, function=lambda x: [x[0] * x[1], x[0]])
+        nengo.Connection(e, o2, synapse=0.005, function=lambda x: x[0] ** 2)
+        nengo.Probe(o, synapse=0.02)
+        nengo.Probe(o2)
+    m = build(net)
+    assert m.stage_info["enabled"]
+    _stage_order_holds(m)
+    readout = [o_ for o_ in m.ops if o_["kind"] == "matvec" and o_["cols"] == 300]
+    assert len(readout) == 2 and all(o_["stage"] == 1 for o_ in readout)
+    _stage_order_holds(pi_model[1])
+
+
 def test_cycle_without_synapse_is_rejected():
     with nengo.Network(seed=0) as m:
         a = nengo.Node(size_in=1)

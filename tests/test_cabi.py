@@ -37,7 +37,7 @@ def test_header_symbols_are_exported_and_declared(lib):
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.OpDesc) == 6 * 4 + 12 * 8 + 4 * 8 and _lib.OpDesc.i.offset == 24
     assert C.sizeof(_lib.BufferDesc) == 24 and C.sizeof(_lib.ProbeDesc) == 32 and C.sizeof(_lib.Range) == 16
-    assert C.sizeof(_lib.Counters) == 112 and _lib.Counters.block_slots.offset == 96 and _lib.Counters.block_tpb.offset == 64 and _lib.Counters.fft_transforms.offset == 80
+    assert C.sizeof(_lib.Counters) == 120 and _lib.Counters.fused_populations.offset == 112 and _lib.Counters.block_slots.offset == 96 and _lib.Counters.block_tpb.offset == 64 and _lib.Counters.fft_transforms.offset == 80
     assert _lib.Counters.block_members.offset == 88
     assert _lib.ModelDesc.dt.offset == 16 and _lib.ModelDesc.buffers.offset == 56
     assert _lib.ModelDesc.pre_to_core.offset == 88 and _lib.ModelDesc.exchange.offset == 112 and C.sizeof(_lib.ModelDesc) == 128

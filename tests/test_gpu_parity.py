@@ -170,6 +170,57 @@ def test_neuron_types_and_dense_ensembles(Simulator):
             np.testing.assert_allclose(sim.data[ps], ref.probe_data(1), atol=1e-9)
 
 
+def test_encoder_product_with_the_neuron_update_in_its_epilogue(Simulator):
+    """Round plan: where a dense population's encoder product is the last writer of its current vector and nothing else reads
+    that vector, the workgroup that owns 16 rows of the product steps their 16 neurons and leaves their spikes as a 16-neuron
+    segment of the spike list (matvec_neurons_body; by default for populations of more than 4096 neurons, here forced for small
+    ones).  Sizes that leave a partial last workgroup and a partial wave, an input wider than one 16-byte vector per lane with
+    a scalar tail, all three neuron types, a second decoded connection through the same spike list: f64 equal to the oracle and
+    bit-equal to the unfused plan, f32 equal to the unfused plan up to the rounding of another summation order."""
+    saved = {k: os.environ.get(k) for k in ("SSN_FUSE_MIN_ROWS", "SSN_FUSE_NEURONS")}
+    try:
+        # (an input of at most 16 dimensions makes the encoder product a glue micro-operator: nothing to fuse with)
+        for nt, n, d in ((nengo.LIF(), 1003, 19), (nengo.LIF(), 330, 67), (nengo.LIFRate(), 300, 17), (nengo.RectifiedLinear(), 77, 18)):
+            with nengo.Network(seed=4) as m:
+                u = nengo.Node(lambda t, d=d: np.sin(8 * t + np.arange(d)) * 0.8)
+                a = nengo.Ensemble(200, d)                 # (a tabulated input's encoder product runs time-batched: the fused
+                e = nengo.Ensemble(n, d, neuron_type=nt)   #  population takes its input from another population's filtered output)
+                o = nengo.Node(size_in=2)
+                o2 = nengo.Node(size_in=1)
+                nengo.Connection(u, a, synapse=None)
+                nengo.Connection(a, e, synapse=0.01)
+                nengo.Connection(e, o, synapse=0.01, function=lambda x: [x[0] * x[1], x[0]])
+                nengo.Connection(e, o2, synapse=0.005, function=lambda x: x[0] ** 2)
+                p = nengo.Probe(o, synapse=0.02)
+                p2 = nengo.Probe(o2)
+                ps = nengo.Probe(e.neurons[:5])
+            model = build(m)
+            ref = OracleSimulator(model)
+            ref.run_steps(300)
+            outs = {}
+            for dtype in ("f64", "f32"):
+                for fused in (True, False):
+                    os.environ["SSN_FUSE_MIN_ROWS"] = "1"
+                    os.environ["SSN_FUSE_NEURONS"] = "1" if fused else "0"
+                    with Simulator(None, model=model, dtype=dtype) as sim:
+                        assert sim.counters()["fused_populations"] == (1 if fused else 0), (nt, n, d, dtype)
+                        sim.run_steps(300)
+                        outs[dtype, fused] = (sim.data[p], sim.data[p2], sim.data[ps])
+            for q in range(3):
+                np.testing.assert_allclose(outs["f64", True][q], ref.probe_data(q), atol=1e-9, err_msg=f"{nt} {n} {d} probe {q}")
+                np.testing.assert_array_equal(outs["f64", True][q], outs["f64", False][q], err_msg=f"{nt} {n} {d} probe {q}")
+                # (f32: below 4097 rows the unfused product is the one-row-per-wave variant, which adds a row's terms in another
+                #  order - rounding only; from 4097 rows on both are the four-rows-per-wave order and config 3 is bit-equal)
+                np.testing.assert_allclose(outs["f32", True][q], outs["f32", False][q], atol=1e-5 * max(1.0, np.abs(outs["f32", False][q]).max()),
+                                           err_msg=f"{nt} {n} {d} probe {q}")
+            assert np.abs(outs["f32", True][0]).max() > 0.01
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("neuron_type,n", [("LIFRate", 13000), ("LIF", 16000)])
 def test_dense_product_over_a_long_activity_vector(Simulator, neuron_type, n):
     """A learned (PES) decoder product over more activities than k_matvec's 48 KB LDS stage holds (12 288 f32 /
@@ -469,7 +520,7 @@ def test_serial_chains_equal_plain_rounds(Simulator):
                 sim.run_steps(200)
                 outs[name] = sim.data[sm.probe]
                 c = sim.counters()
-                launches[name] = (c["launches_per_step"], c["fft_transforms"])
+                launches[name] = (c["launches_per_step"], c["fft_transforms"], c["serial_chains"])
     finally:
         for k, v in saved.items():
             os.environ.pop(k, None)
@@ -479,6 +530,7 @@ def test_serial_chains_equal_plain_rounds(Simulator):
     np.testing.assert_array_equal(outs["default"], outs["off"])
     np.testing.assert_array_equal(outs["dft"], outs["off"])
     assert launches["dft"][0] <= launches["default"][0] <= launches["off"][0]
+    assert launches["off"][2] == 0 and launches["default"][2] > 0 and launches["dft"][2] > 0
 
 
 def test_feedforward_model_runs_fully_batched(Simulator):
