@@ -1,6 +1,7 @@
 """Test helpers: an oracle-backed stand-in with the Simulator's Python surface (tests only)."""
 import numpy as np
 
+import sspslam_amd.frontend as nengo
 from oracle import OracleSimulator
 
 
@@ -62,3 +63,126 @@ def small_pathint(ssp_dim=7, n=64, T=2.0, seed=1, limit=0.5, **kw):
     space = H.make_ssp_space(2, ssp_dim=ssp_dim)
     path, vels = H.make_random_path(T, limit=limit, seed=seed)
     return H.make_pathint_model(space, path, vels, n, **kw)
+
+
+def random_network(seed):
+    """Nodes, ensembles of every neuron type, an ensemble array, pass-through nodes; decoded connections with functions and
+    transforms, slices, neuron-to-node read-outs, recurrent and feedback connections through synapses, direct (synapse=None)
+    connections only forwards in declaration order (no algebraic loops), an optional PES rule; probes with and without
+    synapses on everything."""
+    rng = np.random.RandomState(seed)
+    probes = []
+    with nengo.Network(seed=seed) as net:
+        n_in = rng.randint(1, 3)
+        sources = []                                     # (object, dimensions, may be the pre of a direct connection)
+        for k in range(n_in):
+            d = int(rng.choice([1, 2, 3, 5, 17, 24]))
+            w = rng.uniform(2.0, 12.0, size=d)
+            ph = rng.uniform(0, 6.28, size=d)
+            amp = rng.uniform(0.3, 0.9)
+            sources.append((nengo.Node(lambda t, w=w, ph=ph, amp=amp: amp * np.sin(w * t + ph)), d))
+        objs = list(sources)
+        n_ens = rng.randint(2, 5)
+        ens = []
+        for k in range(n_ens):
+            d = int(rng.choice([1, 2, 3, 4, 9, 17, 20]))
+            n = int(rng.choice([30, 64, 100, 257, 300, 700, 1100]))
+            nt = [nengo.LIF(), nengo.LIF(), nengo.LIF(tau_rc=0.03, tau_ref=0.001), nengo.LIFRate(), nengo.RectifiedLinear()][rng.randint(0, 5)]
+            e = nengo.Ensemble(n, d, neuron_type=nt, radius=float(rng.choice([1.0, 1.5])))
+            ens.append((e, d))
+            objs.append((e, d))
+        if rng.rand() < 0.5:
+            K, dk = int(rng.choice([3, 8, 21])), int(rng.choice([1, 2]))
+            ea = nengo.EnsembleArray(int(rng.choice([40, 90])), K, ens_dimensions=dk)
+            objs.append((ea.input, K * dk))
+            arr_out = (ea.output, K * dk)
+        else:
+            arr_out = None
+        n_pass = rng.randint(0, 3)
+        passes = []
+        for k in range(n_pass):
+            d = int(rng.choice([1, 2, 3, 6]))
+            pnode = nengo.Node(size_in=d)
+            passes.append((pnode, d))
+            objs.append((pnode, d))
+        order = {id(o): i for i, (o, _) in enumerate(objs)}
+
+        def transform(d_out, d_in):
+            if d_out == d_in and rng.rand() < 0.4:
+                return float(rng.uniform(0.3, 1.2))
+            return rng.uniform(-1.0, 1.0, size=(d_out, d_in)) / np.sqrt(d_in)
+
+        def connect(pre, d_pre, post, d_post, synapse, allow_function):
+            kw = {}
+            if allow_function and rng.rand() < 0.4:
+                f_d = int(rng.choice([1, 2]))
+                if f_d == 1:
+                    kw["function"] = lambda x: x[0] ** 2
+                else:
+                    kw["function"] = lambda x: [x[0] * x[-1], x[0]]
+                d_pre = f_d
+            kw["transform"] = transform(d_post, d_pre)
+            return nengo.Connection(pre, post, synapse=synapse, **kw)
+
+        # every ensemble gets at least one input, from something declared before it (directly or through a synapse)
+        targets = [(e, d) for e, d in ens] + ([(ea.input, arr_out[1])] if arr_out else []) + passes
+        producers = list(sources)
+        learned = None
+        for post, d_post in targets:
+            pre, d_pre = producers[rng.randint(0, len(producers))]
+            is_ens = isinstance(pre, nengo.Ensemble)
+            syn = [None, 0.005, 0.02][rng.randint(0, 3)]
+            if is_ens and learned is None and isinstance(post, nengo.Node) and syn is not None and rng.rand() < 0.7:
+                # a PES rule on this decoded connection: error = post - (a transform of the first input), as in the reference's
+                # associative memory (associativememory.py:41-54)
+                learned = nengo.Connection(pre, post, synapse=syn, transform=transform(d_post, d_pre),
+                                           learning_rule_type=nengo.PES(learning_rate=float(rng.choice([1e-4, 5e-4]))))
+                err = nengo.Node(size_in=d_post)
+                nengo.Connection(post, err, synapse=None)
+                nengo.Connection(sources[0][0], err, transform=-rng.uniform(-1.0, 1.0, size=(d_post, sources[0][1])), synapse=None)
+                nengo.Connection(err, learned.learning_rule, synapse=None)
+            else:
+                connect(pre, d_pre, post, d_post, syn, is_ens)
+            producers.append((post, d_post))
+        if arr_out:
+            producers.append(arr_out)
+        # extra connections: backwards or recurrent ones only through a synapse
+        for k in range(rng.randint(1, 5)):
+            pre, d_pre = producers[rng.randint(0, len(producers))]
+            post, d_post = targets[rng.randint(0, len(targets))]
+            if pre is post:
+                syn = 0.05
+            else:
+                syn = [0.005, 0.01, 0.05][rng.randint(0, 3)]
+            connect(pre, d_pre, post, d_post, syn, isinstance(pre, nengo.Ensemble))
+        # a circular convolution of two of the producers (reference networks/binding.py:297-317; the transforms are FFTs on the device)
+        if rng.rand() < 0.45:
+            from sspslam_amd.networks import CircularConvolution
+            dc = int(rng.choice([9, 16, 25, 36]))
+            cc = CircularConvolution(int(rng.choice([20, 50])), dc, invert_b=bool(rng.rand() < 0.5))
+            for inp in (cc.input_a, cc.input_b):
+                pre, d_pre = producers[rng.randint(0, len(producers))]
+                nengo.Connection(pre, inp, transform=rng.uniform(-1.0, 1.0, size=(dc, d_pre)) / np.sqrt(d_pre),
+                                 synapse=[0.005, 0.02][rng.randint(0, 2)])
+            probes.append(nengo.Probe(cc.output, synapse=[None, 0.01][rng.randint(0, 2)]))
+            if rng.rand() < 0.5:
+                post, d_post = targets[rng.randint(0, len(targets))]
+                nengo.Connection(cc.output, post, transform=rng.uniform(-1.0, 1.0, size=(d_post, dc)) / np.sqrt(dc), synapse=0.01)
+        # read-outs
+        for e, d in ens:
+            r = rng.rand()
+            if r < 0.5:
+                probes.append(nengo.Probe(e, synapse=[None, 0.01, 0.03][rng.randint(0, 3)]))
+            if rng.rand() < 0.4:
+                probes.append(nengo.Probe(e.neurons[:min(7, e.n_neurons)]))
+            if rng.rand() < 0.4:
+                o = nengo.Node(size_in=1)
+                nengo.Connection(e, o, synapse=0.01, function=lambda x: x[0] ** 2)
+                probes.append(nengo.Probe(o, synapse=[None, 0.02][rng.randint(0, 2)]))
+        for pnode, d in passes:
+            probes.append(nengo.Probe(pnode, synapse=[None, 0.01][rng.randint(0, 2)]))
+        if arr_out:
+            probes.append(nengo.Probe(arr_out[0], synapse=0.01))
+        if not probes:
+            probes.append(nengo.Probe(ens[0][0], synapse=0.01))
+    return net, probes

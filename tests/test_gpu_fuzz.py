@@ -1,0 +1,95 @@
+"""Seeded random networks through the whole stack (front end -> builder -> stages -> round plan -> HIP kernels) against the oracle.
+
+The parity tests of test_gpu_parity.py follow the reference's two networks and the shapes their parts take; the partitioning
+and planning code in between (stages.py, glue.py, build_rounds) is written for any nengo-shaped graph, and its corner cases
+only show on graphs nobody drew by hand (round 4: a hand-off operator that copied a core filter's and a read-out filter's state
+in one go left the read-out one step-major stale).  Every network here is small, runs 150 timesteps in the f64 parity mode and
+has to match the oracle to 1e-9 on every probe; a handful also run in f32 against the cosine bar."""
+import numpy as np
+import pytest
+
+import sspslam_amd.frontend as nengo
+from sspslam_amd.builder import build
+from oracle import OracleSimulator
+
+from helpers import random_network
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Simulator():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    from sspslam_amd.simulator import Simulator
+    return Simulator
+
+
+SEEDS = list(range(1, 41))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_network_f64_matches_oracle(Simulator, seed):
+    net, probes = random_network(seed)
+    model = build(net)
+    ref = OracleSimulator(model)
+    steps = 150
+    ref.run_steps(steps)
+    with Simulator(None, model=model, dtype="f64") as sim:
+        sim.run_steps(70)
+        sim.run_steps(steps - 70)
+        for p in probes:
+            q = [i for i, mp in enumerate(model.probes) if mp["probe"] is p][0]
+            want = ref.probe_data(q)
+            got = sim.data[p]
+            assert got.shape == want.shape
+            np.testing.assert_allclose(got, want, atol=1e-9, rtol=0, err_msg=f"seed {seed} probe {q}")
+
+
+@pytest.mark.parametrize("seed", SEEDS[:12])
+def test_random_network_f32_within_the_cosine_bar(Simulator, seed):
+    net, probes = random_network(seed)
+    model = build(net)
+    ref = OracleSimulator(model)
+    steps = 150
+    ref.run_steps(steps)
+    with Simulator(None, model=model, dtype="f32") as sim:
+        sim.run_steps(steps)
+        for p in probes:
+            if p.synapse is None:
+                continue                  # (unfiltered spikes / currents: one flipped spike is a cosine error of its own)
+            q = [i for i, mp in enumerate(model.probes) if mp["probe"] is p][0]
+            want, got = ref.probe_data(q), sim.data[p]
+            big = np.linalg.norm(want, axis=1) > 0.05
+            if big.sum() < 10:
+                continue
+            num = np.sum(want[big] * got[big], axis=1)
+            den = np.linalg.norm(want[big], axis=1) * np.linalg.norm(got[big], axis=1)
+            assert (1.0 - num / den).max() < 1e-3, f"seed {seed} probe {q}"
+
+
+@pytest.mark.parametrize("seed", SEEDS[::3])
+def test_random_network_under_the_opt_in_plans(Simulator, seed):
+    """The same networks with the planner's size thresholds and switches moved so that small graphs take the paths of big ones:
+    every dense population's neuron update fused into its encoder product (SSN_FUSE_MIN_ROWS=1), transforms allowed into serial
+    chains with a generous cap, 16 timesteps per graph, and the one-launch-per-operator plan of round 1 (flag 2097152)."""
+    import os
+    net, probes = random_network(seed)
+    model = build(net)
+    ref = OracleSimulator(model)
+    steps = 100
+    ref.run_steps(steps)
+    saved = {k: os.environ.get(k) for k in ("SSN_FUSE_MIN_ROWS", "SSN_SOLO_DFT", "SSN_SOLO_CAP_US")}
+    try:
+        os.environ.update(SSN_FUSE_MIN_ROWS="1", SSN_SOLO_DFT="1", SSN_SOLO_CAP_US="60")
+        for kw in (dict(steps_per_graph=16), dict(flags=2097152), dict(steps_per_graph=1)):
+            with Simulator(None, model=model, dtype="f64", **kw) as sim:
+                sim.run_steps(steps)
+                for p in probes:
+                    q = [i for i, mp in enumerate(model.probes) if mp["probe"] is p][0]
+                    np.testing.assert_allclose(sim.data[p], ref.probe_data(q), atol=1e-9, rtol=0, err_msg=f"seed {seed} probe {q} {kw}")
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v

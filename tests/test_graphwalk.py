@@ -11,7 +11,7 @@ from sspslam_amd.builder import build
 from oracle import OracleSimulator
 from oracle.graphwalk import GraphWalkSimulator
 
-from helpers import small_pathint
+from helpers import random_network, small_pathint
 
 
 def _probe_index(model, probe):
@@ -113,3 +113,20 @@ def test_gridcell_population_options_lower_like_the_graph_walk():
             a, b = ref.probe_data(_probe_index(model, p)), walk.probe_data(p)
             assert a.shape == b.shape and np.abs(a).max() > 0
             np.testing.assert_allclose(a, b, atol=1e-9, rtol=0)
+
+
+@pytest.mark.parametrize("seed", [2, 5, 6, 12, 17, 20, 22, 23])
+def test_random_networks_lowering_equals_the_graph_walk(seed):
+    """Seeded random networks (helpers.random_network: nodes, ensembles of every neuron type, an ensemble array, pass-through
+    nodes, decoded / direct / recurrent connections, probes on everything; the same generator feeds the GPU fuzz tests):
+    the lowered operator list - merged, pruned, partitioned into stages - against the object-graph interpreter."""
+    net, probes = random_network(seed)
+    model = build(net)
+    ref = OracleSimulator(model)
+    walk = GraphWalkSimulator(net, model)
+    ref.run_steps(80)
+    walk.run_steps(80)
+    for p in probes:
+        a, b = ref.probe_data(_probe_index(model, p)), walk.probe_data(p)
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a, b, atol=1e-9, rtol=0, err_msg=f"seed {seed}")
