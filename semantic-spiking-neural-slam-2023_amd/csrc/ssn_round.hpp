@@ -133,9 +133,24 @@ __device__ __forceinline__ void glue_body(const MicroOp<T>& op, const int chunk,
       const long long i = (long long)chunk * GLUE_ROWS + tid;
       if (i < op.len) {
         const long long k = i / dout, r = i - k * dout;
+        const int dst = didx[i];                 // (fetched beside the partial sums, not behind them)
         T s = T(0);
-        for (int p = 0; p < P; ++p) s += part[((size_t)k * P + p) * dout + r];
-        sig[didx[i]] = s;
+        int p = 0;
+        for (; p + 8 <= P; p += 8) {             // eight partial sums in flight, added in workgroup order
+          T v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = part[((size_t)k * P + p + q) * dout + r];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        {
+          T v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = p + q < P ? part[((size_t)k * P + p + q) * dout + r] : T(0);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) if (p + q < P) s += v[q];
+        }
+        sig[dst] = s;
       }
       break;
     }
@@ -147,7 +162,14 @@ __device__ __forceinline__ void glue_body(const MicroOp<T>& op, const int chunk,
       if (r < op.len) {
         T s = T(0);
         int c = 0;
-        for (; c + 8 <= nc; c += 8) {            // eight chunk reads in flight, added in chunk order
+        for (; c + 16 <= nc; c += 16) {          // sixteen chunk reads in flight (a reduction is one of the dependent trips of every
+          T v[16];                               // population hop: 40 chunks are three trips this way, five with eight), added in chunk order
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = part[(size_t)(c + q) * op.i1 + r];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) s += v[q];
+        }
+        for (; c + 8 <= nc; c += 8) {
           T v[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(c + q) * op.i1 + r];
