@@ -117,7 +117,7 @@ __device__ inline T wave_sum(T v) {
 // ---------------------------------------------------------------------------------------------
 template <int DOUT> struct DecPitch { static constexpr int value = DOUT <= 4 ? 4 : 8; };
 
-template <typename T, int DIN, int DOUT, int MODE>   // MODE 0 generic | 1 fast, spike-sparse decoders | 2 fast, dense decoders
+template <typename T, int DIN, int DOUT, int MODE, bool RND = false>   // MODE 0 generic | 1 fast, spike-sparse decoders | 2 fast, dense decoders; RND: a body of the round grid
 __device__ __forceinline__ void ens_body(const EnsArgs<T>& a, const int bx, unsigned char* smem) {   // smem: 4 * DOUT + DIN values of T
   if (bx >= a.K * a.P) return;          // (grid.x is sized for the larger array of a batch)
   using vec = typename VecT<T>::type;
@@ -157,7 +157,8 @@ __device__ __forceinline__ void ens_body(const EnsArgs<T>& a, const int bx, unsi
   T x[DIN];
   long long step = 0;
   if (a.xrows || a.defer) step = a.ctx->step + a.sub;
-  if (a.defer == 2) {
+  // (the self-finishing form exists in the round grid only: in the stand-alone kernel - config 4's - its branch cost 1 %)
+  if (RND && a.defer == 2) {
     // Round plan (round 4): the array completes ITS OWN previous timestep.  Every workgroup of ensemble k sums the P partial
     // sums that the ensemble's workgroups left at timestep s - 1 for the rows that feed its inputs, advances the recurrent
     // filter states (identical values in every workgroup; workgroup p = 0 keeps them: fstate ping-pongs by timestep parity)

@@ -334,9 +334,9 @@ __device__ __forceinline__ void round_block(const RoundArgs<T>& ra, int vb, unsi
     case RK_DFT:
       if constexpr (sizeof(T) == 4) dft_body<true>(*(const DftArgs*)e.args, smem);
       break;
-    case RK_ENS_3_4_S: ens_body<T, 3, 4, 1>(*(const EnsArgs<T>*)e.args, bx, smem); break;
-    case RK_ENS_3_5_S: ens_body<T, 3, 5, 1>(*(const EnsArgs<T>*)e.args, bx, smem); break;
-    case RK_ENS_1_1_D: ens_body<T, 1, 1, 2>(*(const EnsArgs<T>*)e.args, bx, smem); break;
+    case RK_ENS_3_4_S: ens_body<T, 3, 4, 1, true>(*(const EnsArgs<T>*)e.args, bx, smem); break;
+    case RK_ENS_3_5_S: ens_body<T, 3, 5, 1, true>(*(const EnsArgs<T>*)e.args, bx, smem); break;
+    case RK_ENS_1_1_D: ens_body<T, 1, 1, 2, true>(*(const EnsArgs<T>*)e.args, bx, smem); break;
     case RK_ENS_SMALL: ens_small_body<T>(*(const EnsArgs<T>*)e.args, bx); break;
     case RK_GRID_LHS: grid_lhs_body<T>(*(const GridLhsArgs<T>*)e.args, bx); break;
     case RK_GRID_DOT: {      // row block bx of the remaining-axis factors against left-operand row by: similarities [by * nn + 16 bx ...)
