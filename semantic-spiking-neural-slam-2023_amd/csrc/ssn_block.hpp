@@ -138,13 +138,19 @@ __device__ inline f32x2 pk_fma_clamp01_vs_negv(f32x2 x, f32x2 y, f32x2 z) {     
 //   U  = (Jm1 + W0) * em - W0     V - 1 = V0 + (J - V0) em - 1
 //   spk = clamp(U * 2^100)        1 if V > 1, else 0 (a positive U is at least 2^-53: it is the rounded difference of a
 //                                 product >= 2^-6 and a W0 next to it)
-//   nu = clamp(K tau_ref + K tau_rc ln(1 - U / Jm1))      K (tau_ref + t_spike - dt) of a spiking neuron, inside [0, 1] because
-//                                 dt <= tau_ref.  A silent neuron feeds rcp / log whatever its operands are (0, negative: inf,
-//                                 NaN); the clamp turns any of it into a number in [0, 1] (DX10 clamp: NaN -> 0), spk = 0 discards it
+//   nu = clamp(K tau_ref + K tau_rc ln(1 - u)), u = U / Jm1      K (tau_ref + t_spike - dt) of a spiking neuron, inside [0, 1]
+//                                 because dt <= tau_ref.  A neuron that crosses the threshold in this step has
+//                                 0 <= u <= 1 - exp(-dt / tau_rc) <= 0.049 (the overshoot V - 1 is at most (J - 1) (1 - exp(-delta / tau_rc))),
+//                                 and there ln(1 - u) = u phi(u) with phi = ln(1 - u) / u replaced by its quadratic interpolant through
+//                                 three Chebyshev nodes of [0, u_max]: within 5e-8 of ln(1 - u) - what v_log_f32 of the ROUNDED 1 - u
+//                                 gives as well - for three packed FMAs instead of an FMA and two transcendentals per neuron pair
+//                                 (round 4: 40 -> 20 transcendentals per wave and timestep).  A silent neuron feeds rcp whatever
+//                                 its operand is (0, negative: inf, NaN); the clamp turns any of it into a number in [0, 1]
+//                                 (DX10 clamp: NaN -> 0), spk = 0 discards it
 //   Wn = clamp(spk * 2^100 - U)   1 - Vn: voltage of a silent neuron clamped at min_voltage 0, Vn = 0 for a spiking one
 //   w' = (Wn + nmt) + spk * nu    (spiking: Wn = 1, nmt = 0; silent: spk = 0 - exact selects, products with 0 / 1)
 // Requires dt / tau_rc <= 1/20 and tau_ref >= dt (checked by the host planner).
-struct LifConstV3 { float na, ca, m1, c1, c2, c3, ktau_ln2, ktau_ref, K; };
+struct LifConstV3 { float na, ca, m1, c1, c2, c3, p0, p1, p2, ktau_ref, K; };      // p: K tau_rc phi(u) ~ p0 + p1 u + p2 u^2
 
 // K, the constants of dl / nmt and the coefficients of P for dl in units of dt (uniform; evaluated once per launch, in double)
 __device__ inline LifConstV3 lif_const_v3(double dt, double tau_rc, double tau_ref) {
@@ -164,7 +170,17 @@ __device__ inline LifConstV3 lif_const_v3(double dt, double tau_rc, double tau_r
   if ((double)ca < (double)a + 1.0) ca = __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, ca) + 1u);      // next float up: c - a >= 1 in exact arithmetic, a full step is 1, never 1 - ulp
   c.na = -a; c.ca = ca; c.m1 = (float)(1.0 + K * dt);
   c.c1 = (float)(q0 * h); c.c2 = (float)(q1 * h * h); c.c3 = (float)(q2 * h * h * h);       // x = dl * h
-  c.ktau_ln2 = (float)(K * tau_rc * 0.6931471805599453); c.ktau_ref = (float)(K * tau_ref); c.K = (float)K;
+  {
+    // phi(u) = ln(1 - u) / u on [0, u_max], u_max = 1 - exp(-h): interpolant through the Chebyshev nodes, times K tau_rc
+    const double um = -expm1(-h);
+    const double u0 = um * 0.9330127018922193, u1 = um * 0.5, u2 = um * 0.0669872981077807;
+    auto phi = [](double u) { return log1p(-u) / u; };
+    const double g0 = phi(u0), g1 = phi(u1), g2 = phi(u2);
+    const double e01 = (g1 - g0) / (u1 - u0), e12 = (g2 - g1) / (u2 - u1), e012 = (e12 - e01) / (u2 - u0);
+    const double r2 = e012, r1 = e01 - e012 * (u0 + u1), r0 = g0 - e01 * u0 + e012 * u0 * u1;
+    c.p0 = (float)(K * tau_rc * r0); c.p1 = (float)(K * tau_rc * r1); c.p2 = (float)(K * tau_rc * r2);
+  }
+  c.ktau_ref = (float)(K * tau_ref); c.K = (float)K;
   return c;
 }
 
@@ -196,11 +212,11 @@ __device__ inline void lif_finish_spiking(f32x2 Jm1, f32x2& w, f32x2 U, f32x2 nm
   f32x2 rc;
   rc.x = __builtin_amdgcn_rcpf(Jm1.x);
   rc.y = __builtin_amdgcn_rcpf(Jm1.y);
-  const f32x2 omu = __builtin_elementwise_fma(-U, rc, (f32x2)(1.0f));       // 1 - (V - 1) / (J - 1)
-  f32x2 lg2;
-  lg2.x = __builtin_amdgcn_logf(omu.x);
-  lg2.y = __builtin_amdgcn_logf(omu.y);
-  const f32x2 nu = pk_fma_clamp01_trans_vvs(lg2, (f32x2)(c.ktau_ln2), (f32x2)(c.ktau_ref));
+  const f32x2 u = U * rc;                                                    // (V - 1) / (J - 1)
+  f32x2 P, nu;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(u), "v"((f32x2)(c.p2)), "s"((f32x2)(c.p1)));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(u), "v"(P), "s"((f32x2)(c.p0)));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(nu) : "v"(u), "v"(P), "s"((f32x2)(c.ktau_ref)));
   const f32x2 Wn = pk_fma_clamp01_vs_negv(spk, big, U);
   w = __builtin_elementwise_fma(spk, nu, Wn + nmt);
 }
@@ -216,18 +232,19 @@ __device__ inline f32x2 lif_input_part(f32x2 Jm1, f32x2& w, f32x2 W0, f32x2 em, 
   f32x2 rc;
   rc.x = __builtin_amdgcn_rcpf(Jm1.x);
   rc.y = __builtin_amdgcn_rcpf(Jm1.y);
-  const f32x2 omu = __builtin_elementwise_fma(-U, rc, (f32x2)(1.0f));       // 1 - (V - 1) / (J - 1)
-  f32x2 lg2;
-  lg2.x = __builtin_amdgcn_logf(omu.x);
-  lg2.y = __builtin_amdgcn_logf(omu.y);
-  // Wn = clamp(spk * 2^100 - U) and nu = clamp(lg2 * K tau_rc ln 2 + K tau_ref) as ONE asm statement, Wn first: the wait state a
-  // non-transcendental reader of v_log's result needs (see pk_fma_clamp01_trans_vvs) is filled by an instruction that has to be
-  // issued anyway instead of an s_nop - 20 s_nop per wave and timestep at 20 neurons per lane (round 4)
-  f32x2 nu, Wn;
+  // Wn = clamp(spk * 2^100 - U) sits between the reciprocals and their first reader: the wait state a non-transcendental reader
+  // of a transcendental's result needs is filled by an instruction that has to be issued anyway (the compiler's hazard recognizer
+  // does not look inside inline asm, so the order is fixed by ONE asm statement: Wn, then u = U * rc)
+  f32x2 Wn, u;
   asm("v_pk_fma_f32 %0, %2, %3, %4 neg_lo:[0,0,1] neg_hi:[0,0,1] clamp\n\t"
-      "v_pk_fma_f32 %1, %5, %6, %7 clamp"
-      : "=&v"(Wn), "=v"(nu)
-      : "v"(spk), "s"(big), "v"(U), "v"(lg2), "v"((f32x2)(c.ktau_ln2)), "s"((f32x2)(c.ktau_ref)));
+      "v_pk_mul_f32 %1, %4, %5"
+      : "=&v"(Wn), "=v"(u)
+      : "v"(spk), "s"(big), "v"(U), "v"(rc));
+  // nu = clamp(K tau_ref + u (p0 + u (p1 + u p2))): the spike time without v_log (see the table above)
+  f32x2 P, nu;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(u), "v"((f32x2)(c.p2)), "s"((f32x2)(c.p1)));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(u), "v"(P), "s"((f32x2)(c.p0)));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(nu) : "v"(u), "v"(P), "s"((f32x2)(c.ktau_ref)));
   w = __builtin_elementwise_fma(spk, nu, Wn + nmt);
   return spk;
 }
@@ -315,7 +332,7 @@ __global__ __launch_bounds__(TPB) void k_ens_block(BlockArgs<T> a) {   // SPLIT:
   //  them as their one constant-bus operand)
   auto uni = [](float v) { return bits_f(__builtin_amdgcn_readfirstlane(f_bits(v))); };
   LifConstV3 lc = lif_const_v3((double)np.dt, (double)np.tau_rc, (double)np.tau_ref);
-  lc.na = uni(lc.na); lc.ca = uni(lc.ca); lc.m1 = uni(lc.m1); lc.c1 = uni(lc.c1); lc.c2 = uni(lc.c2); lc.c3 = uni(lc.c3); lc.ktau_ln2 = uni(lc.ktau_ln2); lc.ktau_ref = uni(lc.ktau_ref);
+  lc.na = uni(lc.na); lc.ca = uni(lc.ca); lc.m1 = uni(lc.m1); lc.c1 = uni(lc.c1); lc.c2 = uni(lc.c2); lc.c3 = uni(lc.c3); lc.p0 = uni(lc.p0); lc.p1 = uni(lc.p1); lc.p2 = uni(lc.p2); lc.ktau_ref = uni(lc.ktau_ref);
   lc.K = uni(lc.K);
   const f32x2 big = {0x1p100f, 0x1p100f};
 

@@ -712,6 +712,7 @@ class Simulator:
             self._uncollected = True
 
     def phase_sync(self, stream_ptr):
+        self._cycle_seg = 0              # (the library leaves a cycle it is synchronised inside of, with an error)
         self._check(self._lib.ssn_phase_sync(self._h, C.c_void_p(stream_ptr or None)))
 
     def exchange_size(self):

@@ -3,7 +3,7 @@
 usage: isa_loop_count.py [--asm FILE | --src ssn_f32.hip] --kernel <mangled-name-substring> [--npt N] [--json OUT] [-- extra hipcc flags]
 
 The time loop is found structurally: the innermost loop - by the compiler's block annotations - of the kernel that
-contains the LIF step's `v_log_f32` instructions.  (Round 1's version bracketed the loop by the workgroup barriers
+contains the LIF step's transcendentals (`v_log_f32`; `v_rcp_f32` only since round 4).  (Round 1's version bracketed the loop by the workgroup barriers
 around the first / last `v_log`; after a kernel change the second barrier lay outside the time loop and the count
 came out as 301 instead of 608 issue slots - VERDICT r1, roofline item.)
 
@@ -64,9 +64,10 @@ def loop_lines(body):
             cur[1] = cur[0]
         if not m:
             cur[2].append(l)
-    with_log = [b for b in blocks if any("v_log_f32" in x for x in b[2])]
+    # (round 4: the spike time no longer takes a v_log_f32; the reciprocal of J - 1 is the LIF step's transcendental now)
+    with_log = [b for b in blocks if any("v_log_f32" in x for x in b[2])] or [b for b in blocks if any("v_rcp_f32" in x for x in b[2]) and b[1] is not None]
     if not with_log:
-        raise SystemExit("no v_log_f32 in the kernel: not an f32 LIF block kernel")
+        raise SystemExit("no v_log_f32 / v_rcp_f32 in a loop of the kernel: not an f32 LIF block kernel")
     heads = {b[1] for b in with_log}
     if len(heads) != 1 or None in heads:
         raise SystemExit(f"the LIF step is spread over loops {heads}")
