@@ -247,3 +247,50 @@ def test_choose_plan_is_collective_and_keeps_one_candidate_resident():
     ref = OracleSimulator(build(small_pathint(ssp_dim=55, n=30, T=10.0, limit=0.2).model))
     ref.run_steps(128)
     np.testing.assert_array_equal(got, ref.probe_data(0))
+
+
+def test_sharded_slam_runner_issues_whole_cycles_then_single_timesteps():
+    """ShardedSLAM.run_steps against a stand-in with the HIP simulator's phase surface: whole cycles of the plan pipelined over
+    the exchange first (cycle_steps + 1 segments, the exchange between consecutive ones - never behind the last), the remaining
+    timesteps as 0, x, 2, x, ..., 1; `cycles=False` keeps the per-timestep phases; the host loop and the stream-ordered loop
+    issue the same sequence."""
+    from sspslam_amd.sharding import ShardedSLAM
+
+    class Sim:
+        def __init__(self, c):
+            self.c, self.calls, self.n_steps, self._prepared_until = c, [], 0, 10 ** 9
+        def cycle_steps(self):
+            return self.c
+        def run_phase(self, p):
+            self.calls.append(p)
+        def phase_async(self, p, buf, stream):
+            self.calls.append(p)
+        def phase_sync(self, stream):
+            self.calls.append("sync")
+        def exchange_host(self, f):
+            self.calls.append("x")
+
+    class Runner(ShardedSLAM):
+        def __init__(self, c, cycles, stream_ordered):
+            self.sim, self.world, self.rank, self.cycles, self.host_loop = Sim(c), 2, 0, cycles, not stream_ordered
+            self.n_steps, self._buf, self._stream, self._so = 0, None, None, stream_ordered
+        def _agree(self, err):
+            assert err is None
+        def _stream_ordered(self):
+            return False                      # (the stream-ordered branch needs torch streams: its sequence is checked on the GPU)
+        def _exchange(self):
+            self.sim.calls.append("x")
+
+    r = Runner(4, True, False)
+    r.run_steps(11)                           # 2 cycles of 4 + 3 single timesteps
+    cyc = [3, "x", 3, "x", 3, "x", 3, "x", 3]
+    assert r.sim.calls == cyc + cyc + [0, "x", 2, "x", 2, "x", 1] and r.n_steps == 11
+    r = Runner(4, True, False)
+    r.run_steps(8)
+    assert r.sim.calls == cyc + cyc
+    r = Runner(4, False, False)
+    r.run_steps(3)
+    assert r.sim.calls == [0, "x", 2, "x", 2, "x", 1]
+    r = Runner(0, True, False)               # a library without a cycle plan for this model
+    r.run_steps(2)
+    assert r.sim.calls == [0, "x", 2, "x", 1]
