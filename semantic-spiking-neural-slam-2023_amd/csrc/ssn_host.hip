@@ -1795,6 +1795,10 @@ struct Sim final : ssn_sim {
   // single-workgroup unit (us), and the number of blocks of its grid (0: not splittable).
   // latency of the single-workgroup bodies as the balancer prices them (us): alone a transform takes 9.5 us and the argmax ~3; inside a
   // round that also streams they take 25 - 30 and ~13 (tools/round_stamps.py) - SSN_LAT_DFT / SSN_LAT_SOLO for A/B runs
+  // (fractions of its matrix a learning rule's update is priced at: dense it reads and writes everything, in the reference's memory
+  //  1.3 % of the filtered activities are nonzero - SSN_COST_PES / SSN_COST_VOJA for A/B runs)
+  double cost_pes = getenv("SSN_COST_PES") ? atof(getenv("SSN_COST_PES")) : 2.0;
+  double cost_voja = getenv("SSN_COST_VOJA") ? atof(getenv("SSN_COST_VOJA")) : 0.2;
   double lat_dft = getenv("SSN_LAT_DFT") ? atof(getenv("SSN_LAT_DFT")) : 9.0;
   double lat_solo = getenv("SSN_LAT_SOLO") ? atof(getenv("SSN_LAT_SOLO")) : 3.0;
   void unit_cost(int mop, int item, double* us, double* lat, int* blocks) const {
@@ -1816,8 +1820,8 @@ struct Sim final : ssn_sim {
         *us = (double)it.rows * it.ld * sizeof(T) / per_us;
         if ((size_t)it.cols * sizeof(T) <= 48 * 1024) *blocks = it.rows <= 4096 ? (it.rows + 3) / 4 : (it.rows + 15) / 16;
         break;
-      case IT_PES: *us = 2.0 * it.rows * it.ld * sizeof(T) / per_us; *blocks = ((it.cols + 1023) / 1024) * ((it.rows + ssn::PES_ROWS - 1) / ssn::PES_ROWS); break;
-      case IT_VOJA: *us = 0.2 * it.rows * it.ld * sizeof(T) / per_us; break;
+      case IT_PES: *us = cost_pes * it.rows * it.ld * sizeof(T) / per_us; *blocks = ((it.cols + 1023) / 1024) * ((it.rows + ssn::PES_ROWS - 1) / ssn::PES_ROWS); break;
+      case IT_VOJA: *us = cost_voja * it.rows * it.ld * sizeof(T) / per_us; break;
       case IT_SPMV: *us = 0.1 * (double)it.cols * it.ld * sizeof(T) / per_us; break;
       case IT_NEURONS: *us = (double)it.n * 5.0 * sizeof(T) / per_us; break;
       case IT_MATVEC_NEURONS: *us = (double)it.rows * it.ld * sizeof(T) / per_us; *blocks = (it.rows + 15) / 16; break;
