@@ -168,11 +168,36 @@ def random_network(seed):
             if rng.rand() < 0.5:
                 post, d_post = targets[rng.randint(0, len(targets))]
                 nengo.Connection(cc.output, post, transform=rng.uniform(-1.0, 1.0, size=(d_post, dc)) / np.sqrt(dc), synapse=0.01)
+        # slices on both ends, a neuron-to-neuron weight matrix, a Voja rule on a decoded connection into an ensemble
+        if rng.rand() < 0.5 and len(ens) >= 2:
+            (ea_, da), (eb_, db) = ens[0], ens[-1]
+            k = min(da, db)
+            lo_a, lo_b = int(rng.randint(0, da - k + 1)), int(rng.randint(0, db - k + 1))
+            pre = ea_[lo_a:lo_a + k] if k > 1 else ea_[lo_a]
+            post = eb_[lo_b:lo_b + k] if k > 1 else eb_[lo_b]
+            nengo.Connection(pre, post, synapse=0.01, transform=float(rng.uniform(0.3, 1.0)))
+        if rng.rand() < 0.35 and len(ens) >= 2:
+            (ea_, da), (eb_, db) = ens[rng.randint(0, len(ens))], ens[rng.randint(0, len(ens))]
+            if ea_ is not eb_:
+                na, nb = min(ea_.n_neurons, 64), min(eb_.n_neurons, 48)
+                nengo.Connection(ea_.neurons[:na], eb_.neurons[:nb], synapse=0.005,
+                                 transform=rng.uniform(-1e-3, 1e-3, size=(nb, na)))
+        if rng.rand() < 0.35:
+            post, d_post = ens[rng.randint(0, len(ens))]
+            if isinstance(post.neuron_type, nengo.LIF):
+                # (the builder takes Voja on a plain Node -> Ensemble connection, as the reference's memory has it: associativememory.py:31)
+                wv, phv = rng.uniform(2.0, 9.0, size=d_post), rng.uniform(0, 6.28, size=d_post)
+                vsrc = nengo.Node(lambda t, w=wv, ph=phv: 0.6 * np.sin(w * t + ph))
+                vc = nengo.Connection(vsrc, post, synapse=None,
+                                      learning_rule_type=nengo.Voja(learning_rate=float(rng.choice([1e-3, 5e-3])), post_synapse=None))
+                if rng.rand() < 0.5:
+                    lsig = nengo.Node(lambda t: -1.0 if (t % 0.05) < 0.02 else 0.0)
+                    nengo.Connection(lsig, vc.learning_rule, synapse=None)
         # read-outs
         for e, d in ens:
             r = rng.rand()
             if r < 0.5:
-                probes.append(nengo.Probe(e, synapse=[None, 0.01, 0.03][rng.randint(0, 3)]))
+                probes.append(nengo.Probe(e, synapse=[None, 0.01, 0.03][rng.randint(0, 3)], sample_every=[None, None, 0.003][rng.randint(0, 3)]))
             if rng.rand() < 0.4:
                 probes.append(nengo.Probe(e.neurons[:min(7, e.n_neurons)]))
             if rng.rand() < 0.4:
