@@ -81,6 +81,12 @@ def random_network(seed):
             ph = rng.uniform(0, 6.28, size=d)
             amp = rng.uniform(0.3, 0.9)
             sources.append((nengo.Node(lambda t, w=w, ph=ph, amp=amp: amp * np.sin(w * t + ph)), d))
+        if rng.rand() < 0.4:                          # a constant node, and a piecewise-constant one (few distinct table rows)
+            dcn = int(rng.choice([1, 3, 7]))
+            sources.append((nengo.Node(rng.uniform(-0.6, 0.6, size=dcn)), dcn))
+        if rng.rand() < 0.4:
+            levels = rng.uniform(-0.8, 0.8, size=(5, 2))
+            sources.append((nengo.Node(lambda t, L=levels: L[int(t * 40) % 5]), 2))
         objs = list(sources)
         n_ens = rng.randint(2, 5)
         ens = []
@@ -88,7 +94,14 @@ def random_network(seed):
             d = int(rng.choice([1, 2, 3, 4, 9, 17, 20]))
             n = int(rng.choice([30, 64, 100, 257, 300, 700, 1100]))
             nt = [nengo.LIF(), nengo.LIF(), nengo.LIF(tau_rc=0.03, tau_ref=0.001), nengo.LIFRate(), nengo.RectifiedLinear()][rng.randint(0, 5)]
-            e = nengo.Ensemble(n, d, neuron_type=nt, radius=float(rng.choice([1.0, 1.5])))
+            kw = {}
+            if rng.rand() < 0.3:
+                kw["intercepts"] = nengo.Uniform(-0.5, 0.9)
+                kw["max_rates"] = nengo.Uniform(100, 300)
+            if rng.rand() < 0.2:
+                enc = np.random.RandomState(seed * 131 + k).randn(n, d)
+                kw["encoders"] = enc / np.linalg.norm(enc, axis=1, keepdims=True)
+            e = nengo.Ensemble(n, d, neuron_type=nt, radius=float(rng.choice([1.0, 1.5])), **kw)
             ens.append((e, d))
             objs.append((e, d))
         if rng.rand() < 0.5:
