@@ -65,8 +65,10 @@ def small_pathint(ssp_dim=7, n=64, T=2.0, seed=1, limit=0.5, **kw):
     return H.make_pathint_model(space, path, vels, n, **kw)
 
 
-def random_network(seed):
-    """Nodes, ensembles of every neuron type, an ensemble array, pass-through nodes; decoded connections with functions and
+def random_network(seed, big=False):
+    """(``big``: populations of 1500 - 9000 neurons, arrays of up to 20 x 2600, 64 - 128-point convolutions - the sizes at which the
+    device leaves the glue micro-operators for its big kernels.)
+    Nodes, ensembles of every neuron type, an ensemble array, pass-through nodes; decoded connections with functions and
     transforms, slices, neuron-to-node read-outs, recurrent and feedback connections through synapses, direct (synapse=None)
     connections only forwards in declaration order (no algebraic loops), an optional PES rule; probes with and without
     synapses on everything."""
@@ -91,8 +93,8 @@ def random_network(seed):
         n_ens = rng.randint(2, 5)
         ens = []
         for k in range(n_ens):
-            d = int(rng.choice([1, 2, 3, 4, 9, 17, 20]))
-            n = int(rng.choice([30, 64, 100, 257, 300, 700, 1100]))
+            d = int(rng.choice([1, 2, 3, 4, 9, 17, 20])) if not big else int(rng.choice([3, 20, 33, 64]))
+            n = int(rng.choice([30, 64, 100, 257, 300, 700, 1100])) if not big else int(rng.choice([1500, 4500, 9000]))
             nt = [nengo.LIF(), nengo.LIF(), nengo.LIF(tau_rc=0.03, tau_ref=0.001), nengo.LIFRate(), nengo.RectifiedLinear()][rng.randint(0, 5)]
             kw = {}
             if rng.rand() < 0.3:
@@ -106,7 +108,9 @@ def random_network(seed):
             objs.append((e, d))
         if rng.rand() < 0.5:
             K, dk = int(rng.choice([3, 8, 21])), int(rng.choice([1, 2]))
-            ea = nengo.EnsembleArray(int(rng.choice([40, 90])), K, ens_dimensions=dk)
+            if big:
+                K, dk = int(rng.choice([6, 20])), int(rng.choice([1, 2, 3]))
+            ea = nengo.EnsembleArray(int(rng.choice([40, 90])) if not big else int(rng.choice([1200, 2600])), K, ens_dimensions=dk)
             objs.append((ea.input, K * dk))
             arr_out = (ea.output, K * dk)
         else:
@@ -171,7 +175,7 @@ def random_network(seed):
         # a circular convolution of two of the producers (reference networks/binding.py:297-317; the transforms are FFTs on the device)
         if rng.rand() < 0.45:
             from sspslam_amd.networks import CircularConvolution
-            dc = int(rng.choice([9, 16, 25, 36]))
+            dc = int(rng.choice([9, 16, 25, 36])) if not big else int(rng.choice([64, 97, 128]))
             cc = CircularConvolution(int(rng.choice([20, 50])), dc, invert_b=bool(rng.rand() < 0.5))
             for inp in (cc.input_a, cc.input_b):
                 pre, d_pre = producers[rng.randint(0, len(producers))]

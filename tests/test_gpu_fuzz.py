@@ -99,3 +99,21 @@ def test_random_network_under_the_opt_in_plans(Simulator, seed):
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108])
+def test_big_random_network_f64_matches_oracle(Simulator, seed):
+    """The same generator at the sizes where the device leaves the glue micro-operators for its big kernels: dense products as
+    grids of row blocks (fused with the neuron update from 4097 rows on), segmented spike lists and spike-sparse decodes,
+    ensemble arrays with several workgroups per ensemble, transforms of 64 - 128 points."""
+    net, probes = random_network(seed, big=True)
+    model = build(net, n_eval_points=800)
+    ref = OracleSimulator(model)
+    steps = 80
+    ref.run_steps(steps)
+    for kw in (dict(), dict(steps_per_graph=1)):
+        with Simulator(None, model=model, dtype="f64", **kw) as sim:
+            sim.run_steps(steps)
+            for p in probes:
+                q = [i for i, mp in enumerate(model.probes) if mp["probe"] is p][0]
+                np.testing.assert_allclose(sim.data[p], ref.probe_data(q), atol=1e-9, rtol=0, err_msg=f"seed {seed} probe {q} {kw}")
