@@ -117,3 +117,38 @@ def test_big_random_network_f64_matches_oracle(Simulator, seed):
             for p in probes:
                 q = [i for i, mp in enumerate(model.probes) if mp["probe"] is p][0]
                 np.testing.assert_allclose(sim.data[p], ref.probe_data(q), atol=1e-9, rtol=0, err_msg=f"seed {seed} probe {q} {kw}")
+
+
+@pytest.mark.parametrize("seed", SEEDS[1::4])
+def test_random_network_in_pieces_over_block_boundaries_and_after_a_reset(Simulator, seed):
+    """Runs cut into uneven pieces that straddle the time-batched blocks (64 timesteps here: carry rows of the batched filters,
+    table rows and probe slots across block boundaries, a graph replay cut short), a reset, and the same run again."""
+    net, probes = random_network(seed)
+    model = build(net)
+    ref = OracleSimulator(model)
+    steps = 37 + 100 + 64 + 1
+    ref.run_steps(steps)
+    with Simulator(None, model=model, dtype="f64", block_steps=64) as sim:
+        for rep in range(2):
+            for piece in (37, 100, 64, 1):
+                sim.run_steps(piece)
+            for p in probes:
+                q = [i for i, mp in enumerate(model.probes) if mp["probe"] is p][0]
+                np.testing.assert_allclose(sim.data[p], ref.probe_data(q), atol=1e-9, rtol=0, err_msg=f"seed {seed} probe {q} run {rep}")
+            sim.reset()
+
+
+@pytest.mark.parametrize("seed", SEEDS[2::8])
+def test_random_network_through_the_pipelined_run(Simulator, seed):
+    """`sim.run(T)` as a reference script calls it - input nodes tabulated chunk by chunk on a helper thread, tables staged and
+    committed between chunks, probe data read back by a collector thread - on networks with several input nodes of different
+    widths, constant and piecewise-constant ones among them."""
+    net, probes = random_network(seed)
+    model = build(net)
+    ref = OracleSimulator(model)
+    ref.run_steps(1500)
+    with Simulator(None, model=model, dtype="f64") as sim:
+        sim.run(1.5)
+        for p in probes:
+            q = [i for i, mp in enumerate(model.probes) if mp["probe"] is p][0]
+            np.testing.assert_allclose(sim.data[p], ref.probe_data(q), atol=1e-9, rtol=0, err_msg=f"seed {seed} probe {q}")
