@@ -65,7 +65,7 @@ def small_pathint(ssp_dim=7, n=64, T=2.0, seed=1, limit=0.5, **kw):
     return H.make_pathint_model(space, path, vels, n, **kw)
 
 
-def random_network(seed, big=False):
+def random_network(seed, big=False, shardable=False):
     """(``big``: populations of 1500 - 9000 neurons, arrays of up to 20 x 2600, 64 - 128-point convolutions - the sizes at which the
     device leaves the glue micro-operators for its big kernels.)
     Nodes, ensembles of every neuron type, an ensemble array, pass-through nodes; decoded connections with functions and
@@ -195,7 +195,7 @@ def random_network(seed, big=False):
             nengo.Connection(pre, post, synapse=0.01, transform=float(rng.uniform(0.3, 1.0)))
         if rng.rand() < 0.35 and len(ens) >= 2:
             (ea_, da), (eb_, db) = ens[rng.randint(0, len(ens))], ens[rng.randint(0, len(ens))]
-            if ea_ is not eb_:
+            if ea_ is not eb_ and not shardable:       # (neuron slices and neuron probes are refused for neuron-sharded builds)
                 na, nb = min(ea_.n_neurons, 64), min(eb_.n_neurons, 48)
                 nengo.Connection(ea_.neurons[:na], eb_.neurons[:nb], synapse=0.005,
                                  transform=rng.uniform(-1e-3, 1e-3, size=(nb, na)))
@@ -215,7 +215,7 @@ def random_network(seed, big=False):
             r = rng.rand()
             if r < 0.5:
                 probes.append(nengo.Probe(e, synapse=[None, 0.01, 0.03][rng.randint(0, 3)], sample_every=[None, None, 0.003][rng.randint(0, 3)]))
-            if rng.rand() < 0.4:
+            if rng.rand() < 0.4 and not shardable:
                 probes.append(nengo.Probe(e.neurons[:min(7, e.n_neurons)]))
             if rng.rand() < 0.4:
                 o = nengo.Node(size_in=1)
