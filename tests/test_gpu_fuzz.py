@@ -152,3 +152,29 @@ def test_random_network_through_the_pipelined_run(Simulator, seed):
         for p in probes:
             q = [i for i, mp in enumerate(model.probes) if mp["probe"] is p][0]
             np.testing.assert_allclose(sim.data[p], ref.probe_data(q), atol=1e-9, rtol=0, err_msg=f"seed {seed} probe {q}")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 5, 8, 9, 14, 21, 23, 36, 44, 52])
+def test_random_network_as_a_neuron_sharded_model_on_one_rank(Simulator, seed):
+    """The phased plans on graphs nobody drew by hand: `build(neuron_shard=(0, 1))` gives a model with exchange ranges and two
+    phases per timestep; one rank (its sums are complete) runs it through ShardedSLAM - whole cycles of the plan pipelined over
+    the exchange (16 timesteps as 17 segments, phase 3), then single timesteps (phases 0 / 2 / 1) - stream-ordered and in the
+    host loop, and with the cycles switched off: every probe equal to the unsharded oracle run."""
+    import types
+    from sspslam_amd.sharding import ShardedSLAM
+    net, probes = random_network(seed, shardable=True)
+    full = build(net)
+    ref = OracleSimulator(full)
+    steps = 16 * 4 + 5
+    ref.run_steps(steps)
+    sm = types.SimpleNamespace(model=net, probe=probes[0], slam=None)
+    for host_loop, cycles in ((False, True), (True, True), (False, False)):
+        r = ShardedSLAM(sm, 0, 1, dtype="f64", replicate=[], host_loop=host_loop, cycles=cycles)
+        assert r._cycle_steps() == (16 if cycles else 0)
+        r.prepare(steps)
+        r.run_steps(40)
+        r.run_steps(steps - 40)
+        for p in probes:
+            q = [i for i, mp in enumerate(full.probes) if mp["probe"] is p][0]
+            np.testing.assert_allclose(r.sim.data[p], ref.probe_data(q), atol=1e-9, rtol=0, err_msg=f"seed {seed} probe {q} host_loop {host_loop} cycles {cycles}")
+        r.close()
