@@ -422,7 +422,8 @@ class Simulator:
                 pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_FIRST, steps))
                 self._tr("tabulate first", t_tab, pipelined[1])
                 self._tab_rate = (time.perf_counter() - t_tab) / max(1, pipelined[1])      # seconds per timestep, host
-                self._dev_rate = None                                                        # ... device: known after the first chunk
+                # (... device: known after the first chunk of this simulator's first run; a later run starts from the last one's rate,
+                #  so that plain closures do not get a second chunk four times the first to tabulate under it)
                 if collect:
                     # the samples of chunk k are fetched (float64, straight into one array per probe) on a helper thread
                     # while the device steps chunk k + 1: the library downloads on its own stream
@@ -441,6 +442,8 @@ class Simulator:
             # a failed run must not leave the helper threads or the bulk arrays of the pipelined read-back behind: the
             # tabulation thread would go on calling the user's node closures (and this object) after the caller has seen the
             # exception, and the next run_steps would collect into stale arrays
+            if self._tab_go is not None:
+                self._tab_go.set()               # (a helper still waiting for its start signal)
             for th in (self._tab_worker, self._collector):
                 if th is not None:
                     th.join()
@@ -454,6 +457,7 @@ class Simulator:
 
     _collector = None
     _tab_worker = None
+    _tab_go = None
     _tab_rate = None
     _dev_rate = None
 
@@ -476,6 +480,13 @@ class Simulator:
             n = remaining - tail
         elif remaining <= n + mid + tail:
             n = remaining - mid - tail if remaining - mid - tail >= self.PIPELINE_MIN else remaining - tail
+        elif remaining <= 2 * n + mid + tail:
+            # two long chunks left, the second of them short: halve what is left between them instead - a 544-timestep chunk in
+            # front of the 2048 of PIPELINE_MID left that one's tabulation (plain closures: 4.6 ms) 1.7 ms of device time to hide under
+            half = (remaining - mid - tail + 1) // 2
+            if half >= align:
+                half += -half % align
+            n = max(self.PIPELINE_MIN, min(n, half))
         return max(1, min(n, remaining))
 
     def _step_loop(self, steps, profile, pipelined, buf_probes):
@@ -504,7 +515,9 @@ class Simulator:
                     import threading
                     box = {}
                     n_next = self._next_chunk_len(chunk, steps - done - chunk)
-                    def tab(box=box, nxt=nxt, n_next=n_next):
+                    go = self._tab_go = threading.Event()
+                    def tab(box=box, nxt=nxt, n_next=n_next, go=go):
+                        go.wait()            # (see below: the device run of this chunk is enqueued first)
                         try:
                             t0 = time.perf_counter()
                             box.update(r=self._tabulate_chunk(nxt, n_next))
@@ -517,6 +530,11 @@ class Simulator:
                 r = (self.n_steps + 1) % p["every"]
                 chunk = min(chunk, p["every"] - r if r else p["every"])
             t_dev = time.perf_counter()
+            if worker is not None:
+                # A helper that starts calling plain Python closures keeps the interpreter lock for a whole switch interval (5 ms):
+                # started in front of the call below it delayed the launch of this chunk by 4 ms (timeline of round 4).  It waits on
+                # an event instead, set right in front of the foreign call - which gives the lock up by itself.
+                go.set()
             self._check(self._lib.ssn_run_steps(self._h, chunk, int(profile)))
             self._tr("run", t_dev, chunk)
             if chunk >= self.PIPELINE_MIN:
