@@ -422,8 +422,7 @@ class Simulator:
                 pipelined = self._tabulate_chunk(self.n_steps, min(self.PIPELINE_FIRST, steps))
                 self._tr("tabulate first", t_tab, pipelined[1])
                 self._tab_rate = (time.perf_counter() - t_tab) / max(1, pipelined[1])      # seconds per timestep, host
-                # (... device: known after the first chunk of this simulator's first run; a later run starts from the last one's rate,
-                #  so that plain closures do not get a second chunk four times the first to tabulate under it)
+                self._dev_rate = None                                                        # ... device: known after the first chunk
                 if collect:
                     # the samples of chunk k are fetched (float64, straight into one array per probe) on a helper thread
                     # while the device steps chunk k + 1: the library downloads on its own stream
@@ -458,6 +457,7 @@ class Simulator:
     _collector = None
     _tab_worker = None
     _tab_go = None
+    _tab_gate_off = os.environ.get("SSN_TAB_GATE", "1") == "0"      # A/B knob: the helper starts in front of the device call again
     _tab_rate = None
     _dev_rate = None
 
@@ -480,13 +480,6 @@ class Simulator:
             n = remaining - tail
         elif remaining <= n + mid + tail:
             n = remaining - mid - tail if remaining - mid - tail >= self.PIPELINE_MIN else remaining - tail
-        elif remaining <= 2 * n + mid + tail:
-            # two long chunks left, the second of them short: halve what is left between them instead - a 544-timestep chunk in
-            # front of the 2048 of PIPELINE_MID left that one's tabulation (plain closures: 4.6 ms) 1.7 ms of device time to hide under
-            half = (remaining - mid - tail + 1) // 2
-            if half >= align:
-                half += -half % align
-            n = max(self.PIPELINE_MIN, min(n, half))
         return max(1, min(n, remaining))
 
     def _step_loop(self, steps, profile, pipelined, buf_probes):
@@ -525,12 +518,14 @@ class Simulator:
                         except BaseException as e:       # noqa: BLE001 - re-raised on the caller's thread
                             box["e"] = e
                     worker = self._tab_worker = threading.Thread(target=tab)
+                    if self._tab_gate_off:
+                        go.set()
                     worker.start()
             for _, p in buf_probes:          # stop before the next timestep whose sample is due (taken at the top of the loop)
                 r = (self.n_steps + 1) % p["every"]
                 chunk = min(chunk, p["every"] - r if r else p["every"])
             t_dev = time.perf_counter()
-            if worker is not None:
+            if worker is not None and not self._tab_gate_off:
                 # A helper that starts calling plain Python closures keeps the interpreter lock for a whole switch interval (5 ms):
                 # started in front of the call below it delayed the launch of this chunk by 4 ms (timeline of round 4).  It waits on
                 # an event instead, set right in front of the foreign call - which gives the lock up by itself.

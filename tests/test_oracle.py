@@ -299,7 +299,3 @@ def test_chunk_schedule_of_a_pipelined_run():
                 assert sorted(chunks[1:-2])[len(chunks[1:-2]) // 2] <= Simulator.PIPELINE_FIRST
             if dev and tab and tab < 0.2 * dev:
                 assert len(chunks) <= 5 + steps // Simulator.PIPELINE_MAX
-            # no short chunk in front of the mid one (its tabulation would have nothing to hide under): whatever precedes the last two
-            # chunks of a long run is at least half of its own predecessor
-            if len(chunks) >= 5 and dev and tab and tab < dev:
-                assert chunks[-3] >= min(chunks[-4] // 2, Simulator.PIPELINE_MID // 2), chunks
