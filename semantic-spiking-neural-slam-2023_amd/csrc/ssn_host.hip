@@ -1894,6 +1894,12 @@ struct Sim final : ssn_sim {
       }
     }
     all.insert(all.end(), extra.begin(), extra.end());
+    if (getenv("SSN_DEBUG_PLAN")) {          // what the balancer believes the rounds cost (us): bandwidth-bound load | longest single-workgroup body
+      fprintf(stderr, "[ssn] balanced rounds (load | latency, us):");
+      double total = 0.0;
+      for (int r = 0; r < nr; ++r) { fprintf(stderr, " %.0f|%.0f", load[(size_t)r], lat[(size_t)r]); total += std::max(load[(size_t)r], lat[(size_t)r]); }
+      fprintf(stderr, "\n[ssn] sum of max(load, latency) over %d rounds: %.0f us\n", nr, total);
+    }
   }
 
   // Round plan, recurrent ensemble arrays (the SLAM network's oscillators, reference pathintegration.py:180-182: ensemble k ->
