@@ -207,7 +207,7 @@ struct Sim final : ssn_sim {
   // timestep k sits between segments k and k + 1 (ssn_run_phase / ssn_phase_async with phase 3 = "the next segment")
   std::vector<std::vector<Launch>> cycle_segs;
   int cycle_steps = 0, next_seg = 0;
-  int n_fused_populations = 0, n_serial_chains = 0;      // (counters of the round plan)
+  int n_fused_populations = 0, n_serial_chains = 0, n_folded_inputs = 0;      // (counters of the round plan)
   std::vector<hipGraph_t> cycle_graph;
   std::vector<hipGraphExec_t> cycle_exec;
   std::vector<Launch> phase2_list;            // neuron-sharded models: the updates of timestep s and timestep s + 1 up to its exchange,
@@ -2120,6 +2120,61 @@ struct Sim final : ssn_sim {
         if (getenv("SSN_DEBUG_PLAN")) fprintf(stderr, "[ssn] encoder product %d x %d and the update of its %d neurons fused (items %d, %zu)\n", N.rows, N.cols, N.n, jm, jn);
       }
     }
+    // Round 4: the input of an ensemble array assembled by the array itself.  The product ensembles of a circular convolution read
+    // x = alpha_1 A + alpha_2 B of the two transforms' outputs (reference binding.py:297-317); as a lincomb operator of its own that
+    // sum is one more dependent round on the network's long loop, between the transforms and the ensembles.  EnsArgs carries up to
+    // four such terms already (the per-timestep PathIntegration kernel's input assembly): where a lincomb that SETS exactly the
+    // array's input range from at most four terms is the range's only writer, the array its only reader, the range starts at zero and
+    // nothing between the two writes a term's source, the terms move into the array and the operator leaves the plan.
+    // Measured at SLAM config 3 (four lincombs fold, 217 -> 204 rounds per 64 timesteps): 101.5 us per timestep against 100.3 without,
+    // twice on one box - like the transforms in serial chains, fewer rounds on the loop and no gain; opt-in (SSN_FOLD_ENS_INPUT=1).
+    if (getenv("SSN_FOLD_ENS_INPUT") && atoi(getenv("SSN_FOLD_ENS_INPUT")) == 1) {
+      for (size_t ei = 0; ei < items.size(); ++ei) {
+        Item& E = items[ei];
+        if (E.type != IT_ENS || E.ens.n_rec != 0 || E.ens.xrows || E.ens.defer || ens_round_kind(E.ens) < 0) continue;
+        const int64_t x0 = E.ens.x_off, xn = (int64_t)E.ens.K * E.ens.din;
+        // program-order positions: (item index, program, op index)
+        int pj = 0, lp = -1, lo = -1, li = -1;
+        bool ok = true;
+        std::vector<std::pair<int, std::vector<Rng>>> seq;           // (item index, accesses) of every other operator
+        for (size_t i = 0; i < items.size(); ++i) {
+          if (items[i].type == IT_PROGRAM) {
+            const int pr = item_prog[(size_t)pj++];
+            for (size_t q = 0; q < programs[(size_t)pr].size(); ++q) {
+              const MOp& op = programs[(size_t)pr][q];
+              if (op.kind == ssn::M_LINCOMB && op.dst == x0 && op.len == xn && lp < 0 && i < ei) { lp = pr; lo = (int)q; li = (int)i; continue; }
+              seq.push_back({(int)i, {}});
+              micro_access(seq.back().second, op, false);
+            }
+          } else if (i != ei) {
+            seq.push_back({(int)i, {}});
+            item_access(seq.back().second, items[i]);
+          }
+        }
+        if (lp < 0) continue;
+        const MOp L = programs[(size_t)lp][(size_t)lo];
+        auto lt = lin_terms.find(L.p0);
+        if (lt == lin_terms.end() || lt->second.empty() || lt->second.size() > 4 || L.a != T(0) || L.b != T(1) || L.c != T(0)) continue;
+        for (int64_t q = 0; q < xn && ok; ++q) if (sig_init[(size_t)(x0 + q)] != 0.0) ok = false;
+        for (const auto& e : seq) {
+          if (!ok) break;
+          for (const Rng& r : e.second) {
+            if (r.space != (const void*)sig) continue;
+            if (r.lo < x0 + xn && x0 < r.hi) ok = false;                                  // someone else touches the input range
+            if (r.w && e.first >= li && e.first <= (int)ei)
+              for (const auto& t : lt->second) if (r.lo < t.src + xn && t.src < r.hi) ok = false;      // a source changes between the two
+          }
+        }
+        if (!ok) continue;
+        E.ens.n_rec = (int)lt->second.size();
+        for (int j = 0; j < E.ens.n_rec; ++j) {
+          E.ens.rec_dst[j] = x0; E.ens.rec_len[j] = xn; E.ens.rec_src[j] = lt->second[(size_t)j].src; E.ens.rec_alpha[j] = lt->second[(size_t)j].alpha;
+        }
+        programs[(size_t)lp].erase(programs[(size_t)lp].begin() + lo);
+        n_folded_inputs += 1;
+        if (getenv("SSN_DEBUG_PLAN")) fprintf(stderr, "[ssn] input lincomb of %d terms folded into ensemble array %zu (K %d)\n", E.ens.n_rec, ei, E.ens.K);
+      }
+    }
     // Element-wise micro-operators are cut at every range endpoint of the other operators.  The builder merges
     // neighbouring resets / hand-offs into one long operator (one fill over all accumulators of a network); as a unit
     // it would inherit the hazards of every signal it spans - the reset of an accumulator that is read in the last
@@ -2946,6 +3001,7 @@ struct Sim final : ssn_sim {
       case IT_ENS:
         if (it.ens.direct) acc_index_list(a, (const void*)it.ens.didx, true);
         acc_sig(a, it.ens.x_off, (int64_t)it.ens.K * it.ens.din, false);
+        for (int j = 0; j < it.ens.n_rec; ++j) acc_sig(a, it.ens.rec_src[j], it.ens.rec_len[j], false);      // (folded input terms)
         acc_ptr(a, it.ens.partials, true); acc_ptr(a, it.ens.V, true); acc_ptr(a, it.ens.R, true);
         acc_ptr(a, it.ens.enc, false); acc_ptr(a, it.ens.bias, false); acc_ptr(a, it.ens.dec, false);
         break;
