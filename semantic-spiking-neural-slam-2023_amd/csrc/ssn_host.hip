@@ -2656,7 +2656,7 @@ struct Sim final : ssn_sim {
             case IT_VOJA: {
               ssn::VojaArgs<T> a{it.Wm, it.src, it.aux0, it.aux1, it.aux2, it.rows, it.cols, it.ld, it.scalar};
               if (ao < 0) ao = (long long)put(&a, sizeof a);
-              entry(ssn::RK_VOJA, (it.rows + 3) / 4, 1, 64, 0, (size_t)ao);
+              entry(ssn::RK_VOJA, (it.rows + 4 * ssn::VOJA_ROWS_PER_WAVE - 1) / (4 * ssn::VOJA_ROWS_PER_WAVE), 1, 64, 0, (size_t)ao);
               continue;
             }
             default: break;

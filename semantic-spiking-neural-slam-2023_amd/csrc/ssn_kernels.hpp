@@ -1722,26 +1722,31 @@ hipError_t launch_neurons(hipStream_t s, const NeuronsBatch<T>& b, int count) {
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void pes_body(const PesArgs<T>& a, const int bx, const int by) {
+  // The PES_ROWS row factors of this workgroup come with ONE load per wave (lane l: row r0 + l); the rows whose factor is not zero -
+  // 1.3 % of the memory population's filtered activities - are walked by ballot.  (Eight factors per workgroup as uniform loads
+  // were 1 269 workgroups per SLAM timestep, most of which waited a memory trip for eight zeros: 12 ms of workgroup-slot time per
+  // timestep, tools/round_stamps.py.)
   const int r0 = by * PES_ROWS;
-  T e[PES_ROWS];
-#pragma unroll
-  for (int q = 0; q < PES_ROWS; ++q) e[q] = r0 + q < a.rows ? a.kappa * a.err[r0 + q] : T(0);
+  const int lane = threadIdx.x & 63;
+  const T el = (lane < PES_ROWS && r0 + lane < a.rows) ? a.kappa * a.err[r0 + lane] : T(0);
   if (a.lp_dst) {
     // folded filter of the row factors (planned only where one column tile covers the matrix: this workgroup is the only reader
-    // of its eight factors): every wave has its copies before thread q advances factor q
+    // of its factors): every wave has its copies before thread q advances factor q
     __syncthreads();
     const int q = threadIdx.x;
     if (bx == 0 && q < PES_ROWS && r0 + q < a.rows) a.lp_dst[r0 + q] = a.lp_a * a.lp_dst[r0 + q] + a.lp_b * a.lp_src[r0 + q];
   }
+  unsigned long long m = __ballot(el != T(0));
   const int c0 = bx * 1024;
-#pragma unroll
-  for (int q = 0; q < PES_ROWS; ++q) {
-    if (e[q] == T(0)) continue;
+  while (m) {
+    const int q = __builtin_ctzll(m);
+    m &= m - 1ull;
+    const T e = __shfl(el, q, 64);
     T* wr = a.Wm + (size_t)(r0 + q) * a.ld;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = c0 + j * 256 + threadIdx.x;
-      if (c < a.cols) wr[c] += e[q] * a.act[c];
+      if (c < a.cols) wr[c] += e * a.act[c];
     }
   }
 }
@@ -1764,15 +1769,26 @@ hipError_t launch_pes(hipStream_t s, T* Wm, const T* err, const T* act, int rows
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void voja_body(const VojaArgs<T>& v, const int bx) {
+  // A wave owns VOJA_ROWS_PER_WAVE consecutive rows: their activities come with ONE load (lane l: row i0 + l), the rows that moved
+  // - a percent of them in the reference's memory - are walked by ballot.  (One row per wave was 2 538 workgroups per SLAM
+  // timestep that each waited a memory trip for one zero and left: 12 ms of workgroup-slot time per timestep, tools/round_stamps.py.)
   const int lane = threadIdx.x & 63;
-  const int i = bx * 4 + (threadIdx.x >> 6);
-  if (i >= v.rows) return;
-  const T a = v.spk[i];
-  if (a == T(0)) return;
+  const int i0 = (bx * 4 + (int)(threadIdx.x >> 6)) * VOJA_ROWS_PER_WAVE;
+  if (i0 >= v.rows) return;
+  const int il = i0 + lane;
+  const T al = (lane < VOJA_ROWS_PER_WAVE && il < v.rows) ? v.spk[il] : T(0);
+  unsigned long long m = __ballot(al != T(0));
+  if (m == 0ull) return;
   const T g = v.lr_dt * (T(1) + v.learn[0]);
-  const T sa = v.scale[i] * a;
-  T* er = v.E + (size_t)i * v.ld;
-  for (int c = lane; c < v.cols; c += 64) er[c] += g * (sa * v.key[c] - a * er[c]);
+  while (m) {
+    const int r = __builtin_ctzll(m);
+    m &= m - 1ull;
+    const int i = i0 + r;
+    const T a = __shfl(al, r, 64);
+    const T sa = v.scale[i] * a;
+    T* er = v.E + (size_t)i * v.ld;
+    for (int c = lane; c < v.cols; c += 64) er[c] += g * (sa * v.key[c] - a * er[c]);
+  }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_voja(T* __restrict__ E, const T* __restrict__ spk, const T* __restrict__ key,
@@ -1784,7 +1800,7 @@ __global__ __launch_bounds__(256) void k_voja(T* __restrict__ E, const T* __rest
 template <typename T>
 hipError_t launch_voja(hipStream_t s, T* E, const T* spk, const T* key, const T* learn, const T* scale,
                        int rows, int cols, int ld, T lr_dt) {
-  hipLaunchKernelGGL((k_voja<T>), dim3((rows + 3) / 4), dim3(256), 0, s, E, spk, key, learn, scale, rows, cols, ld, lr_dt);
+  hipLaunchKernelGGL((k_voja<T>), dim3((rows + 4 * VOJA_ROWS_PER_WAVE - 1) / (4 * VOJA_ROWS_PER_WAVE)), dim3(256), 0, s, E, spk, key, learn, scale, rows, cols, ld, lr_dt);
   return hipGetLastError();
 }
 

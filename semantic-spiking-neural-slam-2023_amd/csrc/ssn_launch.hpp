@@ -245,7 +245,7 @@ struct BatchOp {
 // names the operator body that runs them.  The arguments of every body live in device memory (they do not change
 // from timestep to timestep; the step counter is read from StepCtx).
 // ---------------------------------------------------------------------------------------------
-constexpr int PES_ROWS = 8;      // rows per workgroup of the PES update (pes_body)
+constexpr int PES_ROWS = 32;     // rows per workgroup of the PES update (pes_body: their factors are one load per wave; at most 64)
 template <typename T> struct PesArgs { T* Wm; const T* err; const T* act; int rows, cols, ld; T kappa;
                                        // round plan (round 4): the Lowpass that filters the row factors (the memory population's activities, reference
                                        // associativememory.py:38-43: PES(pre_synapse)) folded into the update - row r's factor is advanced by the
@@ -276,6 +276,7 @@ struct GlueBlock { int op; int chunk; };        // micro-operator index (into Ro
 // needs no barrier and no launch of its own when the same thread handles the same index in program order.
 struct RoundEntry { int kind; int first; int gx; int gy; const void* args; int lo; int cnt; };   // blocks [lo, lo + cnt) of the gx x gy grid
 constexpr int MAX_ROUND_ENTRIES = 96;
+constexpr int VOJA_ROWS_PER_WAVE = 8;         // rows of the encoder matrix one wave of the Voja body looks at (32 per workgroup)
 constexpr int SOLO_MAX_MEMBERS = 24;         // members of a serial chain (their descriptors are staged in LDS)
 template <typename T>
 struct RoundArgs {
