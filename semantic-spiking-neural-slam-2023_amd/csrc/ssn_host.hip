@@ -1793,7 +1793,7 @@ struct Sim final : ssn_sim {
   const bool no_small_ens = getenv("SSN_SMALL_ENS") && atoi(getenv("SSN_SMALL_ENS")) == 0;      // A/B knob
   // blocks of an ensemble array's grid inside a round
   int ens_round_blocks(const ssn::EnsArgs<T>& a) const {
-    return ens_round_kind(a) == ssn::RK_ENS_SMALL ? (a.K + 15) / 16 : a.K * a.P;
+    return ens_round_kind(a) == ssn::RK_ENS_SMALL ? (a.K + 4 * ssn::ENS_SMALL_PER_WAVE - 1) / (4 * ssn::ENS_SMALL_PER_WAVE) : a.K * a.P;
   }
 
   // Cost model of the round balancer: device time a unit needs when bandwidth-bound (us at ~5 TB/s), the latency of a

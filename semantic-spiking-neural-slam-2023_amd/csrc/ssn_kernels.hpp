@@ -350,7 +350,7 @@ __device__ __forceinline__ void ens_body(const EnsArgs<T>& a, const int bx, unsi
 // workgroup (508 workgroups per timestep instead of 8 128).  LIF fast path (packed state word), dense decoders, n <= 64.
 template <typename T>
 __device__ __forceinline__ void ens_small_body(const EnsArgs<T>& a, const int bx) {
-  constexpr int EPW = 4;
+  constexpr int EPW = ENS_SMALL_PER_WAVE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k0 = (bx * 4 + wave) * EPW;
   const NeuronParams<T> np = a.np;

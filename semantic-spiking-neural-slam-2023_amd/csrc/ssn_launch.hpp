@@ -276,6 +276,7 @@ struct GlueBlock { int op; int chunk; };        // micro-operator index (into Ro
 // needs no barrier and no launch of its own when the same thread handles the same index in program order.
 struct RoundEntry { int kind; int first; int gx; int gy; const void* args; int lo; int cnt; };   // blocks [lo, lo + cnt) of the gx x gy grid
 constexpr int MAX_ROUND_ENTRIES = 96;
+constexpr int ENS_SMALL_PER_WAVE = 4;         // small ensembles one wave of ens_small_body steps (16 per workgroup; 6: no gain - 98.3 vs 97.8 us per SLAM timestep; 8 costs k_round a 73rd VGPR)
 constexpr int VOJA_ROWS_PER_WAVE = 8;         // rows of the encoder matrix one wave of the Voja body looks at (32 per workgroup)
 constexpr int SOLO_MAX_MEMBERS = 24;         // members of a serial chain (their descriptors are staged in LDS)
 template <typename T>
