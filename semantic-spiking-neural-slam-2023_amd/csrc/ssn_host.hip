@@ -1424,7 +1424,8 @@ struct Sim final : ssn_sim {
             int seg = 0;
             if (std::find(seg_spikes.begin(), seg_spikes.end(), o.i[1]) != seg_spikes.end()) {
               const int n_seg = ((int)o.i[3] + 255) / 256;       // segments of 256 neurons, ~32 chunks
-              seg = std::max(1, (n_seg + 63) / 64);
+              const int max_chunks = getenv("SSN_SPMV_MAX_CHUNKS") ? std::max(1, atoi(getenv("SSN_SPMV_MAX_CHUNKS"))) : 64;      // (A/B knob)
+              seg = std::max(1, (n_seg + max_chunks - 1) / max_chunks);
               chunks = (n_seg + seg - 1) / seg;
             }
             T* partial = nullptr;

@@ -68,3 +68,17 @@ for pos in range(first, min(len(ids), first + count)):
               (KINDS[k] if k < len(KINDS) else str(k), int(mk.sum()), (t0[mk].min() - a) / 100.0, (t1[mk].max() - a) / 100.0,
                d.mean(), d.max(), d.sum()))
 print("sum over the %d launches shown: %.1f us" % (count, tot))
+# the whole replay by body kind: workgroup-slot time (blocks x block time) per timestep - what the bodies take of the chip's
+# 256 CUs x 7 workgroups = 1792 slots, whether they stream or wait
+print("\nwhole replay (%d timesteps), per timestep:" % G)
+span = (t1.max() - t0.min()) / 100.0
+print("  wall %.1f us per timestep; slot time available %.1f ms per timestep (1792 slots)" % (span / G, 1792 * span / G / 1e3))
+rows = []
+for k in sorted(set(kind.tolist())):
+    mk = kind == k
+    d = (t1[mk] - t0[mk]) / 100.0
+    rows.append((d.sum() / G / 1e3, KINDS[k] if k < len(KINDS) else str(k), int(mk.sum()) / G, d.mean(), np.median(d), np.percentile(d, 10)))
+tot_ms = sum(r[0] for r in rows)
+for ms, name, nb, mean, med, p10 in sorted(rows, reverse=True):
+    print("  %-15s %7.2f ms slot time (%4.1f %%)  %7.1f blocks  block time mean %6.2f  median %6.2f  10th pct %6.2f us" % (name, ms, 100 * ms / tot_ms, nb, mean, med, p10))
+print("  total %.2f ms" % tot_ms)
