@@ -1803,6 +1803,9 @@ struct Sim final : ssn_sim {
   // round that also streams they take 25 - 30 and ~13 (tools/round_stamps.py) - SSN_LAT_DFT / SSN_LAT_SOLO for A/B runs
   // (fractions of its matrix a learning rule's update is priced at: dense it reads and writes everything, in the reference's memory
   //  1.3 % of the filtered activities are nonzero - SSN_COST_PES / SSN_COST_VOJA for A/B runs)
+  // tallest matrix that runs four rows per workgroup with four vectors of a row in flight per lane (one trip for 1015 columns)
+  // instead of sixteen rows per workgroup with one vector of four rows in flight (four trips)
+  int matvec_r1_max = getenv("SSN_MATVEC_R1_MAX") ? atoi(getenv("SSN_MATVEC_R1_MAX")) : 4096;
   double cost_pes = getenv("SSN_COST_PES") ? atof(getenv("SSN_COST_PES")) : 2.0;
   double cost_voja = getenv("SSN_COST_VOJA") ? atof(getenv("SSN_COST_VOJA")) : 0.2;
   double lat_dft = getenv("SSN_LAT_DFT") ? atof(getenv("SSN_LAT_DFT")) : 9.0;
@@ -1824,7 +1827,7 @@ struct Sim final : ssn_sim {
         break;
       case IT_MATVEC:
         *us = (double)it.rows * it.ld * sizeof(T) / per_us;
-        if ((size_t)it.cols * sizeof(T) <= 48 * 1024) *blocks = it.rows <= 4096 ? (it.rows + 3) / 4 : (it.rows + 15) / 16;
+        if ((size_t)it.cols * sizeof(T) <= 48 * 1024) *blocks = it.rows <= matvec_r1_max ? (it.rows + 3) / 4 : (it.rows + 15) / 16;
         break;
       case IT_PES: *us = cost_pes * it.rows * it.ld * sizeof(T) / per_us; *blocks = ((it.cols + 1023) / 1024) * ((it.rows + ssn::PES_ROWS - 1) / ssn::PES_ROWS); break;
       case IT_VOJA: *us = cost_voja * it.rows * it.ld * sizeof(T) / per_us; break;
@@ -2570,7 +2573,7 @@ struct Sim final : ssn_sim {
           switch (it.type) {
             case IT_MATVEC:
               if (xb <= 48 * 1024) {
-                const bool r1 = it.rows <= 4096;
+                const bool r1 = it.rows <= matvec_r1_max;
                 if (r1) {
                   ssn::MatvecArgs<T> a{it.Wm, it.src, it.dst, it.rows, it.cols, it.ld, it.set};
                   if (ao < 0) ao = (long long)put(&a, sizeof a);
