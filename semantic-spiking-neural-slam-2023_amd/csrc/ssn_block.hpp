@@ -235,13 +235,12 @@ __device__ inline f32x2 lif_input_part(f32x2 Jm1, f32x2& w, f32x2 W0, f32x2 em, 
   // Wn = clamp(spk * 2^100 - U) sits between the reciprocals and their first reader: the wait state a non-transcendental reader
   // of a transcendental's result needs is filled by an instruction that has to be issued anyway (the compiler's hazard recognizer
   // does not look inside inline asm, so the order is fixed by ONE asm statement: Wn, then u = U * rc)
-  f32x2 Wn, u;
+  // nu = clamp(K tau_ref + u (p0 + u (p1 + u p2))): the spike time without v_log (see the table above)
+  f32x2 Wn, u, P, nu;
   asm("v_pk_fma_f32 %0, %2, %3, %4 neg_lo:[0,0,1] neg_hi:[0,0,1] clamp\n\t"
       "v_pk_mul_f32 %1, %4, %5"
       : "=&v"(Wn), "=v"(u)
       : "v"(spk), "s"(big), "v"(U), "v"(rc));
-  // nu = clamp(K tau_ref + u (p0 + u (p1 + u p2))): the spike time without v_log (see the table above)
-  f32x2 P, nu;
   asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(u), "v"((f32x2)(c.p2)), "s"((f32x2)(c.p1)));
   asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(P) : "v"(u), "v"(P), "s"((f32x2)(c.p0)));
   asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(nu) : "v"(u), "v"(P), "s"((f32x2)(c.ktau_ref)));
