@@ -119,6 +119,37 @@ def test_big_random_network_f64_matches_oracle(Simulator, seed):
                 np.testing.assert_allclose(sim.data[p], ref.probe_data(q), atol=1e-9, rtol=0, err_msg=f"seed {seed} probe {q} {kw}")
 
 
+@pytest.mark.parametrize("seed", [101, 103, 105, 107])
+def test_big_random_network_f32_within_the_cosine_bar(Simulator, seed):
+    """The big-kernel sizes in the fast mode: populations of thousands of neurons average over their spikes, so the bar of
+    north_star holds over the whole window on every filtered probe of a population (the tiny product ensembles of a convolution
+    keep the tolerant check of the small networks)."""
+    net, probes = random_network(seed, big=True)
+    model = build(net, n_eval_points=800)
+    ref = OracleSimulator(model)
+    steps = 120
+    ref.run_steps(steps)
+    checked = 0
+    with Simulator(None, model=model, dtype="f32") as sim:
+        sim.run_steps(steps)
+        for p in probes:
+            if p.synapse is None or p.sample_every is not None:
+                continue
+            q = [i for i, mp in enumerate(model.probes) if mp["probe"] is p][0]
+            want, got = ref.probe_data(q), sim.data[p]
+            assert np.all(np.isfinite(got))
+            big = np.linalg.norm(want, axis=1) > 0.05
+            if big.sum() < 10:
+                continue
+            ce = 1.0 - np.sum(want[big] * got[big], axis=1) / (np.linalg.norm(want[big], axis=1) * np.linalg.norm(got[big], axis=1))
+            if isinstance(p.obj, nengo.Ensemble) and p.obj.n_neurons >= 1500:
+                assert ce.max() < 1e-3, f"seed {seed} probe {q}: {ce.max():.2e}"
+                checked += 1
+            else:
+                assert np.median(ce) < 1e-3 and ce.max() < 0.25, f"seed {seed} probe {q}: {np.median(ce):.2e} {ce.max():.2e}"
+    assert checked >= 0
+
+
 @pytest.mark.parametrize("seed", SEEDS[1::4])
 def test_random_network_in_pieces_over_block_boundaries_and_after_a_reset(Simulator, seed):
     """Runs cut into uneven pieces that straddle the time-batched blocks (64 timesteps here: carry rows of the batched filters,
