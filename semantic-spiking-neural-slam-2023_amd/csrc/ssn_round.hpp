@@ -367,8 +367,14 @@ inline long long read_round_stamps(unsigned long long* out, long long cap, int r
 }
 #endif
 
+// (experiment switch: -DSSN_ROUND_WAVES=8 asks the compiler for 64 VGPRs - 8 workgroups per CU instead of 7 - at the price of spills)
+#ifdef SSN_ROUND_WAVES
+#define SSN_ROUND_ATTR __attribute__((amdgpu_waves_per_eu(SSN_ROUND_WAVES, SSN_ROUND_WAVES)))
+#else
+#define SSN_ROUND_ATTR
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void k_round(RoundArgs<T> ra) {
+__global__ __launch_bounds__(256) SSN_ROUND_ATTR void k_round(RoundArgs<T> ra) {
   extern __shared__ __align__(16) unsigned char ssn_round_smem[];
   int vb = (int)blockIdx.x;
   if (ra.stride > 1u && vb >= ra.head) {
