@@ -65,7 +65,7 @@ def small_pathint(ssp_dim=7, n=64, T=2.0, seed=1, limit=0.5, **kw):
     return H.make_pathint_model(space, path, vels, n, **kw)
 
 
-def random_network(seed, big=False, shardable=False):
+def random_network(seed, big=False, shardable=False, learned_probes=False):
     """(``big``: populations of 1500 - 9000 neurons, arrays of up to 20 x 2600, 64 - 128-point convolutions - the sizes at which the
     device leaves the glue micro-operators for its big kernels.)
     Nodes, ensembles of every neuron type, an ensemble array, pass-through nodes; decoded connections with functions and
@@ -144,7 +144,7 @@ def random_network(seed, big=False, shardable=False):
         # every ensemble gets at least one input, from something declared before it (directly or through a synapse)
         targets = [(e, d) for e, d in ens] + ([(ea.input, arr_out[1])] if arr_out else []) + passes
         producers = list(sources)
-        learned = None
+        learned = voja_conn = None
         for post, d_post in targets:
             pre, d_pre = producers[rng.randint(0, len(producers))]
             is_ens = isinstance(pre, nengo.Ensemble)
@@ -205,7 +205,7 @@ def random_network(seed, big=False, shardable=False):
                 # (the builder takes Voja on a plain Node -> Ensemble connection, as the reference's memory has it: associativememory.py:31)
                 wv, phv = rng.uniform(2.0, 9.0, size=d_post), rng.uniform(0, 6.28, size=d_post)
                 vsrc = nengo.Node(lambda t, w=wv, ph=phv: 0.6 * np.sin(w * t + ph))
-                vc = nengo.Connection(vsrc, post, synapse=None,
+                vc = voja_conn = nengo.Connection(vsrc, post, synapse=None,
                                       learning_rule_type=nengo.Voja(learning_rate=float(rng.choice([1e-3, 5e-3])), post_synapse=None))
                 if rng.rand() < 0.5:
                     lsig = nengo.Node(lambda t: -1.0 if (t % 0.05) < 0.02 else 0.0)
@@ -227,4 +227,9 @@ def random_network(seed, big=False, shardable=False):
             probes.append(nengo.Probe(arr_out[0], synapse=0.01))
         if not probes:
             probes.append(nengo.Probe(ens[0][0], synapse=0.01))
+        if learned_probes:      # (after everything random, so that the network of a seed is the same with and without them)
+            if learned is not None:
+                probes.append(nengo.Probe(learned, "weights", sample_every=0.01))
+            if voja_conn is not None:
+                probes.append(nengo.Probe(voja_conn.learning_rule, "scaled_encoders", sample_every=0.02))
     return net, probes

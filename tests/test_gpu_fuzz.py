@@ -74,6 +74,31 @@ def test_random_network_f32_within_the_cosine_bar(Simulator, seed):
             assert np.median(ce) < 1e-3 and ce[:40].max() < 1e-3 and ce.max() < 0.25, f"seed {seed} probe {q}: {np.median(ce):.2e} {ce.max():.2e}"
 
 
+@pytest.mark.parametrize("seed", [2, 3, 4, 6, 7, 8, 9, 10, 13, 23, 28, 37, 47, 48, 55, 64])
+def test_random_network_learned_decoders_and_encoders_match_oracle(Simulator, seed):
+    """Seeds whose network has a PES and / or a Voja rule, with the learned signals themselves probed - `Probe(conn, "weights")`,
+    `Probe(conn.learning_rule, "scaled_encoders")` (reference run_slam.py:263-268, run_slam_map_gif.py:208-209) - next to
+    everything else: the round plan's PES and Voja bodies (rows packed 32 / 8 per workgroup, the activity filter folded into the
+    update) and the eager plan on learned matrices of every shape the generator draws."""
+    net, probes = random_network(seed, learned_probes=True)
+    assert any(p.attr in ("weights", "scaled_encoders") for p in probes)
+    model = build(net)
+    ref = OracleSimulator(model)
+    steps = 150
+    ref.run_steps(steps)
+    for kw in (dict(), dict(steps_per_graph=1)):
+        with Simulator(None, model=model, dtype="f64", **kw) as sim:
+            sim.run_steps(60)
+            sim.run_steps(steps - 60)
+            for p in probes:
+                q = [i for i, mp in enumerate(model.probes) if mp["probe"] is p][0]
+                want, got = ref.probe_data(q), sim.data[p]
+                assert got.shape == want.shape
+                np.testing.assert_allclose(got, want, atol=1e-9, rtol=0, err_msg=f"seed {seed} probe {q} ({p.attr}) {kw}")
+                if p.attr in ("weights", "scaled_encoders"):
+                    assert np.abs(want[-1] - want[0]).max() > 0, f"seed {seed}: the rule never moved its matrix"
+
+
 @pytest.mark.parametrize("seed", SEEDS[::3])
 def test_random_network_under_the_opt_in_plans(Simulator, seed):
     """The same networks with the planner's size thresholds and switches moved so that small graphs take the paths of big ones:
@@ -106,7 +131,7 @@ def test_big_random_network_f64_matches_oracle(Simulator, seed):
     """The same generator at the sizes where the device leaves the glue micro-operators for its big kernels: dense products as
     grids of row blocks (fused with the neuron update from 4097 rows on), segmented spike lists and spike-sparse decodes,
     ensemble arrays with several workgroups per ensemble, transforms of 64 - 128 points."""
-    net, probes = random_network(seed, big=True)
+    net, probes = random_network(seed, big=True, learned_probes=True)     # (learned decoders / encoders probed where the seed has a rule)
     model = build(net, n_eval_points=800)
     ref = OracleSimulator(model)
     steps = 80

@@ -120,7 +120,7 @@ def test_random_networks_lowering_equals_the_graph_walk(seed):
     """Seeded random networks (helpers.random_network: nodes, ensembles of every neuron type, an ensemble array, pass-through
     nodes, decoded / direct / recurrent connections, probes on everything; the same generator feeds the GPU fuzz tests):
     the lowered operator list - merged, pruned, partitioned into stages - against the object-graph interpreter."""
-    net, probes = random_network(seed)
+    net, probes = random_network(seed, learned_probes=True)      # (+ the learned decoders / encoders where the seed has a rule)
     model = build(net)
     ref = OracleSimulator(model)
     walk = GraphWalkSimulator(net, model)
