@@ -13,7 +13,7 @@ fused = chains = 0
 bad = []
 for seed in range(lo, hi):
     try:
-        net, probes = random_network(seed, big=big)
+        net, probes = random_network(seed, big=big, learned_probes=True)
         model = build(net, n_eval_points=800) if big else build(net)
         ref = OracleSimulator(model); ref.run_steps(120)
         for dtype, kw in (("f64", {}), ("f64", dict(steps_per_graph=1))):
