@@ -73,6 +73,7 @@ def random_network(seed, big=False, shardable=False, learned_probes=False):
     connections only forwards in declaration order (no algebraic loops), an optional PES rule; probes with and without
     synapses on everything."""
     rng = np.random.RandomState(seed)
+    rng2 = np.random.RandomState(seed + 7919)       # later additions draw from here: the networks of old seeds keep their shape
     probes = []
     with nengo.Network(seed=seed) as net:
         n_in = rng.randint(1, 3)
@@ -96,6 +97,14 @@ def random_network(seed, big=False, shardable=False, learned_probes=False):
             d = int(rng.choice([1, 2, 3, 4, 9, 17, 20])) if not big else int(rng.choice([3, 20, 33, 64]))
             n = int(rng.choice([30, 64, 100, 257, 300, 700, 1100])) if not big else int(rng.choice([1500, 4500, 9000]))
             nt = [nengo.LIF(), nengo.LIF(), nengo.LIF(tau_rc=0.03, tau_ref=0.001), nengo.LIFRate(), nengo.RectifiedLinear()][rng.randint(0, 5)]
+            if rng2.rand() < 0.35:                   # other parameters of the same types: amplitude, a voltage floor below zero, time constants
+                amp_ = float(rng2.choice([0.5, 2.0]))
+                if type(nt) is nengo.LIF:
+                    nt = [nengo.LIF(amplitude=amp_), nengo.LIF(min_voltage=-1.0), nengo.LIF(tau_rc=0.05, tau_ref=0.0015, amplitude=amp_)][rng2.randint(0, 3)]
+                elif type(nt) is nengo.LIFRate:
+                    nt = [nengo.LIFRate(amplitude=amp_), nengo.LIFRate(tau_rc=0.04, tau_ref=0.001)][rng2.randint(0, 2)]
+                else:
+                    nt = nengo.RectifiedLinear(amplitude=amp_)
             kw = {}
             if rng.rand() < 0.3:
                 kw["intercepts"] = nengo.Uniform(-0.5, 0.9)
