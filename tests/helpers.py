@@ -112,6 +112,10 @@ def random_network(seed, big=False, shardable=False, learned_probes=False):
             if rng.rand() < 0.2:
                 enc = np.random.RandomState(seed * 131 + k).randn(n, d)
                 kw["encoders"] = enc / np.linalg.norm(enc, axis=1, keepdims=True)
+            given_gb = rng2.rand() < 0.15
+            if given_gb and "intercepts" not in kw:      # gain and bias given instead of solved from intercepts / maximum rates
+                g2 = np.random.RandomState(seed * 977 + k)
+                kw["gain"], kw["bias"] = g2.uniform(0.5, 2.5, size=n), g2.uniform(-1.0, 1.5, size=n)
             e = nengo.Ensemble(n, d, neuron_type=nt, radius=float(rng.choice([1.0, 1.5])), **kw)
             ens.append((e, d))
             objs.append((e, d))
@@ -119,7 +123,12 @@ def random_network(seed, big=False, shardable=False, learned_probes=False):
             K, dk = int(rng.choice([3, 8, 21])), int(rng.choice([1, 2]))
             if big:
                 K, dk = int(rng.choice([6, 20])), int(rng.choice([1, 2, 3]))
-            ea = nengo.EnsembleArray(int(rng.choice([40, 90])) if not big else int(rng.choice([1200, 2600])), K, ens_dimensions=dk)
+            ea_kw = {}
+            if rng2.rand() < 0.3:                       # arrays of other neuron types / radii (the generic array body instead of the LIF fast path)
+                ea_kw["neuron_type"] = [nengo.LIFRate(), nengo.RectifiedLinear(), nengo.LIF(tau_rc=0.03, tau_ref=0.001), nengo.LIF(min_voltage=-0.5)][rng2.randint(0, 4)]
+            if rng2.rand() < 0.3:
+                ea_kw["radius"] = 1.5
+            ea = nengo.EnsembleArray(int(rng.choice([40, 90])) if not big else int(rng.choice([1200, 2600])), K, ens_dimensions=dk, **ea_kw)
             objs.append((ea.input, K * dk))
             arr_out = (ea.output, K * dk)
         else:
@@ -236,6 +245,9 @@ def random_network(seed, big=False, shardable=False, learned_probes=False):
             probes.append(nengo.Probe(arr_out[0], synapse=0.01))
         if not probes:
             probes.append(nengo.Probe(ens[0][0], synapse=0.01))
+        if arr_out and rng2.rand() < 0.4:       # a second, function-valued output of the array (EnsembleArray.add_output, reference binding.py:304-306)
+            sq = ea.add_output("square", lambda x: x[0] ** 2)
+            probes.append(nengo.Probe(sq, synapse=0.01))
         if learned_probes:      # (after everything random, so that the network of a seed is the same with and without them)
             if learned is not None:
                 probes.append(nengo.Probe(learned, "weights", sample_every=0.01))
