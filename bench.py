@@ -512,8 +512,8 @@ def pathint_main(args):
             if k > 0:
                 sim.run_steps(k * args.block, profile=True, collect=False)
         else:
-            for _ in range(k):
-                runner.run_block()
+            if k > 0:
+                runner.run_steps(k * args.block)       # (device path: one simulator call per exchange interval, not per block)
 
     run_blocks(args.warmup)
     if runner is not None:
@@ -542,7 +542,7 @@ def pathint_main(args):
         "config": {"workload": f"PathIntegration 2-D ssp_dim={space.ssp_dim} pi_n_neurons={args.pi_n_neurons}/VCO "
                                f"({K} VCOs, {N} LIF neurons), configs[1]",
                    "timesteps_per_step": args.block, "dt": dt, "eval_points_per_vco": eval_points_label(args),
-                   "parallelism": "1 GPU" if not sharded else f"VCO-sharded x{world}, all-gather per {args.block} steps ({args.dist_backend})",
+                   "parallelism": "1 GPU" if not sharded else f"VCO-sharded x{world}, all-gather per {args.block * (runner.gather_every if runner._device_exchange() else 1)} steps ({args.dist_backend})",
                    "build_seconds": round(build_s, 1), "build_cache": (model.stats.get("cache") if model is not None else None)},
     }
 

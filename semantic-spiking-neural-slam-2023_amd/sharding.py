@@ -386,6 +386,11 @@ class ShardedPathIntegration:
         done = 0
         while done < n:
             c = min(self.block, n - done)
+            if self._device_exchange():
+                # device path: everything up to the next exchange in ONE call of the simulator - it cuts the run into its blocks
+                # itself, and a call per block would put a host synchronisation and a cold launch queue behind every block
+                # (bench.py, run_blocks: 3.09 vs 3.03 ms per block)
+                c = min(n - done, max(1, self.gather_every * self.block - self._ungathered))
             self.run_block(c)
             done += c
 
